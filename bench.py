@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sphere-set depth rasterizer, forward + backward.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): a batch of 256 crops of 128x128 px, 41
+spheres per crop from 256 JointAngleDataset poses (torch seed 0 on rank 0, seed
+r on rank r) pushed through forward kinematics; upstream gradient N(0,1).  One
+STEP = one forward launch (spheres -> depth[256,128,128]) + one backward launch
+(grad_depth -> grad_spheres[256,41,4]) through the C ABI, inputs and outputs
+resident in HBM.  Multi-GPU: every rank rasterizes its own 256 crops (weak
+scaling, no data-path collective -- crops are independent); value =
+crops of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (the driver's contract), with
+  roofline      the dominant kernel's algorithmic HBM bytes / its mean launch
+                duration (HIP events on the launching stream) vs the 8 TB/s peak
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference algorithm)
+                timed on this host on the same batch, rank 0, N=1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+S = 128
+BATCH = 256
+J = 41
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_inputs(rank, device):
+    from spherehand_amd import hand_model
+    from spherehand_amd.joint_angle import sample_poses
+    from spherehand_amd.render import HandBallPrimitiveRender
+    from spherehand_amd.kinematicsTransformation import HandTransformationMat
+    mesh = hand_model.load_mesh()
+    params = sample_poses(BATCH, seed=rank)
+    fk = HandTransformationMat([b["offset_matrix"].astype("float32") for b in mesh["bones"]])
+    hbr = HandBallPrimitiveRender(mesh["bones"], S, S)
+    with torch.no_grad():
+        spheres = hbr.spheres(fk(params)).contiguous()          # [256,41,4] on CPU (torch plumbing)
+    g = torch.Generator().manual_seed(1)
+    grad = torch.randn(BATCH, S, S, generator=g)
+    return spheres.to(device), grad.to(device)
+
+
+def cpu_baseline(spheres_host, grad_host, budget_s=12.0):
+    from oracle import oracle
+    oracle.build()
+    cores = oracle.num_threads()
+    oracle.sphere_raster_fwd(spheres_host, S, S, want_argmin=False)   # warm-up
+    oracle.sphere_raster_bwd(spheres_host, grad_host)
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        oracle.sphere_raster_fwd(spheres_host, S, S, want_argmin=False)
+        oracle.sphere_raster_bwd(spheres_host, grad_host)
+        passes += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or passes >= 20:
+            break
+    return {"value": round(passes * BATCH / el, 1), "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": "%d fwd+bwd passes over the same 256-crop 128x128 batch (%.1f s, OpenMP over crops)"
+                      % (passes, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--launch", choices=["direct", "graph"], default="direct",
+                    help="direct: two C-ABI calls per step; graph: one hipGraph replay per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from spherehand_amd import _lib
+    lib = _lib.lib()
+    spheres, grad = make_inputs(rank, dev)
+    depth = torch.empty(BATCH, S, S, device=dev)
+    gsph = torch.empty(BATCH, J, 4, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    sp, gp, dp, op = spheres.data_ptr(), grad.data_ptr(), depth.data_ptr(), gsph.data_ptr()
+
+    def fwd(s):
+        _lib.check(lib.shr_sphere_raster_fwd(sp, BATCH, J, S, S, dp, None, s), "fwd")
+
+    def bwd(s):
+        _lib.check(lib.shr_sphere_raster_bwd(sp, gp, BATCH, J, S, S, op, s), "bwd")
+
+    with torch.cuda.stream(stream):
+        sh = stream.cuda_stream
+        graph = None
+        if args.launch == "graph":
+            fwd(sh); bwd(sh)
+            stream.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                fwd(sh); bwd(sh)
+
+        def step():
+            if graph is not None:
+                graph.replay()
+            else:
+                fwd(sh); bwd(sh)
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # per-kernel mean launch duration: HIP events on the launching stream
+        # around R back-to-back launches of one kernel
+        def kernel_us(fn, reps=200):
+            for _ in range(20):
+                fn(sh)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            best = None
+            for _ in range(5):
+                e0.record(stream)
+                for _ in range(reps):
+                    fn(sh)
+                e1.record(stream)
+                e1.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / reps
+                best = us if best is None else min(best, us)
+            return best
+        fwd_us = kernel_us(fwd)
+        bwd_us = kernel_us(bwd)
+
+    if rank == 0:
+        bytes_fwd = BATCH * (4 * S * S + 16 * J)
+        bytes_bwd = BATCH * (4 * S * S + 16 * J + 16 * J)
+        dom, dom_us, dom_bytes = ("sphere_raster_bwd_kernel", bwd_us, bytes_bwd) if bwd_us >= fwd_us else \
+            ("sphere_raster_fwd_kernel", fwd_us, bytes_fwd)
+        achieved = dom_bytes / (dom_us * 1e-6) / 1e9
+        out = {
+            "metric": "depth crops/s (raster fwd+bwd, 128x128, batch 256)",
+            "value": round(world * BATCH * args.steps / elapsed, 1),
+            "unit": "crops/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 6),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch-256 128x128 sphere raster fwd+bwd, 41 spheres/crop, "
+                                   "JointAngleDataset poses (seed 0), grad N(0,1)",
+                       "crops_per_gpu": BATCH, "image": [S, S], "spheres_per_crop": J,
+                       "launch": args.launch, "parallelism": "batch-sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": dom_bytes,
+                         "launch_us": {"fwd": round(fwd_us, 3), "bwd": round(bwd_us, 3)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spheres.cpu().numpy(), grad.cpu().numpy())
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+/* spherehand_hip.h -- C ABI of libspherehand_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the rasterize-and-fit hot path of melonwan/sphereHand.
+ * Plain pointers and sizes only: no torch / ATen types cross this boundary.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *   - buffers are caller-allocated, contiguous, row-major fp32 unless noted;
+ *     outputs are fully overwritten (no accumulate-into semantics);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *     kernels are enqueued on it and the call returns without synchronising;
+ *     nothing is allocated, freed or synchronised inside the library;
+ *   - return value: 0 (SHR_OK) or a negative SHR_E* code; a positive value is
+ *     a hipError_t reported by the launch.  shr_error_string() names either.
+ *   - image grid: pixel (v,u) has model-space coordinates
+ *       xg = (u - W/2)*300/W , yg = (v - H/2)*300/H            (mm)
+ *     (reference mesh/render.py:31-32).
+ *
+ * Each entry point cites the reference interface it replaces
+ * (file:line relative to the reference repo root).
+ */
+#ifndef SPHEREHAND_HIP_H
+#define SPHEREHAND_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHR_OK 0
+#define SHR_EINVAL (-1)     /* null pointer / non-positive size / misaligned */
+#define SHR_ETOOLARGE (-2)  /* size beyond what the kernels index (see each fn) */
+#define SHR_ENODEVICE (-3)  /* no gfx950 device visible to the process */
+
+#define SHR_MAX_SPHERES 64  /* spheres per crop (reference: 41) */
+#define SHR_ARGMIN_NONE 255 /* argmin value of a pixel no sphere owns */
+
+/* Library / device introspection ------------------------------------------ */
+int shr_abi_version(void);               /* bumps on any signature change */
+const char *shr_error_string(int code);  /* static string, never NULL */
+/* 0 if a gfx950 device is current; fills name (<= name_len bytes, may be NULL),
+ * compute-unit count and peak HBM clock-independent info are for logging only */
+int shr_device_info(char *name_host, int name_len, int *num_cu_host);
+
+/* Sphere-set depth rasterizer ------------------------------------------------
+ * Replaces BallRender.forward + the min over the sphere axis:
+ *   mesh/render.py:26-53 (BallRender), :87-89 (HandBallPrimitiveRender),
+ *   mesh/multiview_utility.py:72-76 (MutualProjection).
+ * spheres[N,J,4] = (x, y, z, r) per sphere in the TARGET view's frame, mm.
+ * depth[N,H,W]   = min_j ( hit_j ? z_j - sqrt(q_j) : 100 ),
+ *                  q_j = (r*r - (xg-x)^2) - (yg-y)^2 , hit_j <=> q_j > 0.01f.
+ * argmin[N,H,W] (uint8, may be NULL): index of the owning sphere, 255 where
+ * the pixel is background.  J <= SHR_MAX_SPHERES.  With J == 1 this IS
+ * BallRender.forward (one map per sphere).
+ * Bit-exact with the reference's fp32 operation sequence (no FMA contraction,
+ * IEEE sqrt). */
+int shr_sphere_raster_fwd(const float *spheres, int N, int J, int H, int W,
+                          float *depth, uint8_t *argmin, void *stream);
+
+/* Analytic backward of the above (the reference gets it from autograd of
+ * mesh/render.py:37-52 + torch.min): for upstream grad_depth[N,H,W],
+ *   grad_spheres[N,J,4] = sum over the pixels sphere j owns of
+ *     g * ( -(xg-x)/sqrt(q), -(yg-y)/sqrt(q), 1, -r/sqrt(q) ).
+ * The owner of every pixel is recomputed (no saved state).  Deterministic:
+ * fixed-order in-wave, in-block reductions, no float atomics. */
+int shr_sphere_raster_bwd(const float *spheres, const float *grad_depth, int N,
+                          int J, int H, int W, float *grad_spheres, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPHEREHAND_HIP_H */

@@ -1,0 +1,62 @@
+"""ctypes loader for libspherehand_hip.so (the C ABI in include/spherehand_hip.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing
+any op raises.  Build it with ``python -m spherehand_amd.build``.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_PKG, "libspherehand_hip.so")
+ABI_VERSION = 1
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> argtypes; every symbol include/spherehand_hip.h declares
+SIGNATURES = {
+    "shr_abi_version": ([], _i),
+    "shr_error_string": ([_i], ctypes.c_char_p),
+    "shr_device_info": ([ctypes.c_char_p, _i, ctypes.POINTER(_i)], _i),
+    "shr_sphere_raster_fwd": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
+    "shr_sphere_raster_bwd": ([_vp, _vp, _i, _i, _i, _i, _vp, _vp], _i),
+}
+
+_lib = None
+
+
+class SphereHandLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise SphereHandLibraryError(
+            "%s not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -m spherehand_amd.build`." % SO_PATH)
+    try:
+        h = ctypes.CDLL(SO_PATH)
+    except OSError as e:  # pragma: no cover
+        raise SphereHandLibraryError("cannot load %s: %s" % (SO_PATH, e))
+    for name, (args, res) in SIGNATURES.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError:
+            raise SphereHandLibraryError("%s does not export %s (stale build?)" % (SO_PATH, name))
+        fn.argtypes = args
+        fn.restype = res
+    v = h.shr_abi_version()
+    if v != ABI_VERSION:
+        raise SphereHandLibraryError("ABI version %d, expected %d: rebuild" % (v, ABI_VERSION))
+    _lib = h
+    return h
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().shr_error_string(rc).decode()
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg, rc))

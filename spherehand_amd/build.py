@@ -1,0 +1,51 @@
+"""Build libspherehand_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m spherehand_amd.build [--force]
+
+No torch headers, no JIT cache: the .so lands next to this file so it travels
+with the source tree.  hipcc cross-compiles gfx950 without a GPU present.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+SO = os.path.join(PKG, "libspherehand_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off",                           # parity: one rounding per written op
+    "-fhip-fp32-correctly-rounded-divide-sqrt",   # IEEE sqrt/div (hipcc default, stated)
+    "-fno-fast-math", "-Wall", "-Wno-unused-function",
+]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")))
+
+
+def stale():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = sources() + glob.glob(os.path.join(PKG, "csrc", "*.h")) + \
+        glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not (force or stale()):
+        return SO
+    cmd = [HIPCC] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "csrc"),
+                             "-o", SO] + sources()
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

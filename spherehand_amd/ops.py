@@ -1,0 +1,75 @@
+"""Tensor-level entry points over the C ABI (device memory + stream plumbing only).
+
+Every function takes CUDA(HIP) fp32 contiguous tensors, allocates its outputs
+with torch, and enqueues the hand-written HIP kernels on torch's CURRENT stream.
+Preconditions mirror the reference extension's CHECK_INPUT
+(mesh/cuda_kernel/depth_rasterization_cuda.cpp:11-19): a violation raises
+RuntimeError.
+"""
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check_input(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s" % (name, dtype))
+
+
+def sphere_raster_fwd(spheres, H, W, want_argmin=False):
+    """spheres [N,J,4] (x,y,z,r) -> depth [N,H,W] (and uint8 argmin [N,H,W])."""
+    _check_input(spheres, "spheres")
+    if spheres.dim() != 3 or spheres.shape[2] != 4:
+        raise RuntimeError("spheres must be [N,J,4]")
+    N, J, _ = spheres.shape
+    with torch.cuda.device(spheres.device):
+        depth = torch.empty((N, H, W), dtype=torch.float32, device=spheres.device)
+        arg = torch.empty((N, H, W), dtype=torch.uint8, device=spheres.device) if want_argmin else None
+        _lib.check(_lib.lib().shr_sphere_raster_fwd(_ptr(spheres), N, J, H, W, _ptr(depth), _ptr(arg),
+                                                    _stream()), "shr_sphere_raster_fwd")
+    return (depth, arg) if want_argmin else depth
+
+
+def sphere_raster_bwd(spheres, grad_depth):
+    """grad_depth [N,H,W] -> grad_spheres [N,J,4]."""
+    _check_input(spheres, "spheres")
+    _check_input(grad_depth, "grad_depth")
+    N, J, _ = spheres.shape
+    if grad_depth.dim() != 3 or grad_depth.shape[0] != N:
+        raise RuntimeError("grad_depth must be [N,H,W]")
+    H, W = grad_depth.shape[1], grad_depth.shape[2]
+    with torch.cuda.device(spheres.device):
+        out = torch.empty((N, J, 4), dtype=torch.float32, device=spheres.device)
+        _lib.check(_lib.lib().shr_sphere_raster_bwd(_ptr(spheres), _ptr(grad_depth), N, J, H, W,
+                                                    _ptr(out), _stream()), "shr_sphere_raster_bwd")
+    return out
+
+
+class SphereDepthRaster(torch.autograd.Function):
+    """depth[N,H,W] = min over the J spheres of a crop (SURVEY 8b "new
+    differentiable op").  Differentiable w.r.t. spheres[N,J,4] = (x,y,z,r)."""
+
+    @staticmethod
+    def forward(ctx, spheres, H, W):
+        spheres = spheres.contiguous()
+        ctx.save_for_backward(spheres)
+        return sphere_raster_fwd(spheres, H, W)
+
+    @staticmethod
+    def backward(ctx, grad_depth):
+        (spheres,) = ctx.saved_tensors
+        return sphere_raster_bwd(spheres, grad_depth.contiguous()), None, None

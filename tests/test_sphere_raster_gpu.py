@@ -1,0 +1,159 @@
+"""GPU parity: hand-written HIP sphere rasterizer (through the C ABI) vs the CPU
+oracle and the reference's golden vectors.  Depth: BIT-EXACT.  Gradients: fp32
+summation order differs from the oracle's fp64 accumulation -> tolerance
+|err| <= 1e-5 * max|grad| + 1e-4 (stated per test)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import bits, golden, spheres_from
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from spherehand_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_g1_rest_pose(ops):
+    g = golden("g1_rest_pose.npz")
+    sp = dev(spheres_from(g["centres"], g["radii"]))
+    for S in (64, 128, 256):
+        d, a = ops.sphere_raster_fwd(sp, S, S, want_argmin=True)
+        ref = g["depth%d_ieee" % S]
+        assert np.array_equal(bits(d.cpu().numpy()[0]), bits(ref)), S
+        fg = ref < 100
+        assert np.array_equal(a.cpu().numpy()[0][fg], g["argmin%d" % S][fg])
+        assert np.all(a.cpu().numpy()[0][~fg] == 255)
+
+
+def test_g3_batch256_full_size(ops, oracle):
+    """BASELINE config 2 inputs: 256 crops, 128x128, 41 spheres."""
+    g = golden("g3_batch256.npz")
+    sp_h = spheres_from(g["centres"], g["radii"])
+    d, a = ops.sphere_raster_fwd(dev(sp_h), 128, 128, want_argmin=True)
+    d = d.cpu().numpy()
+    sha = [hashlib.sha256(d[i].tobytes()).hexdigest() for i in range(256)]
+    assert sha == list(g["depth_ieee_sha256"])
+    od, oa = oracle.sphere_raster_fwd(sp_h, 128, 128)
+    assert np.array_equal(bits(d), bits(od))
+    assert np.array_equal(a.cpu().numpy(), oa)
+    # without the argmin output: same depth
+    d2 = ops.sphere_raster_fwd(dev(sp_h), 128, 128).cpu().numpy()
+    assert np.array_equal(bits(d2), bits(d))
+
+
+def test_g3_backward(ops, oracle):
+    g = golden("g3_batch256.npz")
+    sp_h = spheres_from(g["centres"], g["radii"])
+    gd = np.random.RandomState(int(g["g_seed"])).standard_normal((256, 128, 128)).astype(np.float32)
+    gs = ops.sphere_raster_bwd(dev(sp_h), dev(gd)).cpu().numpy()
+    og = oracle.sphere_raster_bwd(sp_h, gd)
+    tol = 1e-5 * np.abs(og).max() + 1e-4
+    assert np.abs(gs - og).max() <= tol
+    ref = g["grad_centres"]                       # reference autograd
+    assert np.abs(gs[:, :, :3] - ref[:, :, :3]).max() <= tol
+    gr = gs[:, :, 3].reshape(8, 32, 41).sum(1)
+    assert np.abs(gr - g["grad_radii_chunk32"]).max() <= 1e-5 * np.abs(g["grad_radii_chunk32"]).max() + 1e-3
+    # deterministic: bit-identical on a second launch
+    gs2 = ops.sphere_raster_bwd(dev(sp_h), dev(gd)).cpu().numpy()
+    assert np.array_equal(bits(gs), bits(gs2))
+
+
+def test_ball_render_ragged_sizes(ops):
+    """J == 1 is BallRender.forward; odd sizes take the scalar-store path."""
+    g = golden("g_ballrender.npz")
+    for t in "abcde":
+        W, H, N = (int(x) for x in g[t + "_whn"])
+        sp = np.concatenate([g[t + "_centres"], g[t + "_radii"][:, None]], 1).reshape(N, 1, 4)
+        d = ops.sphere_raster_fwd(dev(sp), H, W).cpu().numpy()
+        assert np.array_equal(bits(d), bits(g[t + "_maps_ieee"])), t
+
+
+@pytest.mark.parametrize("N,J,H,W", [(5, 41, 64, 64), (3, 64, 96, 80), (4, 7, 53, 37), (2, 1, 8, 32),
+                                       (1, 3, 1, 1), (6, 2, 130, 258), (2, 41, 256, 256), (3, 5, 24, 100)])
+def test_random_spheres_vs_oracle(ops, oracle, N, J, H, W):
+    rs = np.random.RandomState(N * 1000 + J)
+    sp = np.concatenate([rs.uniform(-160, 160, (N, J, 2)), rs.uniform(-60, 120, (N, J, 1)),
+                         rs.uniform(0.05, 45, (N, J, 1))], -1).astype(np.float32)
+    d, a = ops.sphere_raster_fwd(dev(sp), H, W, want_argmin=True)
+    od, oa = oracle.sphere_raster_fwd(sp, H, W)
+    assert np.array_equal(bits(d.cpu().numpy()), bits(od))
+    assert np.array_equal(a.cpu().numpy(), oa)
+    gd = rs.standard_normal((N, H, W)).astype(np.float32)
+    gs = ops.sphere_raster_bwd(dev(sp), dev(gd)).cpu().numpy()
+    og = oracle.sphere_raster_bwd(sp, gd)
+    assert np.abs(gs - og).max() <= 1e-5 * np.abs(og).max() + 1e-4
+
+
+def test_every_sphere_a_candidate_everywhere(ops, oracle):
+    """Spheres bigger than the image, some deeper than the background: the min
+    may exceed 100 only where all J spheres hit (reference min over J maps)."""
+    sp = np.array([[[0, 0, 400, 300], [10, -5, 500, 350]],
+                   [[0, 0, 400, 300], [200, 0, 0, 20]]], np.float32)
+    d, a = ops.sphere_raster_fwd(dev(sp), 32, 64, want_argmin=True)
+    od, oa = oracle.sphere_raster_fwd(sp, 32, 64)
+    assert od[0].min() > 100.0
+    assert np.array_equal(bits(d.cpu().numpy()), bits(od))
+    assert np.array_equal(a.cpu().numpy(), oa)
+
+
+def test_nan_inf(ops, oracle):
+    sp = np.array([[[0, 0, 10, 20], [np.nan, 0, 0, 5]],
+                   [[0, 0, np.nan, 20], [50, 50, 0, 5]],
+                   [[np.inf, 0, 0, 20], [0, 0, 5, 30]],
+                   [[0, 0, 5, np.inf], [0, 0, 5, 30]]], np.float32)
+    d = ops.sphere_raster_fwd(dev(sp), 16, 32).cpu().numpy()
+    od = oracle.sphere_raster_fwd(sp, 16, 32, want_argmin=False)
+    assert np.array_equal(np.isnan(d), np.isnan(od))
+    assert np.array_equal(bits(d)[~np.isnan(od)], bits(od)[~np.isnan(od)])
+
+
+def test_empty_batch_and_errors(ops):
+    e = ops.sphere_raster_fwd(torch.empty((0, 41, 4), device="cuda"), 64, 64)
+    assert e.shape == (0, 64, 64)
+    with pytest.raises(RuntimeError):
+        ops.sphere_raster_fwd(torch.zeros(1, 41, 4), 64, 64)            # CPU tensor
+    with pytest.raises(RuntimeError):
+        ops.sphere_raster_fwd(torch.zeros(1, 4, 41, device="cuda").transpose(1, 2), 64, 64)
+    with pytest.raises(RuntimeError):
+        ops.sphere_raster_fwd(torch.zeros(1, 65, 4, device="cuda"), 64, 64)  # > SHR_MAX_SPHERES
+    with pytest.raises(RuntimeError):
+        ops.sphere_raster_fwd(torch.zeros(1, 41, 4, device="cuda", dtype=torch.float64), 64, 64)
+
+
+def test_backward_properties_full_size(ops):
+    """Size-independent properties at BASELINE size (256 x 128 x 128):
+    linearity in the upstream gradient, and sum_j dz_j == sum of g over the
+    foreground (every foreground pixel routes its g to exactly one sphere)."""
+    g = golden("g3_batch256.npz")
+    sp = dev(spheres_from(g["centres"], g["radii"]))
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    g1 = torch.randn(256, 128, 128, device="cuda", generator=gen)
+    g2 = torch.randn(256, 128, 128, device="cuda", generator=gen)
+    b1, b2 = ops.sphere_raster_bwd(sp, g1), ops.sphere_raster_bwd(sp, g2)
+    b12 = ops.sphere_raster_bwd(sp, 2.0 * g1 + g2)
+    assert (b12 - (2.0 * b1 + b2)).abs().max().item() <= 1e-5 * b12.abs().max().item() + 1e-3
+    depth = ops.sphere_raster_fwd(sp, 128, 128)
+    fg_sum = (g1.double() * (depth < 100)).sum(dim=(1, 2))
+    assert (b1[:, :, 2].double().sum(1) - fg_sum).abs().max().item() <= 1e-3
+    assert depth.max().item() == 100.0
+
+
+def test_autograd_function(ops):
+    g = golden("g1_rest_pose.npz")
+    sp = dev(spheres_from(g["centres"], g["radii"])).requires_grad_(True)
+    d = ops.SphereDepthRaster.apply(sp, 64, 64)
+    w = torch.linspace(-1, 1, 64 * 64, device="cuda").view(1, 64, 64)
+    (d * w).sum().backward()
+    assert sp.grad.shape == (1, 41, 4)
+    assert torch.isfinite(sp.grad).all() and sp.grad.abs().sum() > 0
