@@ -8,8 +8,8 @@
 Workload (BASELINE.json configs[1]): a batch of 256 crops of 128x128 px, 41
 spheres per crop from 256 JointAngleDataset poses (torch seed 0 on rank 0, seed
 r on rank r) pushed through forward kinematics; upstream gradient N(0,1).  One
-STEP = one forward launch (spheres -> depth[256,128,128]) + one backward launch
-(grad_depth -> grad_spheres[256,41,4]) through the C ABI, inputs and outputs
+STEP = one forward launch (spheres -> depth[256,128,128] + uint8 owner map) + one backward launch
+(grad_depth, owner map -> grad_spheres[256,41,4]) through the C ABI, inputs and outputs
 resident in HBM.  Multi-GPU: every rank rasterizes its own 256 crops (weak
 scaling, no data-path collective -- crops are independent); value =
 crops of all ranks / max-over-ranks time.
@@ -101,15 +101,16 @@ def main():
     lib = _lib.lib()
     spheres, grad = make_inputs(rank, dev)
     depth = torch.empty(BATCH, S, S, device=dev)
+    owner = torch.empty(BATCH, S, S, device=dev, dtype=torch.uint8)
     gsph = torch.empty(BATCH, J, 4, device=dev)
     stream = torch.cuda.Stream(device=dev)
-    sp, gp, dp, op = spheres.data_ptr(), grad.data_ptr(), depth.data_ptr(), gsph.data_ptr()
+    sp, gp, dp, op, ap = spheres.data_ptr(), grad.data_ptr(), depth.data_ptr(), gsph.data_ptr(), owner.data_ptr()
 
     def fwd(s):
-        _lib.check(lib.shr_sphere_raster_fwd(sp, BATCH, J, S, S, dp, None, s), "fwd")
+        _lib.check(lib.shr_sphere_raster_fwd(sp, BATCH, J, S, S, dp, ap, s), "fwd")
 
     def bwd(s):
-        _lib.check(lib.shr_sphere_raster_bwd(sp, gp, BATCH, J, S, S, op, s), "bwd")
+        _lib.check(lib.shr_sphere_raster_bwd(sp, gp, ap, BATCH, J, S, S, op, s), "bwd")
 
     with torch.cuda.stream(stream):
         sh = stream.cuda_stream
@@ -166,10 +167,13 @@ def main():
         bwd_us = kernel_us(bwd)
 
     if rank == 0:
-        bytes_fwd = BATCH * (4 * S * S + 16 * J)
-        bytes_bwd = BATCH * (4 * S * S + 16 * J + 16 * J)
-        dom, dom_us, dom_bytes = ("sphere_raster_bwd_kernel", bwd_us, bytes_bwd) if bwd_us >= fwd_us else \
-            ("sphere_raster_fwd_kernel", fwd_us, bytes_fwd)
+        # algorithmic bytes ("u8 argmin saved" variant: 165 808 B/crop fwd+bwd @128):
+        #   fwd writes depth f32 + owner u8, reads the spheres; bwd reads grad f32 + owner u8 +
+        #   spheres, writes grad_spheres
+        bytes_fwd = BATCH * (4 * S * S + S * S + 16 * J)
+        bytes_bwd = BATCH * (4 * S * S + S * S + 16 * J + 16 * J)
+        dom, dom_us, dom_bytes = ("sphere_zbuf_bwd_kernel", bwd_us, bytes_bwd) if bwd_us >= fwd_us else \
+            ("sphere_zbuf_fwd_kernel", fwd_us, bytes_fwd)
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
         out = {
             "metric": "depth crops/s (raster fwd+bwd, 128x128, batch 256)",

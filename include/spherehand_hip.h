@@ -43,6 +43,16 @@ const char *shr_error_string(int code);  /* static string, never NULL */
  * compute-unit count and peak HBM clock-independent info are for logging only */
 int shr_device_info(char *name_host, int name_len, int *num_cu_host);
 
+/* Launch-shape tuning / test hooks (process-wide, not thread-safe; results never
+ * depend on them).  *_LDS_BYTES cap the LDS a workgroup of the z-buffer kernels
+ * may take (decides rows per region and workgroups per CU); FORCE_GENERAL = 1
+ * routes every call to the general tile kernels. */
+#define SHR_TUNE_FWD_LDS_BYTES 1
+#define SHR_TUNE_FWD_OWNER_LDS_BYTES 2
+#define SHR_TUNE_BWD_LDS_BYTES 3
+#define SHR_TUNE_FORCE_GENERAL 4
+int shr_set_tuning(int key, int value);
+
 /* Sphere-set depth rasterizer ------------------------------------------------
  * Replaces BallRender.forward + the min over the sphere axis:
  *   mesh/render.py:26-53 (BallRender), :87-89 (HandBallPrimitiveRender),
@@ -62,10 +72,12 @@ int shr_sphere_raster_fwd(const float *spheres, int N, int J, int H, int W,
  * mesh/render.py:37-52 + torch.min): for upstream grad_depth[N,H,W],
  *   grad_spheres[N,J,4] = sum over the pixels sphere j owns of
  *     g * ( -(xg-x)/sqrt(q), -(yg-y)/sqrt(q), 1, -r/sqrt(q) ).
- * The owner of every pixel is recomputed (no saved state).  Deterministic:
- * fixed-order in-wave, in-block reductions, no float atomics. */
-int shr_sphere_raster_bwd(const float *spheres, const float *grad_depth, int N,
-                          int J, int H, int W, float *grad_spheres, void *stream);
+ * argmin: the owner map the forward wrote for the SAME spheres (fast path), or
+ * NULL to recompute the owners (slower, no saved state needed).
+ * Deterministic: fixed-order in-wave reductions, no float atomics. */
+int shr_sphere_raster_bwd(const float *spheres, const float *grad_depth,
+                          const uint8_t *argmin, int N, int J, int H, int W,
+                          float *grad_spheres, void *stream);
 
 #ifdef __cplusplus
 }

@@ -6,9 +6,16 @@ any op raises.  Build it with ``python -m spherehand_amd.build``.
 import ctypes
 import os
 
+# torch FIRST: the wheel bundles its own ROCm runtime (torch/lib/libamdhip64.so,
+# SONAME libamdhip64.so.7).  Loaded after torch, our library's NEEDED
+# libamdhip64.so.7 binds to that same runtime; loaded before torch, the process
+# would end up with two HIP runtimes (/opt/rocm's and torch's) and kernels
+# launched on torch's streams fail with hipErrorNoDevice.
+import torch  # noqa: F401  (device memory, streams: the plumbing this library sits on)
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libspherehand_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -20,7 +27,8 @@ SIGNATURES = {
     "shr_error_string": ([_i], ctypes.c_char_p),
     "shr_device_info": ([ctypes.c_char_p, _i, ctypes.POINTER(_i)], _i),
     "shr_sphere_raster_fwd": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
-    "shr_sphere_raster_bwd": ([_vp, _vp, _i, _i, _i, _i, _vp, _vp], _i),
+    "shr_sphere_raster_bwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp], _i),
+    "shr_set_tuning": ([_i, _i], _i),
 }
 
 _lib = None

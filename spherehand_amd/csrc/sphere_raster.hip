@@ -1,272 +1,93 @@
-// sphere_raster.hip -- sphere-set depth rasterizer, forward + analytic backward.
-//
-// Replaces (reference file:line): mesh/render.py:26-53 BallRender.forward and the
-// min over the sphere axis at mesh/render.py:89 / mesh/multiview_utility.py:76;
-// the backward replaces what autograd derives from those lines.
-//
-// Layout.  One workgroup per crop (grid.x) and per slice of the crop's tiles
-// (grid.y); a workgroup is `nwaves` wavefronts of 64.  The crop's J<=64 spheres
-// (x,y,z,r as one float4 each, 16*J bytes, one coalesced read) are staged in LDS
-// once per workgroup.  Every wave then walks 32x8-pixel tiles:
-//   1. lanes = spheres: lane j tests sphere j's extent against the tile,
-//      __ballot gives the 64-bit candidate mask (exact conservative cull, see
-//      tile_candidates());
-//   2. lanes = pixels: each lane owns 4 consecutive pixels of one row; the
-//      wave walks the set bits, the candidate's parameters are broadcast with
-//      v_readlane (SGPR operands), each lane keeps (min depth, owner) in
-//      registers;
-//   3. forward: one 16-byte store per lane (8 lanes = one 128-B line);
-//      backward: per owner sphere, a DPP wave sum of the four partials, added
-//      into the wave's private LDS row; rows are combined in wave order at the
-//      end -> deterministic, no float atomics.
-// Bounded by HBM: 4*H*W bytes written (fwd) / read (bwd) per crop + 16*J.
+// sphere_raster.hip -- C-ABI entry points of the sphere-set depth rasterizer and
+// the dispatch between the fast LDS z-buffer kernels (sphere_zbuf.h) and the
+// general tile kernels (sphere_tile.h).
+#include <stdlib.h>
 
-#include "common.h"
+#include "sphere_zbuf.h"
 
-namespace shr {
-
-constexpr float kBackground = 100.0f;  // mesh/render.py:52
-constexpr float kHitMin = 0.01f;       // mesh/render.py:41-42
-
-struct TileGeom {
-  int x0, y0;        // first pixel of the wave's tile
-  float yg;          // this lane's row coordinate
-  float xg[4];       // this lane's four column coordinates
-  int u0, v;         // this lane's first column / row
-};
-
-__device__ __forceinline__ TileGeom tile_geom(int tile, int tiles_x, const Axis &ax, const Axis &ay,
-                                              int lane) {
-  TileGeom g;
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  g.x0 = tx * kTileW;
-  g.y0 = ty * kTileH;
-  g.u0 = g.x0 + 4 * (lane & 7);
-  g.v = g.y0 + (lane >> 3);
-  g.yg = axis_coord(ay, g.v);
-#pragma unroll
-  for (int k = 0; k < 4; k++) g.xg[k] = axis_coord(ax, g.u0 + k);
-  return g;
-}
-
-// Candidate mask of a tile.  A pixel can only be hit if |fl(xg - x)| <= |r|:
-// fl(r*r) - fl(dx*dx) is exact-or-negative once |dx| > |r| (rounding is
-// monotonic), and q must exceed 0.01.  fl(xg - x) is monotonic in xg, so the
-// tile is culled iff fl(xlo - x) > |r| or fl(xhi - x) < -|r| (same for y): an
-// exact test, no slack needed.  Written as !(outside) so NaN is never culled.
-__device__ __forceinline__ unsigned long long tile_candidates(const float4 sph, bool valid,
-                                                              const TileGeom &g, const Axis &ax,
-                                                              const Axis &ay, int H, int W) {
-  const float xlo = axis_coord(ax, g.x0);
-  const float xhi = axis_coord(ax, min(g.x0 + kTileW, W) - 1);
-  const float ylo = axis_coord(ay, g.y0);
-  const float yhi = axis_coord(ay, min(g.y0 + kTileH, H) - 1);
-  const float ar = fabsf(sph.w);
-  const bool outside = (xlo - sph.x > ar) || (xhi - sph.x < -ar) || (ylo - sph.y > ar) ||
-                       (yhi - sph.y < -ar);
-  return __ballot(valid && !outside);
-}
-
-// Running minimum over the candidates for this lane's 4 pixels.
-//   best[k]  depth so far;  owner[k]  owning sphere (SHR_ARGMIN_NONE = none);
-//   bsq[k]   sqrt(q) of the owner (backward only).
-template <bool KEEP_SQ>
-__device__ __forceinline__ void tile_min(unsigned long long mask, int J, const float4 sph,
-                                         const TileGeom &g, float best[4], int owner[4],
-                                         float bsq[4]) {
-  // A culled sphere is a miss (= 100) for every pixel of the tile; only if all J
-  // spheres are candidates can a pixel's minimum exceed 100.
-  const bool all_cand = (__popcll(mask) == J);
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    best[k] = all_cand ? __builtin_inff() : kBackground;
-    owner[k] = SHR_ARGMIN_NONE;
-    if (KEEP_SQ) bsq[k] = 1.0f;
-  }
-  while (mask) {
-    const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
-    mask &= mask - 1;
-    const float sx = readlane_f(sph.x, j), sy = readlane_f(sph.y, j);
-    const float sz = readlane_f(sph.z, j), sr = readlane_f(sph.w, j);
-    const float rr = sr * sr;
-    const float dy = g.yg - sy;
-    const float dy2 = dy * dy;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const float dx = g.xg[k] - sx;
-      const float q = (rr - dx * dx) - dy2;
-      const bool hit = !(q <= kHitMin);  // clamp(min)!=min; NaN counts as hit (render.py:41-42)
-      if (hit) {
-        const float sq = sqrtf(q);
-        const float d = sz - sq;
-        const bool take = (d < best[k]) || (d != d);  // torch.min: NaN wins, ties keep first
-        if (take) {
-          best[k] = d;
-          owner[k] = j;
-          if (KEEP_SQ) bsq[k] = sq;
-        }
-      } else if (all_cand) {
-        if (kBackground < best[k]) {
-          best[k] = kBackground;
-          owner[k] = SHR_ARGMIN_NONE;
-        }
-      }
-    }
-  }
-}
-
-// --------------------------------------------------------------------------
-template <bool VEC4, bool WRITE_ARG>
-__global__ void __launch_bounds__(1024)
-sphere_raster_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
-                         float *__restrict__ depth, uint8_t *__restrict__ argmin, int tiles_x,
-                         int ntiles) {
-  __shared__ float4 s_sph[SHR_MAX_SPHERES];
-  const int n = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nwaves = blockDim.x >> 6;
-  if (threadIdx.x < J) s_sph[threadIdx.x] = spheres[(size_t)n * J + threadIdx.x];
-  __syncthreads();
-  const bool valid = lane < J;
-  const float4 sph = valid ? s_sph[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const Axis ax = make_axis(W), ay = make_axis(H);
-  float *out = depth + (size_t)n * H * W;
-  uint8_t *aout = WRITE_ARG ? argmin + (size_t)n * H * W : nullptr;
-
-  for (int tile = blockIdx.y * nwaves + wave; tile < ntiles; tile += nwaves * gridDim.y) {
-    const TileGeom g = tile_geom(tile, tiles_x, ax, ay, lane);
-    const unsigned long long mask = tile_candidates(sph, valid, g, ax, ay, H, W);
-    float best[4], bsq[4];
-    int owner[4];
-    tile_min<false>(mask, J, sph, g, best, owner, bsq);
-    if (g.v >= H) continue;
-    const size_t base = (size_t)g.v * W + g.u0;
-    if (VEC4) {
-      if (g.u0 < W) {
-        *reinterpret_cast<float4 *>(out + base) = make_float4(best[0], best[1], best[2], best[3]);
-        if (WRITE_ARG)
-          *reinterpret_cast<uchar4 *>(aout + base) =
-              make_uchar4((uint8_t)owner[0], (uint8_t)owner[1], (uint8_t)owner[2], (uint8_t)owner[3]);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (g.u0 + k < W) {
-          out[base + k] = best[k];
-          if (WRITE_ARG) aout[base + k] = (uint8_t)owner[k];
-        }
-    }
-  }
-}
-
-// --------------------------------------------------------------------------
-// Backward.  grid = (N, 1): the whole crop is reduced inside one workgroup.
-template <bool VEC4>
-__global__ void __launch_bounds__(1024)
-sphere_raster_bwd_kernel(const float4 *__restrict__ spheres, const float *__restrict__ grad_depth,
-                         int J, int H, int W, float4 *__restrict__ grad_spheres, int tiles_x,
-                         int ntiles) {
-  __shared__ float4 s_sph[SHR_MAX_SPHERES];
-  __shared__ float4 s_acc[16 * SHR_MAX_SPHERES];  // [wave][sphere]
-  const int n = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nwaves = blockDim.x >> 6;
-  if (threadIdx.x < J) s_sph[threadIdx.x] = spheres[(size_t)n * J + threadIdx.x];
-  for (int i = threadIdx.x; i < nwaves * J; i += blockDim.x) s_acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  const bool valid = lane < J;
-  const float4 sph = valid ? s_sph[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const Axis ax = make_axis(W), ay = make_axis(H);
-  const float *gin = grad_depth + (size_t)n * H * W;
-  float4 *acc = s_acc + wave * J;
-
-  for (int tile = wave; tile < ntiles; tile += nwaves) {
-    const TileGeom g = tile_geom(tile, tiles_x, ax, ay, lane);
-    const unsigned long long mask = tile_candidates(sph, valid, g, ax, ay, H, W);
-    if (mask == 0) continue;  // wave-uniform: nothing can be hit in this tile
-
-    // upstream gradient of this lane's pixels, issued before the min loop
-    float gk[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool row_ok = g.v < H;
-    const size_t base = (size_t)g.v * W + g.u0;
-    if (VEC4) {
-      if (row_ok && g.u0 < W) {
-        const float4 t = *reinterpret_cast<const float4 *>(gin + base);
-        gk[0] = t.x; gk[1] = t.y; gk[2] = t.z; gk[3] = t.w;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (row_ok && g.u0 + k < W) gk[k] = gin[base + k];
-    }
-
-    float best[4], bsq[4];
-    int owner[4];
-    tile_min<true>(mask, J, sph, g, best, owner, bsq);
-
-    // per-pixel partials  g * ( -dx/sq, -dy/sq, 1, -r/sq )
-    float px[4], py[4], pz[4], pw[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const bool in = row_ok && (g.u0 + k < W) && owner[k] != SHR_ARGMIN_NONE;
-      if (!in) owner[k] = SHR_ARGMIN_NONE;
-      const float w = in ? gk[k] / bsq[k] : 0.f;
-      pz[k] = in ? gk[k] : 0.f;
-      pw[k] = -w;
-      const float4 o = s_sph[in ? owner[k] : 0];
-      px[k] = -(w * (g.xg[k] - o.x));
-      py[k] = -(w * (g.yg - o.y));
-    }
-
-    unsigned long long m = mask;
-    while (m) {
-      const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
-      m &= m - 1;
-      float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
-      bool any = false;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const bool mine = owner[k] == j;
-        any |= mine;
-        sx += mine ? px[k] : 0.f;
-        sy += mine ? py[k] : 0.f;
-        sz += mine ? pz[k] : 0.f;
-        sw += mine ? pw[k] : 0.f;
-      }
-      if (__ballot(any) == 0) continue;  // candidate owns no pixel of the tile
-      sx = wave_sum_lane63(sx);
-      sy = wave_sum_lane63(sy);
-      sz = wave_sum_lane63(sz);
-      sw = wave_sum_lane63(sw);
-      if (lane == 63) {
-        float4 a = acc[j];
-        a.x += sx; a.y += sy; a.z += sz; a.w += sw;
-        acc[j] = a;
-      }
-    }
-  }
-  __syncthreads();
-  // combine the waves' rows in wave order; d/dr = r * sum(-g/sq)
-  if (threadIdx.x < J) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int w = 0; w < nwaves; w++) {
-      const float4 a = s_acc[w * J + threadIdx.x];
-      t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
-    }
-    t.w = t.w * s_sph[threadIdx.x].w;
-    grad_spheres[(size_t)n * J + threadIdx.x] = t;
-  }
-}
-
-}  // namespace shr
-
-// ---------------------------------------------------------------------------
 using namespace shr;
 
-static inline int pick_waves(int ntiles) {
+namespace {
+
+struct Tuning {
+  int fwd_lds_bytes = 64 * 1024;        // depth-only forward: 2 workgroups / CU
+  int fwd_owner_lds_bytes = 80 * 1024;  // forward + owner map (64-bit keys)
+  int bwd_lds_bytes = 128 * 1024;       // backward staging (grad f32 + owner u8)
+  int force_general = 0;                // 1: always the tile kernels (tests)
+} g_tune;
+
+constexpr int kMaxLds = 160 * 1024;
+
+// rows per LDS region: H if the crop fits, else a multiple of 8 balancing the regions; 0 = infeasible
+int pick_rows(int H, long long row_bytes, long long cap, long long hdr) {
+  if (cap > kMaxLds) cap = kMaxLds;
+  long long max_rows = (cap - hdr) / row_bytes;
+  if (max_rows >= H) return H;
+  max_rows &= ~7LL;
+  if (max_rows < 8) return 0;
+  const int nreg = (int)((H + max_rows - 1) / max_rows);
+  int rows = (((H + nreg - 1) / nreg) + 7) & ~7;
+  return rows > max_rows ? (int)max_rows : rows;
+}
+
+int log2_if_pow2(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int s = 0;
+  while ((1 << s) < v) s++;
+  return s;
+}
+
+template <typename K>
+hipError_t allow_big_lds(K kernel, bool *done) {
+  if (*done) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+  if (e == hipSuccess) *done = true;
+  return e;
+}
+
+int pick_waves(int ntiles) {
   int w = 16;
   while (w > 1 && w / 2 >= ntiles) w /= 2;
   return w;
+}
+
+template <bool OWNER, bool VEC4>
+int launch_zbuf_fwd(const float4 *sp, int N, int J, int H, int W, float *depth, uint8_t *argmin, int rows,
+                    hipStream_t s) {
+  static bool attr_done = false;
+  auto k = sphere_zbuf_fwd_kernel<OWNER, VEC4>;
+  const hipError_t e = allow_big_lds(k, &attr_done);
+  if (e != hipSuccess) return (int)e;
+  const size_t lds = kHdrBytes + (size_t)rows * (W + kRowPad) * (OWNER ? 8 : 4);
+  dim3 grid((unsigned)N, (unsigned)((H + rows - 1) / rows)), block(64 * kZWaves);
+  hipLaunchKernelGGL(k, grid, block, lds, s, sp, J, H, W, depth, argmin, rows, log2_if_pow2(W / 4));
+  return (int)hipGetLastError();
+}
+
+template <bool VEC4>
+int launch_zbuf_bwd(const float4 *sp, const float *grad, const uint8_t *argmin, int N, int J, int H, int W,
+                    float4 *gs, int rows, hipStream_t s) {
+  static bool attr_done = false;
+  auto k = sphere_zbuf_bwd_kernel<VEC4>;
+  const hipError_t e = allow_big_lds(k, &attr_done);
+  if (e != hipSuccess) return (int)e;
+  const size_t lds = 1024 + (size_t)rows * (W + kRowPad) * 5;
+  hipLaunchKernelGGL(k, dim3((unsigned)N), dim3(64 * kZWaves), lds, s, sp, grad, argmin, J, H, W, gs, rows,
+                     log2_if_pow2(W / 4));
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int shr_set_tuning(int key, int value) {
+  switch (key) {
+    case SHR_TUNE_FWD_LDS_BYTES: g_tune.fwd_lds_bytes = value; return SHR_OK;
+    case SHR_TUNE_FWD_OWNER_LDS_BYTES: g_tune.fwd_owner_lds_bytes = value; return SHR_OK;
+    case SHR_TUNE_BWD_LDS_BYTES: g_tune.bwd_lds_bytes = value; return SHR_OK;
+    case SHR_TUNE_FORCE_GENERAL: g_tune.force_general = value; return SHR_OK;
+    default: return SHR_EINVAL;
+  }
 }
 
 extern "C" int shr_sphere_raster_fwd(const float *spheres, int N, int J, int H, int W, float *depth,
@@ -275,42 +96,65 @@ extern "C" int shr_sphere_raster_fwd(const float *spheres, int N, int J, int H, 
   if (!spheres || !depth || N < 0 || J <= 0 || H <= 0 || W <= 0) return SHR_EINVAL;
   if (J > SHR_MAX_SPHERES || (long long)H * W > (1LL << 30)) return SHR_ETOOLARGE;
   if (((uintptr_t)spheres & 15u) != 0) return SHR_EINVAL;
-  const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
-  const int ntiles = tiles_x * tiles_y;
   const bool vec4 = (W % 4 == 0) && (((uintptr_t)depth & 15u) == 0) &&
                     (!argmin || ((uintptr_t)argmin & 3u) == 0);
-  // 4 waves per workgroup, each workgroup a slice of `tiles per wave` rounds
+  hipStream_t s = (hipStream_t)stream;
+  const float4 *sp = reinterpret_cast<const float4 *>(spheres);
+
+  const long long row_bytes = (long long)(W + kRowPad) * (argmin ? 8 : 4);
+  const int rows = g_tune.force_general
+                       ? 0
+                       : pick_rows(H, row_bytes, argmin ? g_tune.fwd_owner_lds_bytes : g_tune.fwd_lds_bytes,
+                                   kHdrBytes);
+  if (rows > 0 && (H + rows - 1) / rows <= 65535) {
+    if (argmin) return vec4 ? launch_zbuf_fwd<true, true>(sp, N, J, H, W, depth, argmin, rows, s)
+                            : launch_zbuf_fwd<true, false>(sp, N, J, H, W, depth, argmin, rows, s);
+    return vec4 ? launch_zbuf_fwd<false, true>(sp, N, J, H, W, depth, argmin, rows, s)
+                : launch_zbuf_fwd<false, false>(sp, N, J, H, W, depth, argmin, rows, s);
+  }
+
+  // general tile kernels: 4 waves per workgroup, one 32x8 tile per wave
+  const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
+  const int ntiles = tiles_x * tiles_y;
   const int nwaves = ntiles >= 4 ? 4 : pick_waves(ntiles);
   int slices = (ntiles + nwaves - 1) / nwaves;
   if (slices > 65535) slices = 65535;
   dim3 grid((unsigned)N, (unsigned)slices), block(64 * nwaves);
-  hipStream_t s = (hipStream_t)stream;
-  const float4 *sp = reinterpret_cast<const float4 *>(spheres);
 #define LAUNCH(V, A) \
-  hipLaunchKernelGGL((sphere_raster_fwd_kernel<V, A>), grid, block, 0, s, sp, J, H, W, depth, argmin, tiles_x, ntiles)
+  hipLaunchKernelGGL((sphere_tile_fwd_kernel<V, A>), grid, block, 0, s, sp, J, H, W, depth, argmin, tiles_x, ntiles)
   if (vec4) { if (argmin) LAUNCH(true, true); else LAUNCH(true, false); }
   else      { if (argmin) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
   return (int)hipGetLastError();
 }
 
-extern "C" int shr_sphere_raster_bwd(const float *spheres, const float *grad_depth, int N, int J,
-                                     int H, int W, float *grad_spheres, void *stream) {
+extern "C" int shr_sphere_raster_bwd(const float *spheres, const float *grad_depth, const uint8_t *argmin,
+                                     int N, int J, int H, int W, float *grad_spheres, void *stream) {
   if (N == 0) return SHR_OK;
   if (!spheres || !grad_depth || !grad_spheres || N < 0 || J <= 0 || H <= 0 || W <= 0) return SHR_EINVAL;
   if (J > SHR_MAX_SPHERES || (long long)H * W > (1LL << 30)) return SHR_ETOOLARGE;
   if ((((uintptr_t)spheres | (uintptr_t)grad_spheres) & 15u) != 0) return SHR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const float4 *sp = reinterpret_cast<const float4 *>(spheres);
+  float4 *gs = reinterpret_cast<float4 *>(grad_spheres);
+
+  if (argmin && !g_tune.force_general) {
+    const int rows = pick_rows(H, (long long)(W + kRowPad) * 5, g_tune.bwd_lds_bytes, 1024);
+    if (rows > 0) {
+      const bool vec4 = (W % 4 == 0) && (((uintptr_t)grad_depth & 15u) == 0) && (((uintptr_t)argmin & 3u) == 0);
+      return vec4 ? launch_zbuf_bwd<true>(sp, grad_depth, argmin, N, J, H, W, gs, rows, s)
+                  : launch_zbuf_bwd<false>(sp, grad_depth, argmin, N, J, H, W, gs, rows, s);
+    }
+  }
+  // no owner map (or image rows too wide for LDS): recompute the owners, tile kernel
   const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
   const int ntiles = tiles_x * tiles_y;
   const bool vec4 = (W % 4 == 0) && (((uintptr_t)grad_depth & 15u) == 0);
   const int nwaves = pick_waves(ntiles);
   dim3 grid((unsigned)N, 1), block(64 * nwaves);
-  hipStream_t s = (hipStream_t)stream;
-  const float4 *sp = reinterpret_cast<const float4 *>(spheres);
-  float4 *gs = reinterpret_cast<float4 *>(grad_spheres);
   if (vec4)
-    hipLaunchKernelGGL((sphere_raster_bwd_kernel<true>), grid, block, 0, s, sp, grad_depth, J, H, W, gs, tiles_x, ntiles);
+    hipLaunchKernelGGL((sphere_tile_bwd_kernel<true>), grid, block, 0, s, sp, grad_depth, J, H, W, gs, tiles_x, ntiles);
   else
-    hipLaunchKernelGGL((sphere_raster_bwd_kernel<false>), grid, block, 0, s, sp, grad_depth, J, H, W, gs, tiles_x, ntiles);
+    hipLaunchKernelGGL((sphere_tile_bwd_kernel<false>), grid, block, 0, s, sp, grad_depth, J, H, W, gs, tiles_x, ntiles);
   return (int)hipGetLastError();
 }

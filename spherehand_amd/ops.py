@@ -44,32 +44,50 @@ def sphere_raster_fwd(spheres, H, W, want_argmin=False):
     return (depth, arg) if want_argmin else depth
 
 
-def sphere_raster_bwd(spheres, grad_depth):
-    """grad_depth [N,H,W] -> grad_spheres [N,J,4]."""
+def sphere_raster_bwd(spheres, grad_depth, argmin=None):
+    """grad_depth [N,H,W] (+ the forward's uint8 owner map, or None to recompute
+    the owners) -> grad_spheres [N,J,4]."""
     _check_input(spheres, "spheres")
     _check_input(grad_depth, "grad_depth")
     N, J, _ = spheres.shape
     if grad_depth.dim() != 3 or grad_depth.shape[0] != N:
         raise RuntimeError("grad_depth must be [N,H,W]")
     H, W = grad_depth.shape[1], grad_depth.shape[2]
+    if argmin is not None:
+        _check_input(argmin, "argmin", torch.uint8)
+        if argmin.shape != grad_depth.shape:
+            raise RuntimeError("argmin must be [N,H,W]")
     with torch.cuda.device(spheres.device):
         out = torch.empty((N, J, 4), dtype=torch.float32, device=spheres.device)
-        _lib.check(_lib.lib().shr_sphere_raster_bwd(_ptr(spheres), _ptr(grad_depth), N, J, H, W,
+        _lib.check(_lib.lib().shr_sphere_raster_bwd(_ptr(spheres), _ptr(grad_depth), _ptr(argmin), N, J, H, W,
                                                     _ptr(out), _stream()), "shr_sphere_raster_bwd")
     return out
 
 
+TUNE_FWD_LDS_BYTES, TUNE_FWD_OWNER_LDS_BYTES, TUNE_BWD_LDS_BYTES, TUNE_FORCE_GENERAL = 1, 2, 3, 4
+
+
+def set_tuning(key, value):
+    """Launch-shape / test hook (shr_set_tuning); never changes results."""
+    _lib.check(_lib.lib().shr_set_tuning(int(key), int(value)), "shr_set_tuning")
+
+
 class SphereDepthRaster(torch.autograd.Function):
     """depth[N,H,W] = min over the J spheres of a crop (SURVEY 8b "new
-    differentiable op").  Differentiable w.r.t. spheres[N,J,4] = (x,y,z,r)."""
+    differentiable op").  Differentiable w.r.t. spheres[N,J,4] = (x,y,z,r).
+    The forward saves its uint8 owner map (1 byte/pixel) for the backward."""
 
     @staticmethod
     def forward(ctx, spheres, H, W):
         spheres = spheres.contiguous()
-        ctx.save_for_backward(spheres)
-        return sphere_raster_fwd(spheres, H, W)
+        if ctx.needs_input_grad[0]:
+            depth, owner = sphere_raster_fwd(spheres, H, W, want_argmin=True)
+            ctx.save_for_backward(spheres, owner)
+        else:
+            depth = sphere_raster_fwd(spheres, H, W)
+        return depth
 
     @staticmethod
     def backward(ctx, grad_depth):
-        (spheres,) = ctx.saved_tensors
-        return sphere_raster_bwd(spheres, grad_depth.contiguous()), None, None
+        spheres, owner = ctx.saved_tensors
+        return sphere_raster_bwd(spheres, grad_depth.contiguous(), owner), None, None

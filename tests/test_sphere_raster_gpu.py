@@ -13,11 +13,23 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ops():
+@pytest.fixture(scope="module", params=["zbuf", "general", "zbuf-small-lds"])
+def ops(request):
+    """Every test runs on the fast LDS z-buffer kernels, on the general tile
+    kernels, and on the z-buffer kernels squeezed into 16 KB of LDS (many row
+    regions per crop)."""
     from spherehand_amd import ops as o
     assert torch.cuda.is_available()
-    return o
+    o.set_tuning(o.TUNE_FORCE_GENERAL, 1 if request.param == "general" else 0)
+    small = request.param == "zbuf-small-lds"
+    o.set_tuning(o.TUNE_FWD_LDS_BYTES, 16 * 1024 if small else 64 * 1024)
+    o.set_tuning(o.TUNE_FWD_OWNER_LDS_BYTES, 24 * 1024 if small else 80 * 1024)
+    o.set_tuning(o.TUNE_BWD_LDS_BYTES, 16 * 1024 if small else 128 * 1024)
+    yield o
+    o.set_tuning(o.TUNE_FORCE_GENERAL, 0)
+    o.set_tuning(o.TUNE_FWD_LDS_BYTES, 64 * 1024)
+    o.set_tuning(o.TUNE_FWD_OWNER_LDS_BYTES, 80 * 1024)
+    o.set_tuning(o.TUNE_BWD_LDS_BYTES, 128 * 1024)
 
 
 def dev(a):
@@ -56,16 +68,19 @@ def test_g3_backward(ops, oracle):
     g = golden("g3_batch256.npz")
     sp_h = spheres_from(g["centres"], g["radii"])
     gd = np.random.RandomState(int(g["g_seed"])).standard_normal((256, 128, 128)).astype(np.float32)
-    gs = ops.sphere_raster_bwd(dev(sp_h), dev(gd)).cpu().numpy()
+    _, owner = ops.sphere_raster_fwd(dev(sp_h), 128, 128, want_argmin=True)
+    gs = ops.sphere_raster_bwd(dev(sp_h), dev(gd), owner).cpu().numpy()      # saved owner map
+    gs_re = ops.sphere_raster_bwd(dev(sp_h), dev(gd)).cpu().numpy()          # owners recomputed
     og = oracle.sphere_raster_bwd(sp_h, gd)
     tol = 1e-5 * np.abs(og).max() + 1e-4
     assert np.abs(gs - og).max() <= tol
+    assert np.abs(gs_re - og).max() <= tol
     ref = g["grad_centres"]                       # reference autograd
     assert np.abs(gs[:, :, :3] - ref[:, :, :3]).max() <= tol
     gr = gs[:, :, 3].reshape(8, 32, 41).sum(1)
     assert np.abs(gr - g["grad_radii_chunk32"]).max() <= 1e-5 * np.abs(g["grad_radii_chunk32"]).max() + 1e-3
     # deterministic: bit-identical on a second launch
-    gs2 = ops.sphere_raster_bwd(dev(sp_h), dev(gd)).cpu().numpy()
+    gs2 = ops.sphere_raster_bwd(dev(sp_h), dev(gd), owner).cpu().numpy()
     assert np.array_equal(bits(gs), bits(gs2))
 
 
@@ -90,16 +105,17 @@ def test_random_spheres_vs_oracle(ops, oracle, N, J, H, W):
     assert np.array_equal(bits(d.cpu().numpy()), bits(od))
     assert np.array_equal(a.cpu().numpy(), oa)
     gd = rs.standard_normal((N, H, W)).astype(np.float32)
-    gs = ops.sphere_raster_bwd(dev(sp), dev(gd)).cpu().numpy()
     og = oracle.sphere_raster_bwd(sp, gd)
-    assert np.abs(gs - og).max() <= 1e-5 * np.abs(og).max() + 1e-4
+    for owner in (a, None):
+        gs = ops.sphere_raster_bwd(dev(sp), dev(gd), owner).cpu().numpy()
+        assert np.abs(gs - og).max() <= 1e-5 * np.abs(og).max() + 1e-4
 
 
 def test_every_sphere_a_candidate_everywhere(ops, oracle):
     """Spheres bigger than the image, some deeper than the background: the min
     may exceed 100 only where all J spheres hit (reference min over J maps)."""
-    sp = np.array([[[0, 0, 400, 300], [10, -5, 500, 350]],
-                   [[0, 0, 400, 300], [200, 0, 0, 20]]], np.float32)
+    sp = np.array([[[0, 0, 450, 300], [10, -5, 500, 350]],
+                   [[0, 0, 450, 300], [200, 0, 0, 20]]], np.float32)
     d, a = ops.sphere_raster_fwd(dev(sp), 32, 64, want_argmin=True)
     od, oa = oracle.sphere_raster_fwd(sp, 32, 64)
     assert od[0].min() > 100.0
@@ -140,10 +156,11 @@ def test_backward_properties_full_size(ops):
     gen = torch.Generator(device="cuda").manual_seed(5)
     g1 = torch.randn(256, 128, 128, device="cuda", generator=gen)
     g2 = torch.randn(256, 128, 128, device="cuda", generator=gen)
-    b1, b2 = ops.sphere_raster_bwd(sp, g1), ops.sphere_raster_bwd(sp, g2)
-    b12 = ops.sphere_raster_bwd(sp, 2.0 * g1 + g2)
+    depth, owner = ops.sphere_raster_fwd(sp, 128, 128, want_argmin=True)
+    b1, b2 = ops.sphere_raster_bwd(sp, g1, owner), ops.sphere_raster_bwd(sp, g2, owner)
+    b12 = ops.sphere_raster_bwd(sp, 2.0 * g1 + g2, owner)
     assert (b12 - (2.0 * b1 + b2)).abs().max().item() <= 1e-5 * b12.abs().max().item() + 1e-3
-    depth = ops.sphere_raster_fwd(sp, 128, 128)
+    assert torch.equal(owner != 255, depth < 100)
     fg_sum = (g1.double() * (depth < 100)).sum(dim=(1, 2))
     assert (b1[:, :, 2].double().sum(1) - fg_sum).abs().max().item() <= 1e-3
     assert depth.max().item() == 100.0
