@@ -51,7 +51,13 @@ int shr_device_info(char *name_host, int name_len, int *num_cu_host);
 #define SHR_TUNE_FWD_OWNER_LDS_BYTES 2
 #define SHR_TUNE_BWD_LDS_BYTES 3
 #define SHR_TUNE_FORCE_GENERAL 4
+#define SHR_TUNE_FWD_WAVES 5  /* waves per forward workgroup, 1..16 */
 int shr_set_tuning(int key, int value);
+/* Self-test: adds to *mismatches (device, caller-zeroed u64) the number of fp32
+ * bit patterns in [lo_bits, hi_bits) where the rasterizer's internal square root
+ * differs from the correctly rounded one. */
+int shr_selftest_sqrt(unsigned lo_bits, unsigned hi_bits,
+                      unsigned long long *mismatches, void *stream);
 
 /* Sphere-set depth rasterizer ------------------------------------------------
  * Replaces BallRender.forward + the min over the sphere axis:

@@ -14,6 +14,7 @@ struct Tuning {
   int fwd_owner_lds_bytes = 80 * 1024;  // forward + owner map (64-bit keys)
   int bwd_lds_bytes = 128 * 1024;       // backward staging (grad f32 + owner u8)
   int force_general = 0;                // 1: always the tile kernels (tests)
+  int fwd_waves = 16;                   // waves per forward workgroup
 } g_tune;
 
 constexpr int kMaxLds = 160 * 1024;
@@ -52,30 +53,47 @@ int pick_waves(int ntiles) {
   return w;
 }
 
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+template <bool OWNER, bool VEC4, bool POW2>
+int launch_zbuf_fwd_t(const float4 *sp, int N, int J, int H, int W, float *depth, uint8_t *argmin, int rows,
+                      hipStream_t s) {
+  static bool attr_done = false;
+  auto k = sphere_zbuf_fwd_kernel<OWNER, VEC4, POW2>;
+  const hipError_t e = allow_big_lds(k, &attr_done);
+  if (e != hipSuccess) return (int)e;
+  const size_t lds = kHdrBytes + (size_t)(rows + kPadRows) * (W + kRowPad) * (OWNER ? 8 : 4);
+  dim3 grid((unsigned)N, (unsigned)((H + rows - 1) / rows)), block(64 * g_tune.fwd_waves);
+  hipLaunchKernelGGL(k, grid, block, lds, s, sp, J, H, W, depth, argmin, rows, log2_if_pow2(W / 4));
+  return (int)hipGetLastError();
+}
+
 template <bool OWNER, bool VEC4>
 int launch_zbuf_fwd(const float4 *sp, int N, int J, int H, int W, float *depth, uint8_t *argmin, int rows,
                     hipStream_t s) {
+  return (is_pow2(W) && is_pow2(H))
+             ? launch_zbuf_fwd_t<OWNER, VEC4, true>(sp, N, J, H, W, depth, argmin, rows, s)
+             : launch_zbuf_fwd_t<OWNER, VEC4, false>(sp, N, J, H, W, depth, argmin, rows, s);
+}
+
+template <bool VEC4, bool POW2>
+int launch_zbuf_bwd_t(const float4 *sp, const float *grad, const uint8_t *argmin, int N, int J, int H, int W,
+                      float4 *gs, int rows, hipStream_t s) {
   static bool attr_done = false;
-  auto k = sphere_zbuf_fwd_kernel<OWNER, VEC4>;
+  auto k = sphere_zbuf_bwd_kernel<VEC4, POW2>;
   const hipError_t e = allow_big_lds(k, &attr_done);
   if (e != hipSuccess) return (int)e;
-  const size_t lds = kHdrBytes + (size_t)rows * (W + kRowPad) * (OWNER ? 8 : 4);
-  dim3 grid((unsigned)N, (unsigned)((H + rows - 1) / rows)), block(64 * kZWaves);
-  hipLaunchKernelGGL(k, grid, block, lds, s, sp, J, H, W, depth, argmin, rows, log2_if_pow2(W / 4));
+  const size_t lds = kHdrBytes + kPartBytes + (size_t)(rows + kPadRows) * (W + kRowPad) * 5;
+  hipLaunchKernelGGL(k, dim3((unsigned)N), dim3(64 * kZWaves), lds, s, sp, grad, argmin, J, H, W, gs, rows,
+                     log2_if_pow2(W / 4));
   return (int)hipGetLastError();
 }
 
 template <bool VEC4>
 int launch_zbuf_bwd(const float4 *sp, const float *grad, const uint8_t *argmin, int N, int J, int H, int W,
                     float4 *gs, int rows, hipStream_t s) {
-  static bool attr_done = false;
-  auto k = sphere_zbuf_bwd_kernel<VEC4>;
-  const hipError_t e = allow_big_lds(k, &attr_done);
-  if (e != hipSuccess) return (int)e;
-  const size_t lds = 1024 + (size_t)rows * (W + kRowPad) * 5;
-  hipLaunchKernelGGL(k, dim3((unsigned)N), dim3(64 * kZWaves), lds, s, sp, grad, argmin, J, H, W, gs, rows,
-                     log2_if_pow2(W / 4));
-  return (int)hipGetLastError();
+  return (is_pow2(W) && is_pow2(H)) ? launch_zbuf_bwd_t<VEC4, true>(sp, grad, argmin, N, J, H, W, gs, rows, s)
+                                    : launch_zbuf_bwd_t<VEC4, false>(sp, grad, argmin, N, J, H, W, gs, rows, s);
 }
 
 }  // namespace
@@ -86,6 +104,10 @@ extern "C" int shr_set_tuning(int key, int value) {
     case SHR_TUNE_FWD_OWNER_LDS_BYTES: g_tune.fwd_owner_lds_bytes = value; return SHR_OK;
     case SHR_TUNE_BWD_LDS_BYTES: g_tune.bwd_lds_bytes = value; return SHR_OK;
     case SHR_TUNE_FORCE_GENERAL: g_tune.force_general = value; return SHR_OK;
+    case SHR_TUNE_FWD_WAVES:
+      if (value < 1 || value > 16) return SHR_EINVAL;
+      g_tune.fwd_waves = value;
+      return SHR_OK;
     default: return SHR_EINVAL;
   }
 }
@@ -105,7 +127,7 @@ extern "C" int shr_sphere_raster_fwd(const float *spheres, int N, int J, int H, 
   const int rows = g_tune.force_general
                        ? 0
                        : pick_rows(H, row_bytes, argmin ? g_tune.fwd_owner_lds_bytes : g_tune.fwd_lds_bytes,
-                                   kHdrBytes);
+                                   kHdrBytes + kPadRows * row_bytes);
   if (rows > 0 && (H + rows - 1) / rows <= 65535) {
     if (argmin) return vec4 ? launch_zbuf_fwd<true, true>(sp, N, J, H, W, depth, argmin, rows, s)
                             : launch_zbuf_fwd<true, false>(sp, N, J, H, W, depth, argmin, rows, s);
@@ -139,7 +161,8 @@ extern "C" int shr_sphere_raster_bwd(const float *spheres, const float *grad_dep
   float4 *gs = reinterpret_cast<float4 *>(grad_spheres);
 
   if (argmin && !g_tune.force_general) {
-    const int rows = pick_rows(H, (long long)(W + kRowPad) * 5, g_tune.bwd_lds_bytes, 1024);
+    const long long row_bytes = (long long)(W + kRowPad) * 5;
+    const int rows = pick_rows(H, row_bytes, g_tune.bwd_lds_bytes, kHdrBytes + kPartBytes + kPadRows * row_bytes);
     if (rows > 0) {
       const bool vec4 = (W % 4 == 0) && (((uintptr_t)grad_depth & 15u) == 0) && (((uintptr_t)argmin & 3u) == 0);
       return vec4 ? launch_zbuf_bwd<true>(sp, grad_depth, argmin, N, J, H, W, gs, rows, s)

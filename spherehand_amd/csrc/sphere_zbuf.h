@@ -8,32 +8,34 @@
 // Why not pixel-parallel: a 128x128 crop has 16384 pixels but its 41 spheres
 // cover only ~6000 bounding-box pixels in total (13-15 % foreground), so testing
 // candidates per pixel tile spends >10x more lane-operations than walking each
-// sphere's own pixel box (measured: tile kernel 24 us vs 4.6 us for a plain
-// 16.8 MB fill on MI355X).  Here:
+// sphere's own pixel box (measured on MI355X, batch 256: tile kernel 24 us vs
+// 4.6 us for a plain 16.8 MB fill).  Here:
 //
 //   forward   one workgroup (16 waves) per (crop, row region).  The region's
-//             z-buffer lives in LDS as order-preserving integer keys
-//             (key = depth bits made monotonic; with OWNER the sphere index is
-//             packed in the low word of a 64-bit key, so ds_min_u64 also
-//             yields the first-index owner on exact depth ties).  Waves take
-//             spheres round-robin and scan-convert the sphere's pixel box in
-//             16x4-lane patches: exact reference arithmetic per pixel, one LDS
-//             atomic min per hit.  Then the z-buffer is decoded and streamed
-//             out with full-line 16-byte stores (the only HBM traffic besides
-//             the 16*J-byte sphere read).
-//   backward  one workgroup per crop.  grad_depth and the saved owner map are
-//             staged into LDS with coalesced 16-byte loads; each wave walks the
-//             boxes of its spheres, accumulates the four partials of the pixels
-//             the sphere owns in registers, then ONE DPP wave-sum per sphere and
-//             a single 16-byte store: deterministic, no float atomics, no
-//             cross-wave combine.
+//             z-buffer lives in LDS as order-preserving integer keys (depth bits
+//             made monotonic; with OWNER the sphere index is packed in the low
+//             word of a 64-bit key, so ds_min_u64 also yields the first-index
+//             owner on exact depth ties).  Wave 0 turns the spheres into a work
+//             list of 16x4-pixel patches (lanes = spheres: pixel box, patch
+//             count, prefix sum); the 16 waves then take equal contiguous slices
+//             of that list (lanes = pixels): exact reference arithmetic per
+//             pixel, one LDS atomic min per hit.  Finally the z-buffer is decoded
+//             and streamed out with full-line 16-byte stores -- the only HBM
+//             traffic besides the 16*J-byte sphere read.
+//   backward  one workgroup per crop.  grad_depth and the forward's owner map are
+//             staged into LDS with coalesced 16-byte loads; the waves walk the
+//             same balanced patch list, accumulate the four partials of the
+//             pixels a sphere owns in registers, one DPP wave-sum per (wave,
+//             sphere) segment into a private LDS slot, slots combined in wave
+//             order: deterministic, no float atomics.
 //
 // Exactness: the per-pixel arithmetic is the reference's operation sequence
-// (common.h, -ffp-contract=off, IEEE sqrt).  Integer-key minima are exact.  The
-// fast forward requires, per crop, all sphere parameters finite, |x|,|y|,|r| <
-// 1e6 and z <= 100 (then every hit is < 100, so initialising the z-buffer to the
-// background is the reference's min); any other crop takes the general tile
-// kernel (sphere_tile.h) inside the same workgroup.
+// (common.h, -ffp-contract=off; sqrt_rn() is a correctly rounded square root).
+// Integer-key minima are exact.  The fast forward requires, per crop, all sphere
+// parameters finite, |x|,|y|,|r| < 1e6 and at least one sphere with z <= 100
+// (then initialising the z-buffer to the background is the reference's min: see
+// the kernel); any other crop takes the general tile kernel (sphere_tile.h)
+// inside the same workgroup.
 #pragma once
 #include "sphere_tile.h"
 
@@ -42,8 +44,12 @@ namespace shr {
 constexpr int kZWaves = 16;   // 1024 threads
 constexpr int kPatchW = 16;   // lanes along x
 constexpr int kPatchH = 4;    // lanes along y
-constexpr int kRowPad = 16;   // LDS row padding (elements): rows of a patch hit different banks
-constexpr int kHdrBytes = 1024 + 16;  // staged spheres + flags, keeps 16-B alignment
+constexpr int kRowPad = 16;   // LDS row padding (elements): patches may overhang the image edge
+constexpr int kPadRows = kPatchH - 1;  // ... and the region's last row
+// LDS header: spheres [64] float4 | work items [64] int4 | flags
+constexpr int kOffItems = 1024;
+constexpr int kOffFlags = 2048;
+constexpr int kHdrBytes = 2048 + 16;
 
 __device__ __forceinline__ uint32_t depth_key(float d) {
   const uint32_t b = __float_as_uint(d);
@@ -53,40 +59,125 @@ __device__ __forceinline__ float key_depth(uint32_t k) {
   return __uint_as_float(k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
+// Correctly rounded sqrt for a normal, positive, finite fp32 argument (here
+// q > 0.01): the hardware estimate (v_sqrt_f32, <= 1 ulp) corrected by the exact
+// residuals of its two neighbours -- the same correction hipcc's sqrtf() applies,
+// without its denormal-scaling prologue.  Checked against sqrtf() on every fp32
+// value in [0.01, 1e12] (tests/test_sphere_raster_gpu.py::test_sqrt_rn_exhaustive).
+__device__ __forceinline__ float sqrt_rn(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float dn = __uint_as_float(__float_as_uint(s) - 1u);
+  const float up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float e_dn = __builtin_fmaf(-dn, s, x);
+  const float e_up = __builtin_fmaf(-up, s, x);
+  float r = (e_dn <= 0.0f) ? dn : s;
+  r = (e_up > 0.0f) ? up : r;
+  return r;
+}
+
 __device__ __forceinline__ bool sphere_is_tame(const float4 s) {
   return fabsf(s.x) < 1e6f && fabsf(s.y) < 1e6f && fabsf(s.w) < 1e6f;  // false for NaN/Inf
 }
-__device__ __forceinline__ bool sphere_fast_ok(const float4 s) {
-  return sphere_is_tame(s) && fabsf(s.z) < 1e30f && s.z <= kBackground;
+
+// One work item = one sphere's pixel box clipped to the region, as a grid of
+// 16x4-pixel patches.  Conservative box: a hit needs |fl(xg - x)| <= |r|;
+// xg(u) = (u - half)*300/size  =>  u = xg*size/300 + half, evaluated in fp32
+// (error << 1 px for tame spheres) and widened by one pixel each side.
+struct Item { int u0, v0, npx, npy; };
+
+__device__ __forceinline__ Item sphere_item(const float4 s, const Axis &ax, const Axis &ay, int W, int r0,
+                                            int r1) {
+  int u0 = 0, u1 = W - 1, v0 = r0, v1 = r1 - 1;
+  if (sphere_is_tame(s)) {
+    const float ar = fabsf(s.w);
+    const float kx = ax.size / 300.0f, ky = ay.size / 300.0f;
+    const float ulo = (s.x - ar) * kx + ax.half, uhi = (s.x + ar) * kx + ax.half;
+    const float vlo = (s.y - ar) * ky + ay.half, vhi = (s.y + ar) * ky + ay.half;
+    const float wf = (float)W + 2.f, hf = (float)r1 + 2.f;
+    u0 = max((int)floorf(fminf(fmaxf(ulo, -2.f), wf)) - 1, 0);
+    u1 = min((int)ceilf(fminf(fmaxf(uhi, -2.f), wf)) + 1, W - 1);
+    v0 = max((int)floorf(fminf(fmaxf(vlo, -2.f), hf)) - 1, r0);
+    v1 = min((int)ceilf(fminf(fmaxf(vhi, -2.f), hf)) + 1, r1 - 1);
+  }
+  Item it;
+  it.u0 = u0;
+  it.v0 = v0;
+  it.npx = (u1 >= u0) ? ((u1 - u0) / kPatchW + 1) : 0;
+  it.npy = (v1 >= v0) ? ((v1 - v0) / kPatchH + 1) : 0;
+  return it;
 }
 
-struct Box { int u0, u1, v0, v1; };  // inclusive pixel bounds
+// Wave 0: build the work list in LDS.  s_items[j] = (u0, v0, npx | npy<<16, first
+// patch index); returns the total patch count (valid in every lane of wave 0).
+__device__ __forceinline__ int build_work_list(const float4 s, bool valid, const Axis &ax, const Axis &ay,
+                                               int W, int r0, int r1, int4 *s_items, int lane) {
+  Item it = sphere_item(s, ax, ay, W, r0, r1);
+  const int cnt = valid ? it.npx * it.npy : 0;
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  s_items[lane] = make_int4(it.u0, it.v0, it.npx | (it.npy << 16), incl - cnt);
+  return __shfl(incl, 63);
+}
 
-// Conservative pixel box of a sphere.  Hit needs |fl(xg - x)| <= |r|;
-// xg(u) = (u - half)*300/size  =>  u = xg*size/300 + half.  The inverse map is
-// evaluated in fp32 (error << 1 px for tame spheres) and widened by one pixel.
-__device__ __forceinline__ Box sphere_box(const float4 s, const Axis &ax, const Axis &ay, int W, int H) {
-  Box b;
-  if (!sphere_is_tame(s)) { b.u0 = 0; b.u1 = W - 1; b.v0 = 0; b.v1 = H - 1; return b; }
-  const float ar = fabsf(s.w);
-  const float kx = ax.size / 300.0f, ky = ay.size / 300.0f;
-  const float ulo = (s.x - ar) * kx + ax.half, uhi = (s.x + ar) * kx + ax.half;
-  const float vlo = (s.y - ar) * ky + ay.half, vhi = (s.y + ar) * ky + ay.half;
-  const float wf = (float)W + 2.f, hf = (float)H + 2.f;
-  b.u0 = max((int)floorf(fminf(fmaxf(ulo, -2.f), wf)) - 1, 0);
-  b.u1 = min((int)ceilf(fminf(fmaxf(uhi, -2.f), wf)) + 1, W - 1);
-  b.v0 = max((int)floorf(fminf(fmaxf(vlo, -2.f), hf)) - 1, 0);
-  b.v1 = min((int)ceilf(fminf(fmaxf(vhi, -2.f), hf)) + 1, H - 1);
-  return b;
+// Iterate this wave's slice [i0, i1) of the patch list.  f(j, s, pu, pv, first,
+// last) is called per patch with the sphere index, its parameters and the
+// patch's top-left pixel; `first`/`last` mark the ends of a run on one sphere.
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float rfl(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+template <typename F>
+__device__ __forceinline__ void for_each_patch(const float4 *s_sph, const int4 *s_items, int J, int total,
+                                               int wave, int nwaves, int lane, F &&f) {
+  // everything that steers the loops is wave-uniform: keep it in SGPRs
+  wave = rfl(wave);
+  total = rfl(total);
+  const int i0 = (wave * total) / nwaves, i1 = ((wave + 1) * total) / nwaves;
+  if (i0 >= i1) return;
+  // first sphere whose patch range ends beyond i0 (ends are non-decreasing)
+  const int4 mine = s_items[lane];
+  const int my_end = mine.w + (mine.z & 0xffff) * (mine.z >> 16);
+  int j = __popcll(__ballot(lane < J && my_end <= i0));
+  int i = i0;
+  while (i < i1) {
+    const int4 itv = s_items[j];
+    const int u0 = rfl(itv.x), v0 = rfl(itv.y), zz = rfl(itv.z), start = rfl(itv.w);
+    const int npx = zz & 0xffff, cnt = npx * (zz >> 16);
+    const int p = i - start;
+    const int n = min(cnt - p, i1 - i);
+    if (n > 0) {
+      const float4 sv = s_sph[j];
+      const float4 s = make_float4(rfl(sv.x), rfl(sv.y), rfl(sv.z), rfl(sv.w));
+      int py = p / npx, px = p - py * npx;
+      for (int k = 0; k < n; k++) {
+        f(j, s, u0 + px * kPatchW, v0 + py * kPatchH, k == 0, k == n - 1);
+        if (++px == npx) { px = 0; ++py; }
+      }
+      i += n;
+    }
+    ++j;
+  }
+}
+
+// image axis coordinate with the power-of-two case resolved at compile time
+template <bool POW2>
+__device__ __forceinline__ float axis_coord_t(const Axis &a, int u) {
+  const float t = (float)u - a.half;
+  return POW2 ? t * a.mul : (t * 300.0f) / a.size;
 }
 
 template <bool OWNER> struct KeyOf { using type = uint32_t; };
 template <> struct KeyOf<true> { using type = unsigned long long; };
 
 // ---------------------------------------------------------------------------
-// Forward.  grid = (N, nregions), block = 1024, dynamic LDS = kHdrBytes +
-// rows_per_region * (W + kRowPad) * sizeof(key).
-template <bool OWNER, bool VEC4>
+// Forward.  grid = (N, nregions), block = 64 * nwaves (<= 1024), dynamic LDS = kHdrBytes +
+// (rows_per_region + kPadRows) * (W + kRowPad) * sizeof(key).
+template <bool OWNER, bool VEC4, bool POW2>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
                        float *__restrict__ depth, uint8_t *__restrict__ argmin, int rows_per_region,
@@ -94,35 +185,49 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
   using Key = typename KeyOf<OWNER>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
-  int *s_flag = reinterpret_cast<int *>(smem + 1024);
+  int4 *s_items = reinterpret_cast<int4 *>(smem + kOffItems);
+  int *s_flag = reinterpret_cast<int *>(smem + kOffFlags);
   Key *zbuf = reinterpret_cast<Key *>(smem + kHdrBytes);
 
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nwaves = nthr >> 6;
   const int r0 = blockIdx.y * rows_per_region;
   const int r1 = min(H, r0 + rows_per_region);
   const int rh = r1 - r0;
   const int LW = W + kRowPad;
+  const Axis ax = make_axis(W), ay = make_axis(H);
 
-  if (tid < 64) {
+  if (wave == 0) {
+    const bool valid = lane < J;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < J) { s = spheres[(size_t)n * J + tid]; s_sph[tid] = s; }
-    const unsigned long long bad = __ballot(tid < J && !sphere_fast_ok(s));
-    if (tid == 0) s_flag[0] = (bad != 0ull);
+    if (valid) s = spheres[(size_t)n * J + lane];
+    s_sph[lane] = s;
+    // general path unless every sphere is tame and at least one has z <= 100: a pixel's
+    // minimum can exceed the background only where ALL J spheres hit it, and there the
+    // sphere with z <= 100 contributes z - sqrt(q) < 100, so min(100, hits) is exact.
+    const unsigned long long bad = __ballot(valid && !(sphere_is_tame(s) && fabsf(s.z) < 1e30f));
+    const unsigned long long low = __ballot(valid && s.z <= kBackground);
+    const int total = build_work_list(s, valid, ax, ay, W, r0, r1, s_items, lane);
+    if (lane == 0) {
+      s_flag[0] = (bad != 0ull) || (low == 0ull);
+      s_flag[1] = total;
+    }
   }
-  {  // background everywhere
+  {  // background everywhere (pad rows/columns included)
     const Key bg = OWNER ? (Key)(((unsigned long long)depth_key(kBackground) << 32) | SHR_ARGMIN_NONE)
                          : (Key)depth_key(kBackground);
     constexpr int per16 = 16 / sizeof(Key);
-    const int nvec = rh * LW / per16;  // LW % 4 == 0 when VEC4; else tail handled below
+    const int ncell = (rh + kPadRows) * LW;
+    const int nvec = ncell / per16;
     if (OWNER) {
       const ulonglong2 v = make_ulonglong2(bg, bg);
-      for (int i = tid; i < nvec; i += 1024) reinterpret_cast<ulonglong2 *>(zbuf)[i] = v;
+      for (int i = tid; i < nvec; i += nthr) reinterpret_cast<ulonglong2 *>(zbuf)[i] = v;
     } else {
       const uint4 v = make_uint4((uint32_t)bg, (uint32_t)bg, (uint32_t)bg, (uint32_t)bg);
-      for (int i = tid; i < nvec; i += 1024) reinterpret_cast<uint4 *>(zbuf)[i] = v;
+      for (int i = tid; i < nvec; i += nthr) reinterpret_cast<uint4 *>(zbuf)[i] = v;
     }
-    for (int i = nvec * per16 + tid; i < rh * LW; i += 1024) zbuf[i] = bg;
+    for (int i = nvec * per16 + tid; i < ncell; i += nthr) zbuf[i] = bg;
   }
   __syncthreads();
 
@@ -133,46 +238,39 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
     const int tiles_x = (W + kTileW - 1) / kTileW;
     const int t0 = (r0 / kTileH) * tiles_x, t1 = ((r1 + kTileH - 1) / kTileH) * tiles_x;
     const float4 sph = lane < J ? s_sph[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    tile_forward<VEC4, OWNER>(sph, J, H, W, out, aout, tiles_x, t0 + wave, t1, kZWaves, lane);
+    tile_forward<VEC4, OWNER>(sph, J, H, W, out, aout, tiles_x, t0 + wave, t1, nwaves, lane);
     return;
   }
 
-  // ---- scan-convert: one wave per sphere, 16x4-lane patches ------------------
-  const Axis ax = make_axis(W), ay = make_axis(H);
-  const int lx = lane & (kPatchW - 1), ly = lane >> 4;
-  for (int j = wave; j < J; j += kZWaves) {
-    const float4 s = s_sph[j];
-    Box b = sphere_box(s, ax, ay, W, H);
-    b.v0 = max(b.v0, r0);
-    b.v1 = min(b.v1, r1 - 1);
-    const float rr = s.w * s.w;
-    for (int pv = b.v0; pv <= b.v1; pv += kPatchH) {
-      const int v = pv + ly;
-      const float dy = axis_coord(ay, v) - s.y;
-      const float dy2 = dy * dy;
-      for (int pu = b.u0; pu <= b.u1; pu += kPatchW) {
-        const int u = pu + lx;
-        const float dx = axis_coord(ax, u) - s.x;
-        const float q = (rr - dx * dx) - dy2;
-        if (q > kHitMin && u <= b.u1 && v <= b.v1) {
-          const float d = s.z - sqrtf(q);
-          Key *cell = zbuf + (v - r0) * LW + u;
-          if (OWNER)
-            atomicMin(reinterpret_cast<unsigned long long *>(cell),
-                      ((unsigned long long)depth_key(d) << 32) | (unsigned)j);
-          else
-            atomicMin(reinterpret_cast<unsigned int *>(cell), depth_key(d));
-        }
-      }
-    }
+  // ---- scan-convert the patch list -------------------------------------------------
+  // A patch may overhang the box, the image's right edge or the region's last row:
+  // the hit test is exact for ANY pixel, overhanging lanes land in LDS padding.
+  {
+    const int lx = lane & (kPatchW - 1), ly = lane >> 4;
+    for_each_patch(s_sph, s_items, J, s_flag[1], wave, nwaves, lane,
+                   [&](int j, const float4 s, int pu, int pv, bool, bool) {
+                     const int u = pu + lx, v = pv + ly;
+                     const float dx = axis_coord_t<POW2>(ax, u) - s.x;
+                     const float dy = axis_coord_t<POW2>(ay, v) - s.y;
+                     const float q = (s.w * s.w - dx * dx) - dy * dy;
+                     if (q > kHitMin) {
+                       const float d = s.z - sqrt_rn(q);
+                       Key *cell = zbuf + (v - r0) * LW + u;
+                       if (OWNER)
+                         atomicMin(reinterpret_cast<unsigned long long *>(cell),
+                                   ((unsigned long long)depth_key(d) << 32) | (unsigned)j);
+                       else
+                         atomicMin(reinterpret_cast<unsigned int *>(cell), depth_key(d));
+                     }
+                   });
   }
   __syncthreads();
 
-  // ---- stream the region out ---------------------------------------------------
+  // ---- stream the region out ---------------------------------------------------------
   if (VEC4) {
     const int w4 = W >> 2;
     const int nchunk = rh * w4;
-    for (int c = tid; c < nchunk; c += 1024) {
+    for (int c = tid; c < nchunk; c += nthr) {
       int v, u;
       if (w4_shift >= 0) { v = c >> w4_shift; u = (c & (w4 - 1)) << 2; }
       else { v = c / w4; u = (c - v * w4) << 2; }
@@ -192,7 +290,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
       *reinterpret_cast<float4 *>(out + (size_t)(r0 + v) * W + u) = o;
     }
   } else {
-    for (int p = tid; p < rh * W; p += 1024) {
+    for (int p = tid; p < rh * W; p += nthr) {
       const int v = p / W, u = p - v * W;
       const Key k = zbuf[v * LW + u];
       if (OWNER) {
@@ -207,34 +305,48 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
 
 // ---------------------------------------------------------------------------
 // Backward with the forward's owner map.  grid = (N), block = 1024, dynamic LDS =
-// 1024 + rows_per_region * ((W + kRowPad) * 4 + (W + kRowPad)).
-template <bool VEC4>
+// kHdrBytes + 16*64*16 (wave x sphere partial sums) + (rows + kPadRows) * (W +
+// kRowPad) * (4 + 1).
+constexpr int kPartBytes = kZWaves * SHR_MAX_SPHERES * 16;
+
+template <bool VEC4, bool POW2>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restrict__ grad_depth,
                        const uint8_t *__restrict__ argmin, int J, int H, int W,
                        float4 *__restrict__ grad_spheres, int rows_per_region, int w4_shift) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
+  int4 *s_items = reinterpret_cast<int4 *>(smem + kOffItems);
+  int *s_flag = reinterpret_cast<int *>(smem + kOffFlags);
+  float4 *s_part = reinterpret_cast<float4 *>(smem + kHdrBytes);
   const int LW = W + kRowPad;
-  float *gbuf = reinterpret_cast<float *>(smem + 1024);
-  uint8_t *obuf = smem + 1024 + (size_t)rows_per_region * LW * 4;
+  float *gbuf = reinterpret_cast<float *>(smem + kHdrBytes + kPartBytes);
+  uint8_t *obuf = smem + kHdrBytes + kPartBytes + (size_t)(rows_per_region + kPadRows) * LW * 4;
 
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < J) s_sph[tid] = spheres[(size_t)n * J + tid];
   const float *gin = grad_depth + (size_t)n * H * W;
   const uint8_t *oin = argmin + (size_t)n * H * W;
   const Axis ax = make_axis(W), ay = make_axis(H);
   const int lx = lane & (kPatchW - 1), ly = lane >> 4;
 
-  constexpr int kSlots = SHR_MAX_SPHERES / kZWaves;  // spheres per wave
-  float acc[kSlots][4];
-#pragma unroll
-  for (int t = 0; t < kSlots; t++) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
+  float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (wave == 0) {
+    if (lane < J) sph = spheres[(size_t)n * J + lane];
+    s_sph[lane] = sph;
+  }
+  s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // 1024 = 16 waves x 64 spheres
 
   for (int r0 = 0; r0 < H; r0 += rows_per_region) {
     const int r1 = min(H, r0 + rows_per_region), rh = r1 - r0;
     if (r0 > 0) __syncthreads();  // the previous region's walk is done
+    if (wave == 0) {
+      const int total = build_work_list(sph, lane < J, ax, ay, W, r0, r1, s_items, lane);
+      if (lane == 0) s_flag[1] = total;
+    }
+    // owner padding = "nobody": the walk may overhang the image edge / region end
+    for (int i = tid; i < rh * kRowPad; i += 1024) obuf[(i / kRowPad) * LW + W + (i % kRowPad)] = SHR_ARGMIN_NONE;
+    for (int i = tid; i < kPadRows * LW; i += 1024) obuf[rh * LW + i] = SHR_ARGMIN_NONE;
     if (VEC4) {
       const int w4 = W >> 2;
       const int nchunk = rh * w4;
@@ -255,44 +367,44 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     }
     __syncthreads();
 
-#pragma unroll
-    for (int t = 0; t < kSlots; t++) {
-      const int j = wave + t * kZWaves;
-      if (j >= J) continue;
-      const float4 s = s_sph[j];
-      Box b = sphere_box(s, ax, ay, W, H);
-      b.v0 = max(b.v0, r0);
-      b.v1 = min(b.v1, r1 - 1);
-      const float rr = s.w * s.w;
-      for (int pv = b.v0; pv <= b.v1; pv += kPatchH) {
-        const int v = pv + ly;
-        const float dy = axis_coord(ay, v) - s.y;
-        for (int pu = b.u0; pu <= b.u1; pu += kPatchW) {
-          const int u = pu + lx;
-          if (u <= b.u1 && v <= b.v1 && obuf[(v - r0) * LW + u] == (uint8_t)j) {
-            const float g = gbuf[(v - r0) * LW + u];
-            const float dx = axis_coord(ax, u) - s.x;
-            const float q = (rr - dx * dx) - dy * dy;
-            const float w = g / sqrtf(q);
-            acc[t][0] += -(w * dx);
-            acc[t][1] += -(w * dy);
-            acc[t][2] += g;
-            acc[t][3] += -w;
-          }
-        }
-      }
-    }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for_each_patch(s_sph, s_items, J, s_flag[1], wave, kZWaves, lane,
+                   [&](int j, const float4 s, int pu, int pv, bool, bool last) {
+                     const int u = pu + lx, v = pv + ly;
+                     const int cell = (v - r0) * LW + u;
+                     if (obuf[cell] == (uint8_t)j) {
+                       const float g = gbuf[cell];
+                       const float dx = axis_coord_t<POW2>(ax, u) - s.x;
+                       const float dy = axis_coord_t<POW2>(ay, v) - s.y;
+                       const float q = (s.w * s.w - dx * dx) - dy * dy;
+                       const float w = g * __builtin_amdgcn_rsqf(q);  // g / sqrt(q), ~1e-7 rel.
+                       a0 = __builtin_fmaf(-w, dx, a0);
+                       a1 = __builtin_fmaf(-w, dy, a1);
+                       a2 += g;
+                       a3 -= w;
+                     }
+                     if (last) {  // end of this wave's run on sphere j: one wave sum per component
+                       const float sx = wave_sum_lane63(a0), sy = wave_sum_lane63(a1);
+                       const float sz = wave_sum_lane63(a2), sw = wave_sum_lane63(a3);
+                       if (lane == 63) {
+                         float4 t = s_part[wave * SHR_MAX_SPHERES + j];
+                         t.x += sx; t.y += sy; t.z += sz; t.w += sw;
+                         s_part[wave * SHR_MAX_SPHERES + j] = t;
+                       }
+                       a0 = a1 = a2 = a3 = 0.f;
+                     }
+                   });
   }
-
-#pragma unroll
-  for (int t = 0; t < kSlots; t++) {
-    const int j = wave + t * kZWaves;
-    if (j >= J) continue;
-    const float sx = wave_sum_lane63(acc[t][0]);
-    const float sy = wave_sum_lane63(acc[t][1]);
-    const float sz = wave_sum_lane63(acc[t][2]);
-    const float sw = wave_sum_lane63(acc[t][3]);
-    if (lane == 63) grad_spheres[(size_t)n * J + j] = make_float4(sx, sy, sz, sw * s_sph[j].w);
+  __syncthreads();
+  // combine the waves' partials in wave order; d/dr = r * sum(-g/sqrt(q))
+  if (tid < J) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = 0; w < kZWaves; w++) {
+      const float4 a = s_part[w * SHR_MAX_SPHERES + tid];
+      t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+    }
+    t.w = t.w * s_sph[tid].w;
+    grad_spheres[(size_t)n * J + tid] = t;
   }
 }
 

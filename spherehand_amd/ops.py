@@ -64,7 +64,7 @@ def sphere_raster_bwd(spheres, grad_depth, argmin=None):
     return out
 
 
-TUNE_FWD_LDS_BYTES, TUNE_FWD_OWNER_LDS_BYTES, TUNE_BWD_LDS_BYTES, TUNE_FORCE_GENERAL = 1, 2, 3, 4
+TUNE_FWD_LDS_BYTES, TUNE_FWD_OWNER_LDS_BYTES, TUNE_BWD_LDS_BYTES, TUNE_FORCE_GENERAL, TUNE_FWD_WAVES = 1, 2, 3, 4, 5
 
 
 def set_tuning(key, value):

@@ -174,3 +174,16 @@ def test_autograd_function(ops):
     (d * w).sum().backward()
     assert sp.grad.shape == (1, 41, 4)
     assert torch.isfinite(sp.grad).all() and sp.grad.abs().sum() > 0
+
+
+def test_sqrt_rn_exhaustive():
+    """The rasterizer's trimmed square root is correctly rounded on every fp32
+    value in [0.01, 1e12] (q > 0.01 is the only range it is called on)."""
+    from spherehand_amd import _lib
+    lo = int(np.float32(0.0099).view(np.uint32))
+    hi = int(np.float32(1e12).view(np.uint32))
+    bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib().shr_selftest_sqrt(lo, hi, bad.data_ptr(), torch.cuda.current_stream().cuda_stream),
+               "shr_selftest_sqrt")
+    assert int(bad.item()) == 0
+    assert hi - lo > 350_000_000
