@@ -54,7 +54,7 @@ def make_inputs(rank, device):
     return spheres.to(device), grad.to(device)
 
 
-def cpu_baseline(spheres_host, grad_host, budget_s=12.0):
+def cpu_baseline(spheres_host, grad_host, budget_s=10.0):
     from oracle import oracle
     oracle.build()
     cores = oracle.num_threads()
@@ -67,7 +67,7 @@ def cpu_baseline(spheres_host, grad_host, budget_s=12.0):
         oracle.sphere_raster_bwd(spheres_host, grad_host)
         passes += 1
         el = time.perf_counter() - t0
-        if el > budget_s or passes >= 20:
+        if el > budget_s or passes >= 400:
             break
     return {"value": round(passes * BATCH / el, 1), "unit": "crops/s", "cores": cores, "kind": "port",
             "sample": "%d fwd+bwd passes over the same 256-crop 128x128 batch (%.1f s, OpenMP over crops)"
