@@ -85,6 +85,19 @@ int shr_sphere_raster_bwd(const float *spheres, const float *grad_depth,
                           const uint8_t *argmin, int N, int J, int H, int W,
                           float *grad_spheres, void *stream);
 
+/* Data-to-model loss ------------------------------------------------------------
+ * Replaces DataToModelLoss.forward (mesh/render.py:123-142) and its autograd
+ * backward in ONE pass.  depth[N,H,W] observed depth (background > 99),
+ * centres[N,J,3], radii[J].  Per pixel with depth <= 99:
+ *   e = min_j | ||(xg,yg,depth) - c_j|| - r_j | , clamped to [0,50].
+ * loss_sum[N]: sum of e over the crop's pixels (the reference's scalar is
+ *   sum(loss_sum) / (N*H*W)).
+ * grad_centres[N,J,3] (may be NULL): d loss_sum[n] / d c_j; the caller scales it
+ *   by upstream/(N*H*W).  Deterministic (no atomics). */
+int shr_data_to_model(const float *depth, const float *centres, const float *radii,
+                      int N, int J, int H, int W, float *loss_sum,
+                      float *grad_centres, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

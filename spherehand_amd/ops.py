@@ -91,3 +91,47 @@ class SphereDepthRaster(torch.autograd.Function):
     def backward(ctx, grad_depth):
         spheres, owner = ctx.saved_tensors
         return sphere_raster_bwd(spheres, grad_depth.contiguous(), owner), None, None
+
+
+def data_to_model(depth, centres, radii, want_grad=False):
+    """depth [N,H,W], centres [N,J,3], radii [J] -> loss_sum [N] (and the unit
+    gradient d loss_sum[n]/d centres [N,J,3])."""
+    _check_input(depth, "depth")
+    _check_input(centres, "centres")
+    _check_input(radii, "radii")
+    if depth.dim() != 3 or centres.dim() != 3 or centres.shape[2] != 3 or centres.shape[0] != depth.shape[0]:
+        raise RuntimeError("depth must be [N,H,W] and centres [N,J,3]")
+    N, H, W = depth.shape
+    J = centres.shape[1]
+    if radii.numel() != J:
+        raise RuntimeError("radii must have J entries")
+    with torch.cuda.device(depth.device):
+        loss_sum = torch.empty(N, dtype=torch.float32, device=depth.device)
+        grad = torch.empty((N, J, 3), dtype=torch.float32, device=depth.device) if want_grad else None
+        _lib.check(_lib.lib().shr_data_to_model(_ptr(depth), _ptr(centres), _ptr(radii), N, J, H, W,
+                                                _ptr(loss_sum), _ptr(grad), _stream()), "shr_data_to_model")
+    return (loss_sum, grad) if want_grad else loss_sum
+
+
+class DataToModel(torch.autograd.Function):
+    """mean over ALL N*H*W pixels of the clamped point-to-sphere-surface distance
+    (mesh/render.py:123-142).  The kernel emits the unit gradient with the loss;
+    backward only scales it."""
+
+    @staticmethod
+    def forward(ctx, depth, centres, radii):
+        depth = depth.contiguous()
+        centres = centres.contiguous()
+        count = float(depth.numel())
+        if ctx.needs_input_grad[1]:
+            loss_sum, grad = data_to_model(depth, centres, radii, want_grad=True)
+            ctx.save_for_backward(grad)
+            ctx.count = count
+        else:
+            loss_sum = data_to_model(depth, centres, radii)
+        return (loss_sum.double().sum() / count).float()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (grad,) = ctx.saved_tensors
+        return None, grad * (grad_out / ctx.count), None

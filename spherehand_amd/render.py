@@ -4,12 +4,14 @@ signatures and return values), running on the hand-written HIP kernels.
 
     BallRender               mesh/render.py:10-53
     HandBallPrimitiveRender  mesh/render.py:56-90
+    DataToModelLoss          mesh/render.py:93-142
 """
 import numpy as np
 import torch
 import torch.nn as nn
 
 from . import ops
+from .hand_model import radii_of
 from .kinematicsTransformation import keypoint_skinning
 
 
@@ -65,3 +67,24 @@ class HandBallPrimitiveRender(nn.Module):
                 balls = self.ball_renderer(flat[:, 0:3], flat[:, 3])
         part_maps = balls.view(B, self.num_vertices, self.height, self.width)
         return part_maps, depth_maps
+
+
+class DataToModelLoss(nn.Module):
+    """forward(dms[N,H,W], joints[N,J,3]) -> scalar: mean over all pixels of
+    clamp(min_j | ||(xg,yg,depth) - c_j|| - r_j |, 0, 50) on pixels with depth <=
+    99 (mesh/render.py:123-142).  `mesh` is the model dict or a list of radii
+    (mesh/render.py:107-117)."""
+
+    def __init__(self, width, height, mesh):
+        super().__init__()
+        self.width = width
+        self.height = height
+        radiuses = torch.from_numpy(np.asarray(radii_of(mesh), np.float32))
+        self.num_joints = len(radiuses)
+        self.register_buffer('radiuses', radiuses.view(1, 1, 1, self.num_joints))
+
+    def forward(self, dms, joints):
+        num_batch = dms.shape[0]
+        joints = joints.reshape(num_batch, self.num_joints, 3)
+        return ops.DataToModel.apply(dms.reshape(num_batch, self.height, self.width).float(), joints.float(),
+                                     self.radiuses.view(-1))

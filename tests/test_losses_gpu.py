@@ -1,0 +1,81 @@
+"""GPU parity of the render losses (through the C ABI) vs the CPU oracle and the
+reference's golden vectors.  These are sums of continuous per-pixel terms:
+tolerance 1e-5 relative on the loss, 1e-5 * max|grad| + 1e-7 on gradients (fp32
+summation order + a <= 1 ulp sqrt differ from the oracle's fp64 accumulation)."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_data_to_model_vs_reference_and_oracle(oracle):
+    from spherehand_amd import ops
+    g = golden("g5_data_to_model.npz")
+    for t in "ab":
+        dms, joints, radii = g[t + "_dms"], g[t + "_joints"], g[t + "_radii"]
+        loss_sum, grad = ops.data_to_model(dev(dms), dev(joints), dev(radii), want_grad=True)
+        o_sum = oracle.data_to_model_fwd(dms, joints, radii)
+        assert np.abs(loss_sum.cpu().numpy() - o_sum).max() <= 1e-5 * np.abs(o_sum).max()
+        loss = loss_sum.double().sum().item() / dms.size
+        assert abs(loss - float(g[t + "_loss"])) <= 1e-5 * float(g[t + "_loss"])
+        o_grad = oracle.data_to_model_bwd(dms, joints, radii) * dms.size     # oracle: grad of the mean
+        gh = grad.cpu().numpy()
+        assert np.abs(gh - o_grad).max() <= 1e-5 * np.abs(o_grad).max() + 1e-7
+        assert np.abs(gh / dms.size - g[t + "_grad_joints"]).max() <= 1e-5 * np.abs(g[t + "_grad_joints"]).max() + 1e-9
+        # loss-only launch gives the same sums
+        assert torch.equal(ops.data_to_model(dev(dms), dev(joints), dev(radii)), loss_sum)
+        # deterministic
+        l2, g2 = ops.data_to_model(dev(dms), dev(joints), dev(radii), want_grad=True)
+        assert torch.equal(l2, loss_sum) and torch.equal(g2, grad)
+
+
+@pytest.mark.parametrize("N,J,H,W", [(3, 41, 64, 64), (2, 5, 37, 53), (1, 64, 130, 70), (2, 1, 8, 8), (1, 41, 256, 256)])
+def test_data_to_model_random(oracle, N, J, H, W):
+    from spherehand_amd import ops
+    rs = np.random.RandomState(N + J + H)
+    depth = np.where(rs.uniform(size=(N, H, W)) < 0.3, rs.uniform(-60, 60, (N, H, W)), 100.0).astype(np.float32)
+    depth[0, 0, 0] = 99.0          # boundary: 99 is foreground (background = d > 99)
+    depth[0, 0, 1] = 99.5
+    centres = rs.uniform(-120, 120, (N, J, 3)).astype(np.float32)
+    radii = rs.uniform(5, 25, J).astype(np.float32)
+    loss_sum, grad = ops.data_to_model(dev(depth), dev(centres), dev(radii), want_grad=True)
+    o_sum = oracle.data_to_model_fwd(depth, centres, radii)
+    assert np.abs(loss_sum.cpu().numpy() - o_sum).max() <= 1e-5 * np.abs(o_sum).max() + 1e-6
+    o_grad = oracle.data_to_model_bwd(depth, centres, radii) * depth.size
+    assert np.abs(grad.cpu().numpy() - o_grad).max() <= 1e-5 * np.abs(o_grad).max() + 1e-6
+
+
+def test_data_to_model_all_background_and_far(oracle):
+    from spherehand_amd import ops
+    depth = np.full((2, 16, 16), 100.0, np.float32)
+    depth[1, 4:8, 4:8] = 0.0
+    centres = np.zeros((2, 3, 3), np.float32)
+    centres[1] += 1000.0            # every pixel farther than the clamp: e = 50, zero gradient
+    radii = np.full(3, 10.0, np.float32)
+    loss_sum, grad = ops.data_to_model(dev(depth), dev(centres), dev(radii), want_grad=True)
+    assert loss_sum[0].item() == 0.0 and torch.all(grad[0] == 0)
+    assert loss_sum[1].item() == 16 * 50.0 and torch.all(grad[1] == 0)
+
+
+def test_data_to_model_module_autograd():
+    from spherehand_amd import hand_model
+    from spherehand_amd.render import DataToModelLoss
+    g = golden("g5_data_to_model.npz")
+    crit = DataToModelLoss(64, 64, hand_model.load_mesh()).cuda()
+    assert np.allclose(crit.radiuses.view(-1).cpu().numpy(), g["a_radii"])
+    joints = dev(g["a_joints"]).requires_grad_(True)
+    loss = crit(dev(g["a_dms"]), joints)
+    (loss * 3.0).backward()
+    assert abs(loss.item() - float(g["a_loss"])) <= 1e-5 * float(g["a_loss"])
+    ref = 3.0 * g["a_grad_joints"]
+    assert np.abs(joints.grad.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-9
+    # list-of-radii constructor (mesh/render.py:114-115)
+    crit2 = DataToModelLoss(64, 64, list(g["a_radii"])).cuda()
+    assert abs(crit2(dev(g["a_dms"]), dev(g["a_joints"])).item() - loss.item()) < 1e-9
