@@ -98,6 +98,20 @@ int shr_data_to_model(const float *depth, const float *centres, const float *rad
                       int N, int J, int H, int W, float *loss_sum,
                       float *grad_centres, void *stream);
 
+/* View-to-view projection of the sphere centres ---------------------------------
+ * Replaces MutualTransformation + the projection in MutualProjection.forward
+ * (mesh/multiview_utility.py:13-30, :62-72).  cam, inv_cam [B,V,4,4] (row-major,
+ * p' = R p + t with t in COLUMN 3, as the reference reads them), joints [B,V,J,3],
+ * radii [J].  spheres[B,V,V,J,4]: entry (b,i,j,k) = view-i joint k expressed in
+ * view j, with its radius: the sphere records the rasterizer takes (N = B*V*V). */
+int shr_mutual_project_fwd(const float *cam, const float *inv_cam, const float *joints,
+                           const float *radii, int B, int V, int J, float *spheres,
+                           void *stream);
+/* grad_joints[B,V,J,3] = sum_j R(b,i,j)^T grad_spheres[b,i,j,k].xyz (the view
+ * transforms are constants: detached at mesh/multiview_utility.py:68). */
+int shr_mutual_project_bwd(const float *cam, const float *inv_cam, const float *grad_spheres,
+                           int B, int V, int J, float *grad_joints, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,8 @@ SIGNATURES = {
     "shr_sphere_raster_bwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp], _i),
     "shr_set_tuning": ([_i, _i], _i),
     "shr_data_to_model": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
+    "shr_mutual_project_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
+    "shr_mutual_project_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "shr_selftest_sqrt": ([ctypes.c_uint, ctypes.c_uint, _vp, _vp], _i),
 }
 

@@ -1,0 +1,105 @@
+"""Multiview render losses -- the module-level API of the reference's
+mesh/multiview_utility.py (same class names, constructor arguments, forward
+signatures and return values) on the HIP kernels.
+
+    MutualTransformation        mesh/multiview_utility.py:9-30
+    MutualProjection            mesh/multiview_utility.py:32-77
+    MutualProjectionLoss        mesh/multiview_utility.py:80-130
+    MultiviewConsistencyLoss    mesh/multiview_utility.py:133-167
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .hand_model import radii_of
+from .render import DataToModelLoss
+
+
+class MutualTransformation(nn.Module):
+    """forward(T[B,V,4,4], inv_T[B,V,4,4]) -> [B,V,V,4,4], entry (i,j) = inv_T[j] @ T[i]."""
+
+    def forward(self, trans_mats, inv_trans_mats):
+        assert trans_mats.ndimension() == 4
+        return torch.matmul(inv_trans_mats.unsqueeze(1), trans_mats.unsqueeze(2))
+
+
+class MutualProjection(nn.Module):
+    """forward(cam, inv_cam, joints[B,V,J,3]) -> (depth_imgs[B,V,V,S,S],
+    projected_points[B,V,V,J,3,1]): the spheres of view i rendered in view j.
+    One projection launch + ONE rasterizer launch for all B*V*V crops (the
+    reference materialises B*V*V*J per-sphere maps, :74-76)."""
+
+    def __init__(self, img_size, mesh):
+        super().__init__()
+        self.height = img_size
+        self.width = img_size
+        radiuses = torch.from_numpy(np.asarray(radii_of(mesh), np.float32))
+        self.num_joints = len(radiuses)
+        self.register_buffer('radiuses', radiuses.view(1, 1, 1, self.num_joints))
+
+    def forward(self, camera_poses, inv_camera_poses, joints):
+        B, V, J = joints.shape[0], joints.shape[1], joints.shape[2]
+        spheres = ops.MutualProject.apply(camera_poses.detach(), inv_camera_poses.detach(), joints,
+                                          self.radiuses.view(-1))
+        depth = ops.SphereDepthRaster.apply(spheres.view(B * V * V, J, 4), self.height, self.width)
+        return depth.view(B, V, V, self.height, self.width), spheres[..., 0:3].unsqueeze(-1)
+
+
+class MutualProjectionLoss(nn.Module):
+    """forward(cam, inv_cam, joints, depth_maps[B,V,S,S], is_mv=True) ->
+    (loss, projected_dms).  loss = model->data MSE + 500 * data->model, over all V*V
+    view pairs (is_mv) or the V same-view pairs, with the reference's weights
+    (x9 / x3, mesh/multiview_utility.py:100-129)."""
+
+    def __init__(self, img_size, radiuses):
+        super().__init__()
+        self.mutual_projection = MutualProjection(img_size, radiuses)
+        self.data_to_model_criterion = DataToModelLoss(img_size, img_size, radiuses)
+        self.model_to_data_criterion = nn.MSELoss()
+
+    def forward(self, camera_poses, inv_camera_poses, joints, depth_maps, is_mv=True):
+        projected_dms, projected_joints = self.mutual_projection(camera_poses, inv_camera_poses, joints)
+        B, V = camera_poses.shape[0], camera_poses.shape[1]
+        H, W = depth_maps.shape[-2], depth_maps.shape[-1]
+        J = projected_joints.shape[3]
+        pts = projected_joints.squeeze(-1)                                     # [B,V,V,J,3]
+        if is_mv:
+            real = depth_maps.unsqueeze(1).expand(B, V, V, H, W)             # [b,i,j] = observed view j
+            model_to_data_loss = self.model_to_data_criterion(projected_dms, real) * 9
+            data_to_model_loss = self.data_to_model_criterion(
+                real.reshape(-1, H, W), pts.reshape(-1, J, 3)) * 9
+        else:
+            model_to_data_loss = 0
+            data_to_model_loss = 0
+            for k in range(3):
+                model_to_data_loss = model_to_data_loss + self.model_to_data_criterion(
+                    projected_dms[:, k, k], depth_maps[:, k])
+                data_to_model_loss = data_to_model_loss + self.data_to_model_criterion(
+                    depth_maps[:, k].contiguous(), pts[:, k, k].contiguous())
+            model_to_data_loss = model_to_data_loss * 3
+            data_to_model_loss = data_to_model_loss * 3
+        loss = model_to_data_loss + data_to_model_loss * 500
+        return loss, projected_dms
+
+
+class MultiviewConsistencyLoss(nn.Module):
+    """forward(cam[B,V,4,4], joints[B,V,J,3], hm_weight=None): joints mapped to the
+    canonical frame, pulled towards their per-coordinate median over the views
+    (mesh/multiview_utility.py:138-167)."""
+
+    def __init__(self):
+        super().__init__()
+        self.loss_func = nn.MSELoss()
+
+    def forward(self, camera_poses, joints, hm_weight=None):
+        R = camera_poses[:, :, None, 0:3, 0:3]
+        t = camera_poses[:, :, None, 0:3, 3].unsqueeze(-1)
+        canonical = torch.matmul(R, joints.unsqueeze(-1)) + t                  # [B,V,J,3,1]
+        robust_average, indices = torch.median(canonical, dim=1)
+        robust_average = robust_average.unsqueeze(1)
+        if hm_weight is not None:
+            w = hm_weight.unsqueeze(-1).repeat(1, 1, 1, 3)
+            w = torch.gather(w, dim=1, index=indices.squeeze(-1).unsqueeze(1)).unsqueeze(-1)
+            return (w * (robust_average - canonical) ** 2).sum()
+        return self.loss_func(robust_average.expand_as(canonical), canonical)

@@ -135,3 +135,36 @@ class DataToModel(torch.autograd.Function):
     def backward(ctx, grad_out):
         (grad,) = ctx.saved_tensors
         return None, grad * (grad_out / ctx.count), None
+
+
+class MutualProject(torch.autograd.Function):
+    """(cam, inv_cam [B,V,4,4], joints [B,V,J,3], radii [J]) -> spheres [B,V,V,J,4]:
+    every view's joints expressed in every view (mesh/multiview_utility.py:13-30,
+    :62-72).  Differentiable w.r.t. joints only (the transforms are detached in
+    the reference, :68)."""
+
+    @staticmethod
+    def forward(ctx, cam, inv_cam, joints, radii):
+        cam, inv_cam, joints, radii = (t.contiguous().float() for t in (cam, inv_cam, joints, radii))
+        for t, name in ((cam, "camera_poses"), (inv_cam, "inv_camera_poses"), (joints, "joints"), (radii, "radii")):
+            _check_input(t, name)
+        B, V, J = joints.shape[0], joints.shape[1], joints.shape[2]
+        if cam.shape != (B, V, 4, 4) or inv_cam.shape != (B, V, 4, 4) or joints.shape[3] != 3:
+            raise RuntimeError("expected cam/inv_cam [B,V,4,4] and joints [B,V,J,3]")
+        with torch.cuda.device(joints.device):
+            out = torch.empty((B, V, V, J, 4), dtype=torch.float32, device=joints.device)
+            _lib.check(_lib.lib().shr_mutual_project_fwd(_ptr(cam), _ptr(inv_cam), _ptr(joints), _ptr(radii), B, V, J,
+                                                         _ptr(out), _stream()), "shr_mutual_project_fwd")
+        ctx.save_for_backward(cam, inv_cam)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_spheres):
+        cam, inv_cam = ctx.saved_tensors
+        g = grad_spheres.contiguous()
+        B, V, _, J, _ = g.shape
+        with torch.cuda.device(g.device):
+            out = torch.empty((B, V, J, 3), dtype=torch.float32, device=g.device)
+            _lib.check(_lib.lib().shr_mutual_project_bwd(_ptr(cam), _ptr(inv_cam), _ptr(g), B, V, J, _ptr(out),
+                                                         _stream()), "shr_mutual_project_bwd")
+        return None, None, out, None

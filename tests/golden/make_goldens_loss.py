@@ -120,6 +120,21 @@ def main():
     l.backward()
     out["mvc_loss"] = np.asarray(l.item(), np.float64)
     out["mvc_grad_joints"] = j.grad.numpy()
+    # views that disagree (per-view noise of a few mm): a non-trivial median
+    noisy = joints_est + torch.from_numpy(np.random.RandomState(5).normal(0, 3.0, joints_est.shape).astype(np.float32))
+    j = noisy.clone().requires_grad_(True)
+    l = mvc(cam, j)
+    l.backward()
+    out["mvc2_joints"] = noisy.numpy()
+    out["mvc2_loss"] = np.asarray(l.item(), np.float64)
+    out["mvc2_grad_joints"] = j.grad.numpy()
+    w = torch.from_numpy(np.random.RandomState(6).uniform(0.1, 1.0, (B, V, 41)).astype(np.float32))
+    j = noisy.clone().requires_grad_(True)
+    l = mvc(cam, j, w)
+    l.backward()
+    out["mvc2_hm_weight"] = w.numpy()
+    out["mvc2w_loss"] = np.asarray(l.item(), np.float64)
+    out["mvc2w_grad_joints"] = j.grad.numpy()
     np.savez_compressed(os.path.join(HERE, "g4_mutual_projection.npz"), **out)
     print("done")
 

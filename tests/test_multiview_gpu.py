@@ -1,0 +1,90 @@
+"""GPU parity of the multiview projection path vs the reference's golden vectors
+(tests/golden/g4_mutual_projection.npz, B=4, V=3, 64x64)."""
+import numpy as np
+import pytest
+
+from conftest import bits, golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_projected_points_and_depth():
+    from spherehand_amd import ops
+    from spherehand_amd.multiview_utility import MutualProjection, MutualTransformation
+    g = golden("g4_mutual_projection.npz")
+    mp = MutualProjection(64, list(g["radii"])).cuda()
+    depth, pts = mp(dev(g["cam"]), dev(g["inv_cam"]), dev(g["joints"]))
+    assert depth.shape == (4, 3, 3, 64, 64) and pts.shape == (4, 3, 3, 41, 3, 1)
+    # 4x4 product + 3x3 transform: association differs from the reference's bmm -> tolerance
+    assert np.abs(pts.cpu().numpy() - g["projected_points"]).max() <= 2e-4
+    # the rasterizer fed the reference's own projected points is bit-exact
+    sph = np.concatenate([g["projected_points"][..., 0], np.broadcast_to(g["radii"][None, None, None, :, None],
+                                                                          (4, 3, 3, 41, 1))], -1).astype(np.float32)
+    d = ops.sphere_raster_fwd(dev(sph.reshape(36, 41, 4)), 64, 64).cpu().numpy().reshape(4, 3, 3, 64, 64)
+    assert np.array_equal(bits(d), bits(g["proj_ieee"]))
+    # end to end: only silhouette pixels may flip (centres differ by <= 2e-4 mm)
+    dd = depth.cpu().numpy()
+    flipped = (dd >= 100) != (g["proj_ieee"] >= 100)
+    assert flipped.mean() < 1e-4
+    assert np.abs(dd - g["proj_ieee"])[~flipped].max() < 5e-3
+    mt = MutualTransformation()(dev(g["cam"]), dev(g["inv_cam"]))
+    ref = np.einsum("bjrk,bikc->bijrc", g["inv_cam"], g["cam"])
+    assert np.abs(mt.cpu().numpy() - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("is_mv", [True, False])
+def test_mutual_projection_loss(is_mv):
+    """Loss: the depth MSE term sees (100 - depth)^2 ~ 1e4 per flipped silhouette
+    pixel, so 1e-4 relative is the natural bar; gradients 1e-3 relative to max."""
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    g = golden("g4_mutual_projection.npz")
+    crit = MutualProjectionLoss(64, list(g["radii"])).cuda()
+    joints = dev(g["joints"]).requires_grad_(True)
+    loss, proj = crit(dev(g["cam"]), dev(g["inv_cam"]), joints, dev(g["real_dms"]), is_mv)
+    loss.backward()
+    tag = "mv" if is_mv else "diag"
+    ref = float(g[tag + "_loss"])
+    assert abs(loss.item() - ref) <= 1e-4 * ref
+    gr = g[tag + "_grad_joints"]
+    assert np.abs(joints.grad.cpu().numpy() - gr).max() <= 1e-3 * np.abs(gr).max()
+    assert proj.shape == (4, 3, 3, 64, 64)
+
+
+def test_multiview_consistency_loss():
+    from spherehand_amd.multiview_utility import MultiviewConsistencyLoss
+    g = golden("g4_mutual_projection.npz")
+    crit = MultiviewConsistencyLoss()
+    joints = dev(g["joints"]).requires_grad_(True)
+    l = crit(dev(g["cam"]), joints)              # consistent views: the loss is rounding noise
+    assert abs(l.item()) < 1e-9 and abs(float(g["mvc_loss"])) < 1e-9
+    joints = dev(g["mvc2_joints"]).requires_grad_(True)
+    l = crit(dev(g["cam"]), joints)
+    l.backward()
+    assert abs(l.item() - float(g["mvc2_loss"])) <= 1e-5 * float(g["mvc2_loss"])
+    assert np.abs(joints.grad.cpu().numpy() - g["mvc2_grad_joints"]).max() <= 1e-5 * np.abs(g["mvc2_grad_joints"]).max()
+    joints = dev(g["mvc2_joints"]).requires_grad_(True)
+    l = crit(dev(g["cam"]), joints, dev(g["mvc2_hm_weight"]))
+    l.backward()
+    assert abs(l.item() - float(g["mvc2w_loss"])) <= 1e-5 * float(g["mvc2w_loss"])
+    assert np.abs(joints.grad.cpu().numpy() - g["mvc2w_grad_joints"]).max() <= 1e-5 * np.abs(g["mvc2w_grad_joints"]).max()
+
+
+def test_mutual_project_gradient_is_transpose():
+    """<spheres.xyz, G> differentiated w.r.t. joints equals sum_j R^T G (adjoint test)."""
+    from spherehand_amd import ops
+    g = golden("g4_mutual_projection.npz")
+    cam, inv = dev(g["cam"]), dev(g["inv_cam"])
+    joints = dev(g["joints"]).requires_grad_(True)
+    radii = dev(g["radii"])
+    sph = ops.MutualProject.apply(cam, inv, joints, radii)
+    G = torch.randn_like(sph)
+    (sph * G).sum().backward()
+    M = torch.matmul(inv.unsqueeze(1), cam.unsqueeze(2))[..., :3, :3]           # [B,i,j,3,3]
+    ref = torch.einsum("bijrc,bijkr->bikc", M, G[..., :3])
+    assert (joints.grad - ref).abs().max().item() < 1e-4
+    assert torch.equal(sph[..., 3], radii.view(1, 1, 1, -1).expand(4, 3, 3, 41))
