@@ -112,6 +112,36 @@ int shr_mutual_project_fwd(const float *cam, const float *inv_cam, const float *
 int shr_mutual_project_bwd(const float *cam, const float *inv_cam, const float *grad_spheres,
                            int B, int V, int J, float *grad_joints, void *stream);
 
+/* Triangle-mesh depth rasterizer (forward only) -----------------------------------
+ * Replaces depth_rasterization.forward(width, height, vertices)
+ * (mesh/cuda_kernel/depth_rasterization_cuda.cpp:15-25 ->
+ *  depth_rasterization_cuda_kernel.cu:115-134, kernel :18-113).
+ * face_vertices[B,F,3,3] = pixel-space (x, y, z) of each face's three vertices;
+ * depth[B,H,W] is initialised to 1000 and receives, per covered pixel, the
+ * minimum over faces of the 1/z-interpolated depth.  Coverage (back-face cull,
+ * per-column spans with their truncation quirks) and arithmetic follow the
+ * reference kernel; the result is order independent (integer-key atomic min). */
+int shr_tri_raster_fwd(const float *face_vertices, int B, int F, int W, int H,
+                       float *depth, void *stream);
+/* Same, with the face gather of DepthRasterization.forward (mesh/render.py:308-309)
+ * fused: vertices[B,NV,4] (x,y,z,w) + faces[F,3] vertex indices (winding already
+ * swapped for the right hand, mesh/render.py:298-300). */
+int shr_tri_raster_indexed_fwd(const float *vertices, const int32_t *faces, int B,
+                               int NV, int F, int W, int H, float *depth, void *stream);
+
+/* Skinning + orthographic camera -----------------------------------------------------
+ * Replaces LinearBlendSkinning.forward (mesh/pointTransformation.py:39-46) and
+ * OthographicalProjection.forward (:84-99).  T[B,NB,4,4]; the skin table is CSR by
+ * vertex (skin_vertex_start[NV+1], skin_bone[NS], skin_wv[NS,4] = fp32(weight *
+ * vertex) as the reference stores it, :31), bones ascending within a vertex.
+ * right_hand: negate x (:44-45).  project: 0 = skinned points only; 1 = apply the
+ * camera u = fx*x + cx*w, v = fy*y + cy*w (rand_f NULL, :88-89) or
+ * u = x*rand_f[b]*fx + cx, ..., w = 1 (rand_f given, :91-97).  out[B,NV,4]. */
+int shr_lbs_project(const float *T, int B, int NB, int NV, const int32_t *skin_vertex_start,
+                    const int32_t *skin_bone, const float *skin_wv, int right_hand,
+                    int project, float cx, float cy, float fx, float fy,
+                    const float *rand_f, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,9 @@ SIGNATURES = {
     "shr_data_to_model": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "shr_mutual_project_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "shr_mutual_project_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
+    "shr_tri_raster_fwd": ([_vp, _i, _i, _i, _i, _vp, _vp], _i),
+    "shr_tri_raster_indexed_fwd": ([_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "shr_lbs_project": ([_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp], _i),
     "shr_selftest_sqrt": ([ctypes.c_uint, ctypes.c_uint, _vp, _vp], _i),
 }
 

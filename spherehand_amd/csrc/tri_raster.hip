@@ -1,0 +1,298 @@
+// tri_raster.hip -- triangle-mesh depth rasterizer (forward only) + skinning.
+//
+// Replaces (reference file:line):
+//   mesh/cuda_kernel/depth_rasterization_cuda_kernel.cu:18-113 `kernel` and :6-16
+//   `atomicMin`, :115-134 depth_rasterization_cuda_forward  -> shr_tri_raster_fwd
+//   mesh/pointTransformation.py:39-46 LinearBlendSkinning.forward and :84-99
+//   OthographicalProjection.forward                           -> shr_lbs_project
+//
+// The reference launches one single-thread block per face that walks the face's
+// pixel columns serially and CAS-loops a float min per pixel.  Here a wave takes
+// 64 faces: lanes = faces for the set-up (cull, sort by x, inverse barycentric
+// matrix), then the wave visits the surviving faces one by one with lanes = the
+// pixels of the face's box (set-up values broadcast through SGPRs).  Every
+// pixel repeats the reference's per-column span test and per-pixel arithmetic
+// verbatim (fp32, one rounding per written operator, IEEE division; the
+// `1. / x` the reference evaluates in fp64 and rounds to fp32 equals the fp32
+// quotient exactly -- 53 >= 2*24+2 bits).  The z-buffer holds order-preserving
+// integer keys so the min is a native integer atomic (order independent, hence
+// deterministic); a second pass turns keys back into floats in place.
+#include "common.h"
+
+namespace shr {
+
+__device__ __forceinline__ uint32_t zkey(float d) {
+  const uint32_t b = __float_as_uint(d);
+  return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+constexpr uint32_t kZKeyInit = 0x447A0000u ^ 0x80000000u;  // zkey(1000.0f), .cu:122
+__device__ __forceinline__ float zkey_inv(uint32_t k) {
+  return __uint_as_float(k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+// CUDA double -> int32 conversion (cvt.rzi.s32.f64): truncate, saturate, NaN -> 0.
+// The operands here are fp32 values promoted to double, so fp32 compares suffice.
+__device__ __forceinline__ int cvt_rz_sat(float d) {
+  if (d != d) return 0;
+  if (d >= 2147483648.0f) return 2147483647;
+  if (d <= -2147483648.0f) return (int)0x80000000;
+  return (int)d;
+}
+
+struct FaceSetup {
+  float p[3][3];   // vertices sorted by x
+  float fi[9];     // inverse barycentric matrix / denominator
+  int xi_min, xi_max, r_lo, r_hi;
+  int live;
+};
+
+// .cu:25-69 for one face
+__device__ __forceinline__ FaceSetup face_setup(const float f[9], int width, int height) {
+  FaceSetup s;
+  s.live = 1;
+  if ((f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0])) s.live = 0;  // :33 back face
+  int p0, p2;
+  if (f[0] < f[3]) {
+    p0 = (f[6] < f[0]) ? 2 : 0;
+    p2 = (f[3] < f[6]) ? 2 : 1;
+  } else {
+    p0 = (f[6] < f[3]) ? 2 : 1;
+    p2 = (f[0] < f[6]) ? 2 : 0;
+  }
+  int p1 = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    if (p0 != k && p2 != k) p1 = k;
+  const int order[3] = {p0, p1, p2};
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      // select without dynamic indexing (keeps everything in registers)
+      const int o = order[a];
+      s.p[a][d] = (o == 0) ? f[d] : ((o == 1) ? f[3 + d] : f[6 + d]);
+    }
+  if (s.p[0][0] == s.p[2][0]) s.live = 0;  // :54
+  float (*p)[3] = s.p;
+  s.fi[0] = p[1][1] - p[2][1]; s.fi[1] = p[2][0] - p[1][0]; s.fi[2] = p[1][0] * p[2][1] - p[2][0] * p[1][1];
+  s.fi[3] = p[2][1] - p[0][1]; s.fi[4] = p[0][0] - p[2][0]; s.fi[5] = p[2][0] * p[0][1] - p[0][0] * p[2][1];
+  s.fi[6] = p[0][1] - p[1][1]; s.fi[7] = p[1][0] - p[0][0]; s.fi[8] = p[0][0] * p[1][1] - p[1][0] * p[0][1];
+  const float den = (p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1])) + p[1][0] * (p[2][1] - p[0][1]);
+#pragma unroll
+  for (int k = 0; k < 9; k++) s.fi[k] = s.fi[k] / den;
+  // :68-69  max(ceil(x0), 0.) / min(x2, width - 1.)  (fmax/fmin drop a NaN operand)
+  s.xi_min = cvt_rz_sat(fmaxf(ceilf(p[0][0]), 0.f));
+  s.xi_max = cvt_rz_sat(fminf(p[2][0], (float)width - 1.f));
+  // conservative row range of the columns' spans (the span ends are edge
+  // interpolations, inside the vertices' y range up to rounding; row 0 is always
+  // reachable: a negative span end truncates to 0, :89-90)
+  const float ylo = fminf(fminf(p[0][1], p[1][1]), p[2][1]);
+  const float yhi = fmaxf(fmaxf(p[0][1], p[1][1]), p[2][1]);
+  const bool wild = !(fabsf(ylo) < 1e9f) || !(fabsf(yhi) < 1e9f);
+  s.r_lo = wild ? 0 : max(0, (int)floorf(ylo) - 1);
+  s.r_hi = wild ? height - 1 : min(height - 1, max(0, (int)ceilf(yhi) + 1));
+  if (s.xi_min > s.xi_max) s.live = 0;
+  return s;
+}
+
+// .cu:72-110 for pixel (xi, yi) of a set-up face whose values sit in SGPRs
+__device__ __forceinline__ void face_pixel(const float p[3][3], const float fi[9], int xi, int yi, int width,
+                                           int height, uint32_t *zrow_base) {
+  const float xf = (float)xi;
+  float yi1;
+  if (xf <= p[1][0]) {
+    if (p[1][0] - p[0][0] != 0.f) yi1 = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (xf - p[0][0]) + p[0][1];
+    else yi1 = p[1][1];
+  } else {
+    if (p[2][0] - p[1][0] != 0.f) yi1 = (p[2][1] - p[1][1]) / (p[2][0] - p[1][0]) * (xf - p[1][0]) + p[1][1];
+    else yi1 = p[1][1];
+  }
+  const float yi2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * (xf - p[0][0]) + p[0][1];
+  const int yi_min = cvt_rz_sat(fmaxf(0.f, ceilf(fminf(yi1, yi2))));
+  const int yi_max = cvt_rz_sat(fminf(fmaxf(yi1, yi2), (float)height - 1.f));
+  if (yi < yi_min || yi > yi_max) return;
+  const float yf = (float)yi;
+  float w[3];
+  float w_sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    w[k] = (fi[3 * k + 0] * xf + fi[3 * k + 1] * yf) + fi[3 * k + 2];
+    w[k] = fminf(fmaxf(w[k], 0.f), 1.f);
+    w_sum += w[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) w[k] = w[k] / w_sum;
+  const float zp = 1.0f / ((w[0] / p[0][2] + w[1] / p[1][2]) + w[2] / p[2][2]);
+  if (zp == zp) atomicMin(zrow_base + (size_t)yi * width + xi, zkey(zp));  // fminf(NaN, old) = old
+}
+
+template <bool INDEXED>
+__global__ void __launch_bounds__(256)
+tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, int B, int F, int NV, int width,
+                  int height, uint32_t *__restrict__ zbuf) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int groups = (F + 63) / 64;
+  const int b = wave_global / groups;
+  if (b >= B) return;
+  const int fidx = (wave_global - b * groups) * 64 + lane;
+
+  float f[9];
+  bool have = fidx < F;
+  if (have) {
+    if (INDEXED) {  // vertices [B,NV,4] + faces [F,3]: the gather of mesh/render.py:308-309 fused
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float4 v = reinterpret_cast<const float4 *>(src)[(size_t)b * NV + faces[fidx * 3 + k]];
+        f[3 * k] = v.x; f[3 * k + 1] = v.y; f[3 * k + 2] = v.z;
+      }
+    } else {
+      const float *fp = src + ((size_t)b * F + fidx) * 9;
+#pragma unroll
+      for (int k = 0; k < 9; k++) f[k] = fp[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; k++) f[k] = 0.f;
+  }
+  FaceSetup s = face_setup(f, width, height);
+  unsigned long long live = __ballot(have && s.live);
+  uint32_t *zimg = zbuf + (size_t)b * width * height;
+
+  while (live) {
+    const int src_lane = __builtin_amdgcn_readfirstlane(__builtin_ctzll(live));
+    live &= live - 1;
+    float p[3][3], fi[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) p[a][d] = readlane_f(s.p[a][d], src_lane);
+#pragma unroll
+    for (int k = 0; k < 9; k++) fi[k] = readlane_f(s.fi[k], src_lane);
+    const int x0 = __builtin_amdgcn_readlane(s.xi_min, src_lane), x1 = __builtin_amdgcn_readlane(s.xi_max, src_lane);
+    const int r0 = __builtin_amdgcn_readlane(s.r_lo, src_lane), r1 = __builtin_amdgcn_readlane(s.r_hi, src_lane);
+    const int bw = x1 - x0 + 1, bh = r1 - r0 + 1;
+    if (bh <= 0) continue;
+    // lanes tile the box 8 columns x 8 rows at a time
+    for (int oy = 0; oy < bh; oy += 8)
+      for (int ox = 0; ox < bw; ox += 8) {
+        const int xi = x0 + ox + (lane & 7), yi = r0 + oy + (lane >> 3);
+        if (xi <= x1 && yi <= r1) face_pixel(p, fi, xi, yi, width, height, zimg);
+      }
+  }
+}
+
+__global__ void zbuf_fill_kernel(uint4 *__restrict__ z, size_t n4, uint32_t key, uint32_t *__restrict__ tail,
+                                 int ntail) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const uint4 v = make_uint4(key, key, key, key);
+  for (; i < n4; i += stride) z[i] = v;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = key;
+}
+
+__global__ void zbuf_decode_kernel(uint4 *__restrict__ z, size_t n4, uint32_t *__restrict__ tail, int ntail) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    uint4 k = z[i];
+    k.x = __float_as_uint(zkey_inv(k.x)); k.y = __float_as_uint(zkey_inv(k.y));
+    k.z = __float_as_uint(zkey_inv(k.z)); k.w = __float_as_uint(zkey_inv(k.w));
+    z[i] = k;
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = __float_as_uint(zkey_inv(tail[threadIdx.x]));
+}
+
+// ---------------------------------------------------------------------------------------
+// Skinning + camera.  One thread per (sample, vertex); the sample's bone matrices are
+// staged in LDS.  Visits only the non-zero (bone, vertex) pairs of the reference's dense
+// sum, in ascending bone order (association documented in DESIGN.md).
+__global__ void __launch_bounds__(256)
+lbs_project_kernel(const float *__restrict__ T, int NB, int NV, const int *__restrict__ vstart,
+                   const int *__restrict__ sbone, const float4 *__restrict__ swv, int right_hand, int project,
+                   float cx, float cy, float fx, float fy, const float *__restrict__ rand_f,
+                   float4 *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float s_T[];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < NB * 16; i += blockDim.x) s_T[i] = T[(size_t)b * NB * 16 + i];
+  __syncthreads();
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= NV) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int e = vstart[v]; e < vstart[v + 1]; e++) {
+    const float *M = s_T + sbone[e] * 16;
+    const float4 q = swv[e];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      acc[r] += ((M[4 * r] * q.x + M[4 * r + 1] * q.y) + M[4 * r + 2] * q.z) + M[4 * r + 3] * q.w;
+  }
+  if (right_hand) acc[0] = -acc[0];
+  float4 o;
+  if (!project) {
+    o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  } else if (!rand_f) {
+    o = make_float4(fx * acc[0] + cx * acc[3], fy * acc[1] + cy * acc[3], acc[2], acc[3]);
+  } else {
+    const float rf = rand_f[b];
+    o = make_float4(acc[0] * rf * fx + cx, acc[1] * rf * fy + cy, acc[2], 1.0f);
+  }
+  out[(size_t)b * NV + v] = o;
+}
+
+}  // namespace shr
+
+using namespace shr;
+
+static int tri_raster_common(bool indexed, const float *src, const int *faces, int B, int F, int NV, int W, int H,
+                             float *depth, hipStream_t s) {
+  const size_t n = (size_t)B * W * H;
+  uint32_t *z = reinterpret_cast<uint32_t *>(depth);
+  const size_t n4 = n / 4;
+  const int ntail = (int)(n - n4 * 4);
+  const unsigned fill_blocks = (unsigned)((n4 + 255) / 256 > 4096 ? 4096 : ((n4 + 255) / 256 ? (n4 + 255) / 256 : 1));
+  hipLaunchKernelGGL(zbuf_fill_kernel, dim3(fill_blocks), dim3(256), 0, s, reinterpret_cast<uint4 *>(z), n4,
+                     kZKeyInit, z + n4 * 4, ntail);
+  if (F > 0) {
+    const long long waves = (long long)B * ((F + 63) / 64);
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    if (indexed)
+      hipLaunchKernelGGL(tri_raster_kernel<true>, dim3(blocks), dim3(256), 0, s, src, faces, B, F, NV, W, H, z);
+    else
+      hipLaunchKernelGGL(tri_raster_kernel<false>, dim3(blocks), dim3(256), 0, s, src, faces, B, F, NV, W, H, z);
+  }
+  hipLaunchKernelGGL(zbuf_decode_kernel, dim3(fill_blocks), dim3(256), 0, s, reinterpret_cast<uint4 *>(z), n4,
+                     z + n4 * 4, ntail);
+  return (int)hipGetLastError();
+}
+
+extern "C" int shr_tri_raster_fwd(const float *face_vertices, int B, int F, int W, int H, float *depth,
+                                  void *stream) {
+  if (B == 0) return SHR_OK;
+  if (!depth || (!face_vertices && F > 0) || B < 0 || F < 0 || W <= 0 || H <= 0) return SHR_EINVAL;
+  if ((long long)B * W * H > (1LL << 40) || (long long)B * ((F + 63) / 64) > (1LL << 31)) return SHR_ETOOLARGE;
+  if (((uintptr_t)depth & 15u) != 0) return SHR_EINVAL;
+  return tri_raster_common(false, face_vertices, nullptr, B, F, 0, W, H, depth, (hipStream_t)stream);
+}
+
+extern "C" int shr_tri_raster_indexed_fwd(const float *vertices, const int32_t *faces, int B, int NV, int F, int W,
+                                          int H, float *depth, void *stream) {
+  if (B == 0) return SHR_OK;
+  if (!depth || !vertices || (!faces && F > 0) || B < 0 || F < 0 || NV <= 0 || W <= 0 || H <= 0) return SHR_EINVAL;
+  if ((long long)B * W * H > (1LL << 40) || (long long)B * ((F + 63) / 64) > (1LL << 31)) return SHR_ETOOLARGE;
+  if ((((uintptr_t)depth | (uintptr_t)vertices) & 15u) != 0) return SHR_EINVAL;
+  return tri_raster_common(true, vertices, faces, B, F, NV, W, H, depth, (hipStream_t)stream);
+}
+
+extern "C" int shr_lbs_project(const float *T, int B, int NB, int NV, const int32_t *skin_vertex_start,
+                               const int32_t *skin_bone, const float *skin_wv, int right_hand, int project, float cx,
+                               float cy, float fx, float fy, const float *rand_f, float *out, void *stream) {
+  if (B == 0 || NV == 0) return SHR_OK;
+  if (!T || !skin_vertex_start || !skin_bone || !skin_wv || !out || B < 0 || NB <= 0 || NV < 0) return SHR_EINVAL;
+  if ((((uintptr_t)skin_wv | (uintptr_t)out) & 15u) != 0) return SHR_EINVAL;
+  if (B > 65535 || NB > 2048) return SHR_ETOOLARGE;
+  dim3 grid((unsigned)((NV + 255) / 256), (unsigned)B);
+  hipLaunchKernelGGL(lbs_project_kernel, grid, dim3(256), (size_t)NB * 64, (hipStream_t)stream, T, NB, NV,
+                     skin_vertex_start, skin_bone, reinterpret_cast<const float4 *>(skin_wv), right_hand, project, cx,
+                     cy, fx, fy, rand_f, reinterpret_cast<float4 *>(out));
+  return (int)hipGetLastError();
+}

@@ -168,3 +168,53 @@ class MutualProject(torch.autograd.Function):
             _lib.check(_lib.lib().shr_mutual_project_bwd(_ptr(cam), _ptr(inv_cam), _ptr(g), B, V, J, _ptr(out),
                                                          _stream()), "shr_mutual_project_bwd")
         return None, None, out, None
+
+
+def tri_raster_fwd(width, height, face_vertices):
+    """face_vertices [B,F,3,3] (pixel-space x,y,z) -> depth [B,height,width],
+    background 1000: depth_rasterization.forward (mesh/cuda_kernel)."""
+    _check_input(face_vertices, "vertices")
+    if face_vertices.dim() < 2:
+        raise RuntimeError("vertices must be [B,F,3,3]")
+    B, F = face_vertices.shape[0], face_vertices.shape[1]
+    if face_vertices.numel() != B * F * 9:
+        raise RuntimeError("vertices must hold 9 floats per face ([B,F,3,3])")
+    with torch.cuda.device(face_vertices.device):
+        depth = torch.empty((B, height, width), dtype=torch.float32, device=face_vertices.device)
+        _lib.check(_lib.lib().shr_tri_raster_fwd(_ptr(face_vertices), B, F, width, height, _ptr(depth), _stream()),
+                   "shr_tri_raster_fwd")
+    return depth
+
+
+def tri_raster_indexed_fwd(width, height, vertices, faces):
+    """vertices [B,NV,4] + faces [F,3] int32 -> depth [B,height,width] (gather fused)."""
+    _check_input(vertices, "vertices")
+    _check_input(faces, "faces", torch.int32)
+    if vertices.dim() != 3 or vertices.shape[2] != 4 or faces.dim() != 2 or faces.shape[1] != 3:
+        raise RuntimeError("vertices must be [B,NV,4] and faces [F,3]")
+    B, NV = vertices.shape[0], vertices.shape[1]
+    with torch.cuda.device(vertices.device):
+        depth = torch.empty((B, height, width), dtype=torch.float32, device=vertices.device)
+        _lib.check(_lib.lib().shr_tri_raster_indexed_fwd(_ptr(vertices), _ptr(faces), B, NV, faces.shape[0], width,
+                                                         height, _ptr(depth), _stream()),
+                   "shr_tri_raster_indexed_fwd")
+    return depth
+
+
+def lbs_project(T, skin_vertex_start, skin_bone, skin_wv, right_hand=True, camera=None, rand_f=None):
+    """T [B,NB,4,4] -> skinned (and, with camera=(cx,cy,fx,fy), projected) vertices [B,NV,4]."""
+    _check_input(T, "bone_transformations")
+    _check_input(skin_vertex_start, "skin_vertex_start", torch.int32)
+    _check_input(skin_bone, "skin_bone", torch.int32)
+    _check_input(skin_wv, "skin_wv")
+    if rand_f is not None:
+        _check_input(rand_f, "rand_f")
+    B, NB = T.shape[0], T.shape[1]
+    NV = skin_vertex_start.numel() - 1
+    cx, cy, fx, fy = camera if camera is not None else (0.0, 0.0, 1.0, 1.0)
+    with torch.cuda.device(T.device):
+        out = torch.empty((B, NV, 4), dtype=torch.float32, device=T.device)
+        _lib.check(_lib.lib().shr_lbs_project(_ptr(T), B, NB, NV, _ptr(skin_vertex_start), _ptr(skin_bone),
+                                              _ptr(skin_wv), int(bool(right_hand)), int(camera is not None),
+                                              cx, cy, fx, fy, _ptr(rand_f), _ptr(out), _stream()), "shr_lbs_project")
+    return out

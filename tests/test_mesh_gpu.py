@@ -1,0 +1,123 @@
+"""GPU parity of the triangle-mesh path (through the C ABI): triangle rasterizer
+bit-exact vs the CPU oracle; skinning / camera bit-exact vs the oracle and within
+tolerance of the reference's dense torch result; DepthRender end to end vs the
+reference pipeline (tests/golden/g2_mesh.npz, see its generator for what is and
+is not the reference's code)."""
+import numpy as np
+import pytest
+
+from conftest import bits, golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_tri_raster_full_size_vs_oracle(oracle):
+    """4 poses x 3382 faces at the reference's 640x640 working resolution."""
+    import depth_rasterization
+    g = golden("g2_mesh.npz")
+    fv = g["face_vertices"]
+    d = depth_rasterization.forward(640, 640, dev(fv))
+    assert d.shape == (4, 640, 640) and d.dtype == torch.float32 and d.is_cuda
+    o = oracle.tri_raster_fwd(fv, 640, 640)
+    assert np.array_equal(bits(d.cpu().numpy()), bits(o))
+    assert np.array_equal(bits(d.cpu().numpy()[0]), bits(g["raw640_first"]))
+    assert d.max().item() == 1000.0
+    # order independence: faces reversed -> identical image
+    d2 = depth_rasterization.forward(640, 640, dev(fv[:, ::-1]))
+    assert torch.equal(d, d2)
+    # width != height: output is [B, height, width]
+    fv2 = fv[:1].copy()
+    d3 = depth_rasterization.forward(320, 640, dev(fv2))
+    assert d3.shape == (1, 640, 320)
+    assert np.array_equal(bits(d3.cpu().numpy()), bits(oracle.tri_raster_fwd(fv2, 320, 640)))
+
+
+def test_tri_raster_quirks_and_edge_cases(oracle):
+    import depth_rasterization
+    tri = np.array([
+        [[-0.5, -0.7, 5], [-0.2, 3.0, 5], [-0.1, -0.6, 5]],
+        [[2, 2, 0], [2, 9, 4], [9, 2, 4]],
+        [[5, 5, 3], [5, 9, 3], [5, 7, 3]],
+        [[1, 1, 3], [4, 4, 3], [7, 7, 3]],
+        [[np.nan, 1, 3], [4, 2, 3], [7, 9, 3]],
+        [[3, 12, 2], [12, 3, 2], [3, 3, -2]],
+        [[-40, -30, 7], [60, -20, 7], [10, 70, 7]],            # larger than the image
+    ], np.float32)[None]
+    for fv in (tri, tri[:, ::-1], tri[:, :, [1, 0, 2], :]):
+        for (W, H) in ((16, 16), (17, 9), (5, 33)):
+            d = depth_rasterization.forward(W, H, dev(fv)).cpu().numpy()
+            assert np.array_equal(bits(d), bits(oracle.tri_raster_fwd(fv, W, H))), (W, H)
+    # no faces: all background; empty batch
+    e = depth_rasterization.forward(8, 8, torch.empty(2, 0, 3, 3, device="cuda"))
+    assert e.shape == (2, 8, 8) and torch.all(e == 1000.0)
+    assert depth_rasterization.forward(8, 8, torch.empty(0, 5, 3, 3, device="cuda")).shape == (0, 8, 8)
+    with pytest.raises(RuntimeError):
+        depth_rasterization.forward(8, 8, torch.zeros(1, 4, 3, 3))                     # not a CUDA tensor
+    with pytest.raises(RuntimeError):
+        depth_rasterization.forward(8, 8, torch.zeros(1, 3, 4, 3, device="cuda").transpose(1, 2))  # not contiguous
+
+
+def test_random_faces_vs_oracle(oracle):
+    import depth_rasterization
+    rs = np.random.RandomState(4)
+    B, F, W, H = 3, 500, 96, 72
+    c = rs.uniform(-10, [W + 10, H + 10], (B, F, 1, 2))
+    fv = np.concatenate([c + rs.normal(0, 6, (B, F, 3, 2)), rs.uniform(-30, 60, (B, F, 3, 1))], -1).astype(np.float32)
+    d = depth_rasterization.forward(W, H, dev(fv)).cpu().numpy()
+    assert np.array_equal(bits(d), bits(oracle.tri_raster_fwd(fv, W, H)))
+
+
+def test_lbs_project(oracle):
+    from spherehand_amd import hand_model, ops
+    g = golden("g2_mesh.npz")
+    start, bone, wv = hand_model.sparse_skin(hand_model.load_mesh())
+    cam = (320.0, 320.0, 640 / 300, 640 / 300)
+    args = (dev(g["T"]), dev(start), dev(bone), dev(wv))
+    for camera, rand_f, ref in ((None, None, g["skinned"]), (cam, None, g["verts"]), (cam, g["rand_f"], g["verts_rand_f"])):
+        out = ops.lbs_project(*args, True, camera, None if rand_f is None else dev(rand_f)).cpu().numpy()
+        o = oracle.lbs_project(g["T"], start, bone, wv, True, camera, rand_f)
+        assert np.array_equal(bits(out), bits(o))
+        assert np.abs(out - ref).max() <= 1e-4          # reference's dense bmm + sum: different association
+
+
+def test_depth_render_end_to_end():
+    """T -> depth [B,S,S]: skinning, camera, raster at 640, clamp, bilinear resize.
+    The vertices differ from the reference's by <= 1e-4 px (association), so a few
+    silhouette pixels of the 640x640 raster may flip: bar = < 0.1 % of pixels off
+    by more than 1e-3 mm."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.render import DepthRender
+    g = golden("g2_mesh.npz")
+    mesh = hand_model.load_mesh()
+    faces_before = mesh["faces"].copy()
+    for S in (64, 128, 256):
+        render = DepthRender(mesh, S).cuda()
+        d = render(dev(g["T"])).cpu().numpy()
+        ref = g["depth%d" % S]
+        assert d.shape == ref.shape
+        off = np.abs(d - ref) > 1e-3
+        assert off.mean() < 1e-3, (S, off.mean())
+    assert np.array_equal(mesh["faces"], faces_before)        # the caller's array is not mutated
+    d = DepthRender(mesh, 64).cuda()(dev(g["T"]), dev(g["rand_f"])).cpu().numpy()
+    assert (np.abs(d - g["depth64_rand_f"]) > 1e-3).mean() < 1e-3
+
+
+def test_depth_rasterization_module_paths_agree():
+    """Fused indexed raster == explicit gather + depth_rasterization.forward."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.render import DepthRasterization, DepthRasterizationFunction
+    g = golden("g2_mesh.npz")
+    mesh = hand_model.load_mesh()
+    r = DepthRasterization(128, 128, mesh["faces"]).cuda()
+    verts = dev(g["verts"])
+    a = r(verts)
+    fv = verts[:, r.faces, 0:3].view(4, r.num_faces, 3, 3)
+    assert np.abs(fv.cpu().numpy() - g["face_vertices"]).max() <= 1e-4
+    b = torch.nn.functional.interpolate(DepthRasterizationFunction.apply(640, 640, fv).unsqueeze(1), size=(128, 128),
+                                        mode="bilinear", align_corners=False).squeeze(1)
+    assert torch.equal(a, b)
