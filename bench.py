@@ -44,14 +44,14 @@ def make_inputs(rank, device):
     from spherehand_amd.render import HandBallPrimitiveRender
     from spherehand_amd.kinematicsTransformation import HandTransformationMat
     mesh = hand_model.load_mesh()
-    params = sample_poses(BATCH, seed=rank)
-    fk = HandTransformationMat([b["offset_matrix"].astype("float32") for b in mesh["bones"]])
-    hbr = HandBallPrimitiveRender(mesh["bones"], S, S)
+    params = sample_poses(BATCH, seed=rank).to(device)
+    fk = HandTransformationMat([b["offset_matrix"].astype("float32") for b in mesh["bones"]]).to(device)
+    hbr = HandBallPrimitiveRender(mesh["bones"], S, S).to(device)
     with torch.no_grad():
-        spheres = hbr.spheres(fk(params)).contiguous()          # [256,41,4] on CPU (torch plumbing)
+        spheres = hbr.spheres(fk(params)).contiguous()          # [256,41,4]: HIP forward kinematics
     g = torch.Generator().manual_seed(1)
     grad = torch.randn(BATCH, S, S, generator=g)
-    return spheres.to(device), grad.to(device)
+    return spheres, grad.to(device)
 
 
 def cpu_baseline(spheres_host, grad_host, budget_s=10.0):

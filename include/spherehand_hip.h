@@ -142,6 +142,17 @@ int shr_lbs_project(const float *T, int B, int NB, int NV, const int32_t *skin_v
                     int project, float cx, float cy, float fx, float fy,
                     const float *rand_f, float *out, void *stream);
 
+/* Forward kinematics -------------------------------------------------------------------
+ * Replaces HandTransformationMat.forward (mesh/kinematicsTransformation.py:157-177)
+ * and its autograd backward.  params[B,26] (palm Euler xyz, palm translation, 5 x
+ * (abduct, flex1, flex2, flex3)); offset, offset_inv [17,4,4] = the bones' offset
+ * matrices and their inverses; T[B,17,4,4] (bones 0 and 1 = palm transform). */
+int shr_fk_fwd(const float *params, int B, const float *offset, const float *offset_inv,
+               float *T, void *stream);
+/* grad_params[B,26] = d<grad_T, T>/d params (analytic reverse mode). */
+int shr_fk_bwd(const float *params, int B, const float *offset, const float *offset_inv,
+               const float *grad_T, float *grad_params, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,8 @@ SIGNATURES = {
     "shr_tri_raster_fwd": ([_vp, _i, _i, _i, _i, _vp, _vp], _i),
     "shr_tri_raster_indexed_fwd": ([_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
     "shr_lbs_project": ([_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp], _i),
+    "shr_fk_fwd": ([_vp, _i, _vp, _vp, _vp, _vp], _i),
+    "shr_fk_bwd": ([_vp, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "shr_selftest_sqrt": ([ctypes.c_uint, ctypes.c_uint, _vp, _vp], _i),
 }
 

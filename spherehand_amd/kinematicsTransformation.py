@@ -34,12 +34,22 @@ class HandTransformationMat(nn.Module):
         super().__init__()
         off = torch.from_numpy(np.stack([np.asarray(m, np.float32) for m in offset_mats]))
         self.register_buffer('offset', off)                          # [17,4,4]
-        self.register_buffer('offset_inv', torch.inverse(off))       # :87
+        self.register_buffer('offset_inv', torch.inverse(off).contiguous())  # :87
         ab = torch.tensor([[0, 0, 1], [0, 0, 1], [0, -1, 0], [0, -1, 0], [0, 0, 1]], dtype=torch.float32)
         self.register_buffer('abduct_axis', ab)                      # :162-164
         self.register_buffer('axes', torch.eye(3))
 
     def forward(self, parameters):
+        # one HIP launch forward, one backward (forward_torch below is ~60 torch ops)
+        if not parameters.is_cuda:
+            raise RuntimeError("parameters must be a CUDA tensor: forward kinematics runs on the HIP kernel "
+                               "(forward_torch() is the explicit torch-op evaluation for host-side fixtures)")
+        from . import ops
+        return ops.ForwardKinematics.apply(parameters, self.offset, self.offset_inv)
+
+    def forward_torch(self, parameters):
+        """The same map written with torch ops (any device, autograd by torch):
+        fixture preparation and the independent check of the HIP kernels."""
         p = parameters
         B = p.shape[0]
         ex, ey, ez = self.axes[0], self.axes[1], self.axes[2]

@@ -218,3 +218,34 @@ def lbs_project(T, skin_vertex_start, skin_bone, skin_wv, right_hand=True, camer
                                               _ptr(skin_wv), int(bool(right_hand)), int(camera is not None),
                                               cx, cy, fx, fy, _ptr(rand_f), _ptr(out), _stream()), "shr_lbs_project")
     return out
+
+
+class ForwardKinematics(torch.autograd.Function):
+    """params [B,26] -> bone transforms [B,17,4,4] (mesh/kinematicsTransformation.py:169-177),
+    analytic backward; offset / offset_inv [17,4,4] are constants."""
+
+    @staticmethod
+    def forward(ctx, params, offset, offset_inv):
+        params = params.contiguous().float()
+        for t, name in ((params, "parameters"), (offset, "offset"), (offset_inv, "offset_inv")):
+            _check_input(t, name)
+        if params.dim() != 2 or params.shape[1] != 26:
+            raise RuntimeError("parameters must be [B,26]")
+        B = params.shape[0]
+        with torch.cuda.device(params.device):
+            T = torch.empty((B, 17, 4, 4), dtype=torch.float32, device=params.device)
+            _lib.check(_lib.lib().shr_fk_fwd(_ptr(params), B, _ptr(offset), _ptr(offset_inv), _ptr(T), _stream()),
+                       "shr_fk_fwd")
+        ctx.save_for_backward(params, offset, offset_inv)
+        return T
+
+    @staticmethod
+    def backward(ctx, grad_T):
+        params, offset, offset_inv = ctx.saved_tensors
+        g = grad_T.contiguous().float()
+        B = params.shape[0]
+        with torch.cuda.device(params.device):
+            out = torch.empty((B, 26), dtype=torch.float32, device=params.device)
+            _lib.check(_lib.lib().shr_fk_bwd(_ptr(params), B, _ptr(offset), _ptr(offset_inv), _ptr(g), _ptr(out),
+                                             _stream()), "shr_fk_bwd")
+        return out, None, None
