@@ -1,0 +1,150 @@
+"""Network wrapper and loss assembly -- the reference's
+network/create_network_and_criterion.py surface:
+
+    HeatmapEstimationNetwork   :27-144   hourglass + soft-argmax, real / synthetic / both
+    MultiTaskLoss              :147-263  the loss terms and their weights
+    average_joint_error        network/utils_metric.py:7-17
+"""
+import torch
+import torch.nn as nn
+
+from .hourglass import create_hourglass_network
+from .multiview_utility import MultiviewConsistencyLoss, MutualProjectionLoss
+from .render import BoneLengthLoss, CollisionLoss
+from .util_modules import RecoverXYZCoordinateFromHeatmap, ResizeCropImage, TemporalSmoothnessLoss
+
+SYNT_KEY_POINTS = [33, 32, 27, 26, 21, 20, 15, 14, 39, 40, 38, 0, 1, 2]   # network/constants.py:30
+REAL_KEY_POINTS = [0, 3, 6, 9, 12, 15, 18, 21, 24, 25, 27, 30, 31, 32]    # network/constants.py:31
+
+
+def average_joint_error(gt_joints, est_joints):
+    """Mean over the 14 evaluation key-point pairs of ||gt - est||_2 (the NYU metric);
+    returned as a 0-dim tensor on the inputs' device (no host sync)."""
+    gt = gt_joints[:, :, REAL_KEY_POINTS, :].reshape(-1, len(REAL_KEY_POINTS), 3)
+    est = est_joints[:, :, SYNT_KEY_POINTS, :].reshape(-1, len(SYNT_KEY_POINTS), 3)
+    return (gt - est).norm(dim=-1).mean()
+
+
+class HeatmapEstimationNetwork(nn.Module):
+    """forward(real_dms[B,V,S,S]=None, synt_dms[N,S,S]=None) -> result dict with
+    per-stack lists 'real_uv_hms' [B,V,J,h,w], 'real_d_hms', 'real_xyz' [B,V,J,3]
+    and/or 'synt_uv_hms', 'synt_d_hms', 'synt_xyz'; with both inputs one
+    concatenated pass (+ 'batch_*_fea' latents).  Training-time scale augmentation
+    of the real crops as in the reference (:41-50, :93-102)."""
+
+    def __init__(self, heatmap_size, depth_scale, num_joints, num_stacks, real_aug=True):
+        super().__init__()
+        self.num_joints = num_joints
+        self.hg = create_hourglass_network(num_joints * 2, num_stacks)
+        self.xyz_recover = RecoverXYZCoordinateFromHeatmap(heatmap_size, heatmap_size, depth_scale)
+        self.resize_dm = ResizeCropImage() if real_aug else None
+
+    def _augment(self, dms):
+        n = dms.shape[0]
+        ones = torch.ones(n, device=dms.device)
+        if self.resize_dm is None or not self.training or torch.rand(1).item() < 0.5:
+            return dms, ones, ones
+        scale = torch.rand(n, device=dms.device) * 0.2 + 0.75
+        u_scale = scale + torch.rand_like(scale) * 0.1 - 0.05
+        v_scale = scale + torch.rand_like(scale) * 0.1 - 0.05
+        return self.resize_dm(dms, u_scale, v_scale), u_scale, v_scale
+
+    def _split(self, outputs):
+        return [o[:, :self.num_joints] for o in outputs], [o[:, self.num_joints:] for o in outputs]
+
+    def _real_result(self, uv_hms, d_hms, u_scale, v_scale, B, V):
+        inv = torch.stack([1.0 / u_scale, 1.0 / v_scale, torch.ones_like(u_scale)], dim=-1).unsqueeze(1)
+        xyz = [self.xyz_recover(uv, d, True) * inv for uv, d in zip(uv_hms, d_hms)]
+        shape5 = lambda h: h.reshape(B, V, self.num_joints, h.shape[-2], h.shape[-1])   # noqa: E731
+        return {'real_uv_hms': [shape5(h) for h in uv_hms], 'real_d_hms': [shape5(h) for h in d_hms],
+                'real_xyz': [p.reshape(B, V, self.num_joints, 3) for p in xyz]}
+
+    def forward(self, real_dms=None, synt_dms=None):
+        result = {}
+        n_synt = 0 if synt_dms is None else synt_dms.shape[0]
+        inputs = [] if synt_dms is None else [synt_dms]
+        if real_dms is not None:
+            B, V = real_dms.shape[0], real_dms.shape[1]
+            flat, u_scale, v_scale = self._augment(real_dms.reshape(B * V, real_dms.shape[2], real_dms.shape[3]))
+            inputs.append(flat)
+        outputs, latents = self.hg(torch.cat(inputs, dim=0) if len(inputs) > 1 else inputs[0])
+        if synt_dms is not None:
+            uv, d = self._split([o[:n_synt] for o in outputs])
+            result.update({'synt_uv_hms': uv, 'synt_d_hms': d,
+                           'synt_xyz': [self.xyz_recover(a, b) for a, b in zip(uv, d)]})
+        if real_dms is not None:
+            uv, d = self._split([o[n_synt:] for o in outputs])
+            result.update(self._real_result(uv, d, u_scale, v_scale, B, V))
+            if synt_dms is not None:
+                if self.resize_dm is not None:
+                    result['real_resized_dms'] = flat
+                result['batch_synt_fea'] = [l[:n_synt] for l in latents]
+                result['batch_real_fea'] = [l[n_synt:] for l in latents]
+        return result
+
+
+class MultiTaskLoss(nn.Module):
+    """forward(result, synt_target=None, real_target=None) -> (loss_terms dict,
+    projected depth maps per stack).  Same switches, terms and weights as the
+    reference (:171-181).  `mesh` = hand model dict (or `constant` object with a
+    .mesh attribute, as the reference passes); `prior_loss` = an optional module
+    with .prior_loss(xyz/100) (the reference's frozen PoseVae; not part of this
+    path -- pass an instance to enable the term)."""
+
+    def __init__(self, synthesized_loss, mv_projection_loss, mv_consistency_loss, temporal_smooth_loss,
+                 prior_loss, collision_loss, bone_length_loss, constant, image_size=64, heatmap_size=16):
+        super().__init__()
+        mesh = constant.mesh if hasattr(constant, 'mesh') else constant
+        self.synthesized_loss = nn.MSELoss() if synthesized_loss else None
+        self.mv_projection_loss = MutualProjectionLoss(image_size, mesh) if mv_projection_loss else None
+        self.mv_consistency_loss = MultiviewConsistencyLoss() if mv_consistency_loss else None
+        self.temporal_smooth_loss = TemporalSmoothnessLoss() if temporal_smooth_loss else None
+        self.prior_loss = prior_loss if isinstance(prior_loss, nn.Module) else None
+        self.collision_criterion = CollisionLoss() if collision_loss else None
+        self.bone_length_criterion = BoneLengthLoss() if bone_length_loss else None
+        self.domain_loss = nn.MSELoss()
+        self.heatmap_size = heatmap_size
+        self.weights = {'synt_hm': 1e3, 'synt_pt': 1e-1, 'mv_consistency': 1e-3, 'mv_projection': 1,
+                        'temporal_smooth': 1.0, 'prior': 1e-2, 'hm_mean': 1e-2, 'domain': 0.0,
+                        'collision': 1.0, 'bone_length': 1.0}
+
+    def forward(self, result, synt_target=None, real_target=None):
+        w, terms, projected_dms = self.weights, {}, []
+        mse = self.synthesized_loss
+        if mse is not None and synt_target is not None:
+            terms['synt_uv'] = sum(w['synt_hm'] * mse(h, synt_target['uv_hms']) for h in result['synt_uv_hms'])
+            target_z = synt_target['xyz_pts'][:, :, 2]
+            terms['synt_d'] = sum(w['synt_pt'] * mse(xyz[:, :, 2], target_z) for xyz in result['synt_xyz'])
+        is_mv = False if real_target is None else real_target.get('is_mv', True)
+        if self.mv_projection_loss is not None and real_target is not None:
+            terms['mv_projection'] = 0
+            for xyz in result['real_xyz']:
+                loss, dm = self.mv_projection_loss(real_target['camera_poses'], real_target['inv_camera_poses'], xyz,
+                                                   real_target['real_dms'], is_mv)
+                terms['mv_projection'] = terms['mv_projection'] + loss * w['mv_projection']
+                projected_dms.append(dm)
+        if self.mv_consistency_loss is not None and real_target is not None:
+            wc = w['mv_consistency'] if is_mv else 0
+            terms['mv_consistency'] = sum(wc * self.mv_consistency_loss(real_target['camera_poses'], xyz, None)
+                                          for xyz in result['real_xyz'])
+        if real_target is not None:
+            # like the reference this term needs the MSE criterion of the synthetic switch (:235)
+            terms['uv_hm_mean'] = sum(w['hm_mean'] * mse(h, torch.zeros_like(h)) for h in result['real_uv_hms'])
+        real_xyz = result.get('real_xyz', [])
+        if self.prior_loss is not None:
+            terms['pose_prior'] = sum(w['prior'] * self.prior_loss.prior_loss(xyz / 100.0) for xyz in real_xyz)
+        if self.temporal_smooth_loss is not None:
+            terms['temporal_smooth'] = sum(w['temporal_smooth'] * self.temporal_smooth_loss(xyz) for xyz in real_xyz)
+        if self.collision_criterion is not None:
+            terms['collision'] = sum(w['collision'] * self.collision_criterion(xyz) for xyz in real_xyz)
+        if self.bone_length_criterion is not None:
+            terms['bone_length'] = sum(w['bone_length'] * self.bone_length_criterion(xyz) for xyz in real_xyz)
+        if 'batch_synt_fea' in result and 'batch_real_fea' in result:
+            terms['domain_loss'] = sum(
+                w['domain'] * self.domain_loss(s.mean(dim=(0, 2, 3)), r.mean(dim=(0, 2, 3)))
+                for s, r in zip(result['batch_synt_fea'], result['batch_real_fea']))
+        return terms, projected_dms
+
+
+def combine_loss(loss_terms):
+    return sum(loss_terms.values())

@@ -163,3 +163,109 @@ class DepthRender(nn.Module):
     def forward(self, transformation_mats, rand_fx=None):
         skinned_points = self.lbs(transformation_mats, self.camera, rand_fx)
         return self.rasterizer(skinned_points)
+
+
+class HeatmapRender(nn.Module):
+    """forward(uvd_points[B,J,>=3]) -> (uv_hm[B,J,S,S], scaled_d_hm[B,J,S,S]): a
+    Gaussian exp(-0.5*sigma*d^2) per joint and the joint's depth painted where the
+    Gaussian exceeds 0.05 (mesh/render.py:226-248)."""
+
+    def __init__(self, hm_size, sigma=1.0):
+        super().__init__()
+        self.sigma = sigma
+        self.height = self.width = hm_size
+        grid = torch.arange(hm_size, dtype=torch.float32)
+        self.register_buffer('u_grid', grid.view(1, 1, 1, hm_size))
+        self.register_buffer('v_grid', grid.view(1, 1, hm_size, 1))
+
+    def forward(self, uvd_points):
+        assert uvd_points.ndimension() == 3
+        u = uvd_points[:, :, 0, None, None]
+        v = uvd_points[:, :, 1, None, None]
+        uv_hm = torch.exp(-0.5 * self.sigma * ((self.u_grid - u) ** 2 + (self.v_grid - v) ** 2))
+        d = uvd_points[:, :, 2, None, None].expand_as(uv_hm)
+        return uv_hm, torch.where(uv_hm > 0.05, d, torch.zeros_like(d))
+
+
+class Hand3DHeatmapRender(nn.Module):
+    """forward(T[B,17,4,4], rand_f=None) -> (uv heat-maps, depth heat-maps, xyz of the
+    41 key-points back-projected from the heat-map camera) (mesh/render.py:274-279)."""
+
+    def __init__(self, bones, heatmap_size):
+        super().__init__()
+        from .pointTransformation import InverseOthographicalProjection, OthographicalProjection
+        self.width = self.height = heatmap_size
+        self.hm_renderer = HeatmapRender(heatmap_size)
+        half, f = heatmap_size / 2, heatmap_size / 300
+        self.camera = OthographicalProjection(half, half, f, f)
+        self.inv_camera = InverseOthographicalProjection(half, half, f, f)
+        self.lbs = keypoint_skinning(bones)
+        self.num_vertices = self.lbs.num_vertices
+
+    def forward(self, transformation_mats, rand_f=None):
+        uvd_points = self.camera(self.lbs(transformation_mats), rand_f)
+        hms, dms = self.hm_renderer(uvd_points)
+        return hms, dms, self.inv_camera(uvd_points)
+
+
+def _collision_pairs():
+    """Every finger sphere against the 11 palm spheres, and against every sphere of
+    another finger (mesh/render.py:150-162): 330 + 360 pairs."""
+    a, b = [], []
+    for p in range(11):
+        for q in range(11, 41):
+            a.append(p); b.append(q)
+    for p in range(11, 41):
+        for q in range(p + 1, 41):
+            if (p - 11) // 6 != (q - 11) // 6:
+                a.append(p); b.append(q)
+    return a, b
+
+
+class CollisionLoss(nn.Module):
+    """sum of relu(min_dist^2 - |c_a - c_b|^2) over the pair table (mesh/render.py:168-176)."""
+
+    def __init__(self, min_dist=6):
+        super().__init__()
+        self.min_sq_dist = min_dist ** 2
+        a, b = _collision_pairs()
+        self.register_buffer('joint_1', torch.tensor(a).long())
+        self.register_buffer('joint_2', torch.tensor(b).long())
+
+    def forward(self, joints):
+        joints = joints.reshape(joints.shape[0], -1, 3)
+        sq = ((joints[:, self.joint_1] - joints[:, self.joint_2]) ** 2).sum(-1)
+        return torch.relu(self.min_sq_dist - sq).sum()
+
+
+# The 35 sphere pairs whose distance is held to [0.80, 1.05] x its rest length
+# (data of mesh/bone_length.py:36-55: 20 palm pairs + 3 per finger).
+BONE_PAIRS_1 = [3, 2, 3, 8, 2, 2, 9, 8, 4, 8, 7, 4, 6, 7, 0, 5, 7, 7, 6, 6] + \
+    [11 + 6 * f + 2 * k for f in range(5) for k in range(3)]
+BONE_PAIRS_2 = [2, 9, 8, 2, 4, 10, 10, 4, 10, 7, 4, 6, 10, 6, 5, 1, 0, 5, 5, 1] + \
+    [12 + 6 * f + 2 * k for f in range(5) for k in range(3)]
+BONE_REST_LENGTH = [
+    25.212656021118164, 18.249488830566406, 27.5742244720459, 38.532264709472656, 25.10819435119629,
+    31.173757553100586, 18.329626083374023, 19.15080451965332, 16.209327697753906, 21.52261734008789,
+    32.740535736083984, 30.58920669555664, 33.205970764160156, 11.672294616699219, 17.084707260131836,
+    17.084720611572266, 16.697546005249023, 23.92103385925293, 20.87999725341797, 22.58038330078125,
+    27.55999755859375, 15.471183776855469, 13.214692115783691, 21.748210906982422, 13.021653175354004,
+    16.643720626831055, 18.83765983581543, 12.724685668945312, 16.238431930541992, 18.04928970336914,
+    11.045844078063965, 11.320968627929688, 30.078536987304688, 16.255985260009766, 19.434825897216797]
+
+
+class BoneLengthLoss(nn.Module):
+    """mean relu(min^2 - d^2) + mean relu(d^2 - max^2) over the 35 pairs (mesh/render.py:196-206)."""
+
+    def __init__(self):
+        super().__init__()
+        rest = torch.tensor(BONE_REST_LENGTH).float()
+        self.register_buffer('joint_1', torch.tensor(BONE_PAIRS_1).long())
+        self.register_buffer('joint_2', torch.tensor(BONE_PAIRS_2).long())
+        self.register_buffer('max_length', ((rest * 1.05) ** 2).unsqueeze(0))
+        self.register_buffer('min_length', ((rest * 0.80) ** 2).unsqueeze(0))
+
+    def forward(self, joints):
+        joints = joints.reshape(joints.shape[0], -1, 3)
+        sq = ((joints[:, self.joint_1] - joints[:, self.joint_2]) ** 2).sum(-1)
+        return torch.relu(self.min_length - sq).mean() + torch.relu(sq - self.max_length).mean()

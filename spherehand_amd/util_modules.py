@@ -1,0 +1,187 @@
+"""Network-side helpers around the render path -- same classes and forward
+signatures as the reference's network/util_modules.py.
+
+    HandSynthesizer                     network/util_modules.py:86-122
+    RecoverXYZCoordinateFromHeatmap     :164-201   (soft-argmax heat-map -> xyz)
+    HeatmapVariance                     :204-240
+    DepthNoise / DepthResample          :46-84 / :10-43
+    ResizeCropImage                     :383-424
+    TemporalSmoothnessLoss              :367-381
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .kinematicsTransformation import HandTransformationMat
+from .pointTransformation import RandScale
+from .render import DepthRender, Hand3DHeatmapRender
+
+
+def _spatial_softmax(hms, sigma):
+    n, j, h, w = hms.shape
+    return F.softmax((hms * sigma).reshape(n * j, h * w), dim=1).reshape(n, j, h, w)
+
+
+def _spatial_normalize(hms):
+    """relu(h) / (sum relu(h) + 1e-5) per map (network/util_modules.py:144-161)."""
+    h = torch.relu(hms)
+    return h / (h.sum(dim=(-2, -1), keepdim=True) + 1e-5)
+
+
+class RecoverXYZCoordinateFromHeatmap(nn.Module):
+    """Soft-argmax: uv = sum softmax(20*uv_hm) * grid; depth = sum d_hm * relu-normalised
+    uv_hm; then through the inverse orthographic camera of the heat-map
+    (x = (u - W/2) / (W/300), z = d / depth_scale)."""
+
+    def __init__(self, width, height, depth_scale):
+        super().__init__()
+        self.depth_scale = 1.0 / depth_scale
+        self.fx, self.fy = width / 300.0, height / 300.0
+        self.cx, self.cy = width / 2, height / 2
+        self.register_buffer('u_grid', torch.arange(width, dtype=torch.float32).view(1, 1, 1, width))
+        self.register_buffer('v_grid', torch.arange(height, dtype=torch.float32).view(1, 1, height, 1))
+
+    def forward(self, uv_hms, d_hms, is_shuffing=False):
+        p = _spatial_softmax(uv_hms, 20.0)
+        u = (p * self.u_grid).sum(dim=(-2, -1))
+        v = (p * self.v_grid).sum(dim=(-2, -1))
+        d = (d_hms * _spatial_normalize(uv_hms)).sum(dim=(-2, -1))
+        return torch.stack([(u - self.cx) / self.fx, (v - self.cy) / self.fy, d * self.depth_scale], dim=-1)
+
+
+class HeatmapVariance(nn.Module):
+    """Spread of a heat-map about its soft-argmax (sigma 25), in normalised image units."""
+
+    def __init__(self, width, height):
+        super().__init__()
+        u = (torch.arange(width, dtype=torch.float64) - width / 2) / width
+        v = (torch.arange(height, dtype=torch.float64) - height / 2) / height
+        self.register_buffer('u_grid', u.float().view(1, 1, 1, width))
+        self.register_buffer('v_grid', v.float().view(1, 1, height, 1))
+
+    def forward(self, hms):
+        p = _spatial_softmax(hms, 25.0)
+        w = _spatial_normalize(hms)
+        out = 0
+        for grid in (self.u_grid, self.v_grid):
+            mean = (p * grid).sum(dim=(-2, -1), keepdim=True)
+            out = out + (w * (grid - mean) ** 2).sum(dim=(-2, -1))
+        return out
+
+
+class DepthResample(nn.Module):
+    """Random drop-out to 1.0 (probability 1 - sample_ratio) followed by a fixed 3x3 /
+    5x5 Gaussian blur.  RNG: torch.rand_like on the input's device."""
+    _K3 = [1, 2, 1, 2, 6, 2, 1, 2, 1]
+    _K5 = [1, 4, 7, 4, 1, 4, 16, 26, 16, 4, 7, 26, 41, 26, 7, 4, 16, 26, 16, 4, 1, 4, 7, 4, 1]
+
+    def __init__(self, sample_ratio, kernel_size=3):
+        super().__init__()
+        self.sample_ratio = sample_ratio
+        k = torch.tensor(self._K5 if kernel_size == 5 else self._K3).float()
+        self.gaussian_filter = nn.Conv2d(1, 1, kernel_size, padding=kernel_size // 2, bias=False)
+        self.gaussian_filter.weight.data = (k / k.sum()).view(1, 1, kernel_size, kernel_size)
+        self.gaussian_filter.weight.requires_grad = False
+
+    def forward(self, dm):
+        if dm.ndimension() == 3:
+            dm = dm.unsqueeze(1)
+        dm = torch.where(torch.rand_like(dm) > self.sample_ratio, torch.ones_like(dm), dm)
+        return self.gaussian_filter(dm)
+
+
+class DepthNoise(nn.Module):
+    """Per-pixel random source shift (sigma 0.5 px, rounded) and Gaussian z noise
+    (sigma 0.05) on foreground pixels (< 1.0 in scaled depth)."""
+
+    def __init__(self, width, height):
+        super().__init__()
+        self.sigma_x = self.sigma_y = 0.5
+        self.sigma_z = 0.05
+        self.register_buffer('u_grid', torch.arange(width).view(1, 1, width))
+        self.register_buffer('v_grid', torch.arange(height).view(1, height, 1))
+
+    def forward(self, dm):
+        n, h, w = dm.shape
+        sx = torch.clamp((torch.randn_like(dm) * self.sigma_x + 0.5).long() + self.u_grid, 0, w - 1)
+        sy = torch.clamp((torch.randn_like(dm) * self.sigma_y + 0.5).long() + self.v_grid, 0, h - 1)
+        noisy = torch.gather(dm.reshape(n, h * w), 1, (sy * w + sx).reshape(n, h * w)).view(n, h, w)
+        return torch.where(noisy < 1.0, noisy + torch.randn_like(noisy) * self.sigma_z, noisy)
+
+
+class ResizeCropImage(nn.Module):
+    """Per-image anisotropic down-scale (nearest) pasted centred on a canvas of ones;
+    like the reference, only scales <= 1 in v are pasted (its paste sits under the
+    v-branch's else, network/util_modules.py:411-423)."""
+
+    def forward(self, depth_maps, u_scales, v_scales):
+        h, w = depth_maps.shape[-2], depth_maps.shape[-1]
+        out = torch.ones_like(depth_maps)
+        for idx, (us, vs) in enumerate(zip(u_scales.tolist(), v_scales.tolist())):
+            if vs > 1:
+                continue
+            new_h, new_w = int(h * vs + 0.5), int(w * us + 0.5)
+            resized = F.interpolate(depth_maps[idx].view(1, 1, h, w), (new_h, new_w))[0, 0]
+            if us > 1:
+                ou0 = (new_w - w) // 2
+                u0, u1, ou1 = 0, w, ou0 + w
+            else:
+                ou0, ou1 = 0, int(w * us)
+                u0 = (w - new_w) // 2
+                u1 = u0 + ou1
+            ov1 = int(h * vs)
+            v0 = (h - new_h) // 2
+            out[idx, v0:v0 + ov1, u0:u1] = resized[0:ov1, ou0:ou1]
+        return out
+
+
+class TemporalSmoothnessLoss(nn.Module):
+    """Clamped (+-2500) L2 between consecutive samples' joints; remembers the last
+    sample of the previous batch (stateful, like the reference)."""
+
+    def __init__(self):
+        super().__init__()
+        self.previous_skel = None
+        self.thresh = 2500.0
+
+    def forward(self, joints):
+        assert joints.ndimension() == 4
+        if self.previous_skel is None:
+            prev, curr = joints[:-1].detach(), joints[1:]
+        else:
+            prev = torch.cat([self.previous_skel.unsqueeze(0), joints[:-1].detach()], dim=0)
+            curr = joints
+        self.previous_skel = joints[-1].detach().clone()
+        return (torch.clamp(prev - curr, -self.thresh, self.thresh) ** 2).mean()
+
+
+class HandSynthesizer(nn.Module):
+    """pose [B,26] -> (noisy scaled depth crop [B,S,S], uv heat-maps, depth heat-maps,
+    key-point xyz), all detached: the synthetic training branch (square images).
+    FK, skinning+camera and the triangle rasterizer are HIP kernels."""
+
+    def __init__(self, mesh, image_size, heatmap_size, uv_hm_scale, depth_scale, add_noise=True, out_heatmap=True):
+        super().__init__()
+        self.uv_hm_scale = uv_hm_scale
+        self.depth_scale = depth_scale
+        self.hand_skeleton_transform = HandTransformationMat(
+            [bone['offset_matrix'].astype(np.float32) for bone in mesh['bones']])
+        self.hm_render = Hand3DHeatmapRender(mesh['bones'], heatmap_size)
+        self.dm_render = DepthRender(mesh, image_size)
+        self.rand_scale = RandScale(0.1)
+        self.depth_noiser = DepthNoise(image_size, image_size)
+        self.add_noise = add_noise
+        self.out_heatmap = out_heatmap
+
+    @torch.no_grad()
+    def forward(self, parameters):
+        transform_mats = self.rand_scale(self.hand_skeleton_transform(parameters))
+        rand_f_ratio = (torch.rand(transform_mats.shape[0]) * 0.2 + 0.9).to(transform_mats.device)
+        depth = self.dm_render(transform_mats, rand_f_ratio) * self.depth_scale
+        if self.add_noise:
+            depth = self.depth_noiser(depth)
+        if not self.out_heatmap:
+            return depth
+        uv_hms, depth_hms, xyz_pts = self.hm_render(transform_mats, rand_f_ratio)
+        return depth, uv_hms * self.uv_hm_scale, depth_hms * self.depth_scale, xyz_pts

@@ -1,0 +1,119 @@
+"""GPU: the loss assembly with the HIP-backed terms vs the reference's G7 vector, the
+synthetic branch, and the engine's train/eval steps on sphere-rendered multiview data."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def opts(model_dir, **kw):
+    o = dict(synthesize=True, mv_projection=True, mv_consistency=True, temporal=False, prior=False, collision=True,
+             bone_length=True, mode='Train', model_dir=str(model_dir), initial_model=None, restore_from_model=None,
+             restore_from_epoch=-1, num_stacks=1, epoch=2, dataset_dir=None, depth_resample=0, lr=1e-3, tag='t',
+             image_size=64, log_every=1000, real_batch=4, synt_batch=6, steps_per_epoch=3)
+    o.update(kw)
+    return SimpleNamespace(**o)
+
+
+@pytest.mark.parametrize("is_mv", [True, False])
+def test_multitask_loss_terms_vs_reference(is_mv):
+    from spherehand_amd import hand_model
+    from spherehand_amd.criterion import MultiTaskLoss
+    g, g4 = golden("g7_network.npz"), golden("g4_mutual_projection.npz")
+    crit = MultiTaskLoss(True, True, True, False, False, True, True, hand_model.load_mesh(), image_size=64).cuda()
+    result = {k: [dev(g["mt_res_" + k])] for k in
+              ("real_xyz", "real_uv_hms", "synt_uv_hms", "synt_xyz", "batch_synt_fea", "batch_real_fea")}
+    synt_target = {k: dev(g["mt_synt_" + k]) for k in ("uv_hms", "d_hms", "xyz_pts")}
+    real_target = {"real_dms": dev(g4["real_dms"]), "camera_poses": dev(g4["cam"]),
+                   "inv_camera_poses": dev(g4["inv_cam"]), "is_mv": is_mv}
+    terms, proj = crit(result, synt_target=synt_target, real_target=real_target)
+    tag = "mv" if is_mv else "diag"
+    for k, v in terms.items():
+        ref = float(g["mt_%s_%s" % (tag, k)])
+        assert abs(float(v) - ref) <= 1e-4 * max(1.0, abs(ref)), (k, float(v), ref)
+    assert set(terms) == {"synt_uv", "synt_d", "mv_projection", "mv_consistency", "uv_hm_mean", "collision",
+                          "bone_length", "domain_loss"}
+    assert len(proj) == 1 and proj[0].shape == (4, 3, 3, 64, 64)
+
+
+def test_hand_synthesizer():
+    from spherehand_amd import hand_model
+    from spherehand_amd.joint_angle import sample_poses
+    from spherehand_amd.util_modules import HandSynthesizer
+    syn = HandSynthesizer(hand_model.load_mesh(), 64, 16, 1.0, 0.01).cuda()
+    torch.manual_seed(0)
+    dms, uv, d, xyz = syn(sample_poses(8, seed=3).cuda())
+    assert dms.shape == (8, 64, 64) and uv.shape == (8, 41, 16, 16) and d.shape == uv.shape and xyz.shape == (8, 41, 4)
+    assert not dms.requires_grad and torch.isfinite(dms).all()
+    fg = (dms < 0.99).float().mean().item()
+    assert 0.03 < fg < 0.5                        # a hand covers part of the crop; background = 1.0 (scaled 100)
+    assert uv.max().item() <= 1.0 + 1e-6 and uv.max().item() > 0.5
+    clean = HandSynthesizer(hand_model.load_mesh(), 64, 16, 1.0, 0.01, add_noise=False, out_heatmap=False).cuda()
+    assert clean(sample_poses(2, seed=4).cuda()).shape == (2, 64, 64)
+
+
+def test_engine_train_eval_checkpoint(tmp_path):
+    from spherehand_amd import hand_model
+    from spherehand_amd.datasets import SyntheticMultiviewDataset
+    from spherehand_amd.engine import Engine
+    mesh = hand_model.load_mesh()
+    train = SyntheticMultiviewDataset(mesh, 16, 64, seed=0)
+    evald = SyntheticMultiviewDataset(mesh, 8, 64, seed=1)
+    d, gt, cam, inv = train[0]
+    assert d.shape == (3, 64, 64) and gt.shape == (3, 36, 3) and cam.shape == (3, 4, 4)
+    assert 0.03 < (d < 100).float().mean().item() < 0.5
+    torch.manual_seed(0)
+    eng = Engine(opts(tmp_path), mesh=mesh, real_train_dataset=train, real_eval_dataset=evald)
+    assert eng.with_real and eng.with_synt
+    summary = eng.train()                          # 2 epochs x 3 steps of _epoch_with_both
+    assert np.isfinite(list(summary["loss"].values())).all()
+    assert {"mv_projection", "synt_uv", "collision", "bone_length"} <= set(summary["loss"])
+    files = os.listdir(eng.model_path)
+    assert {"model_-1.pth", "model_0.pth", "model_1.pth", "loss_weights.txt", "log.txt"} <= set(files)
+    ev = eng.eval()
+    assert np.isfinite(ev["metric"]["avg_joint_error"])
+    # restore: weights + optimizer + scheduler position
+    eng2 = Engine(opts(tmp_path, restore_from_model=eng.model_name, restore_from_epoch=1), mesh=mesh,
+                  real_train_dataset=train, real_eval_dataset=evald)
+    assert eng2.starting_epoch == 1
+    for a, b in zip(eng.network.parameters(), eng2.network.parameters()):
+        assert torch.equal(a, b)
+    # weights-only load of a checkpoint path (--initial_model)
+    eng3 = Engine(opts(tmp_path, initial_model=os.path.join(eng.model_path, "model_1.pth"), mode="Test"), mesh=mesh,
+                  real_train_dataset=train, real_eval_dataset=evald)
+    assert eng3.starting_epoch == 0
+    assert torch.equal(next(eng3.network.parameters()), next(eng.network.parameters()))
+
+
+def test_render_loss_fits_a_pose(tmp_path):
+    """Training by fitting: descending the multiview render loss w.r.t. the joints
+    pulls a perturbed skeleton back onto the observed depth maps."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.datasets import SyntheticMultiviewDataset
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    mesh = hand_model.load_mesh()
+    ds = SyntheticMultiviewDataset(mesh, 4, 64, seed=2)
+    crit = MutualProjectionLoss(64, mesh).cuda()
+    real, cam, inv = ds.dms.cuda(), ds.cam.cuda(), ds.inv_cam.cuda()
+    truth = ds.joints.cuda()
+    joints = (truth + 4.0 * torch.randn_like(truth)).requires_grad_(True)
+    opt = torch.optim.Adam([joints], lr=0.5)
+    first = None
+    for it in range(60):
+        opt.zero_grad()
+        loss, _ = crit(cam, inv, joints, real, True)
+        loss.backward()
+        opt.step()
+        first = loss.item() if first is None else first
+    assert loss.item() < 0.5 * first
+    assert (joints - truth).norm(dim=-1).mean().item() < 4.0 * 1.7 * 0.8     # closer than the start (E|N(0,4^2 I)| ~ 6.4)

@@ -1,0 +1,133 @@
+"""CPU: network-side modules and the loss assembly vs the reference's golden vectors
+(tests/golden/g7_network.npz, made by make_goldens_network.py).  Pure-torch modules
+run on CPU here; the terms that need the HIP kernels are covered in test_engine_gpu."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden
+
+torch = pytest.importorskip("torch")
+sys.path.insert(0, GOLDEN)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_hourglass_matches_reference():
+    from make_goldens_network import det_fill
+    from spherehand_amd.hourglass import create_hourglass_network
+    g = golden("g7_network.npz")
+    net = create_hourglass_network(82, 1).eval()
+    assert sum(p.numel() for p in net.parameters()) == 2308946
+    assert ["%s:%s" % (k, tuple(v.shape)) for k, v in net.state_dict().items()] == list(g["hg_keys"])
+    det_fill(net)
+    x = torch.sin(torch.arange(2 * 64 * 64, dtype=torch.float32) * 0.01).view(2, 64, 64)
+    with torch.no_grad():
+        y, lat = net(x)
+    assert np.abs(y[0].numpy() - g["hg_out"]).max() <= 1e-4 * np.abs(g["hg_out"]).max()
+    assert np.abs(lat[0].numpy() - g["hg_latent"]).max() <= 1e-4 * np.abs(g["hg_latent"]).max()
+    out2, _ = create_hourglass_network(82, 2)(x)
+    assert len(out2) == 2 and out2[1].shape == (2, 82, 16, 16)
+
+
+def test_soft_argmax_and_variance():
+    from spherehand_amd.util_modules import HeatmapVariance, RecoverXYZCoordinateFromHeatmap
+    g = golden("g7_network.npz")
+    xyz = RecoverXYZCoordinateFromHeatmap(16, 16, 0.01)(t(g["uv_hms"]), t(g["d_hms"]))
+    assert np.abs(xyz.numpy() - g["xyz"]).max() <= 1e-4 * np.abs(g["xyz"]).max()
+    var = HeatmapVariance(16, 16)(t(g["uv_hms"]))
+    assert np.abs(var.numpy() - g["hm_var"]).max() <= 1e-5
+
+
+def test_heatmap_render():
+    from spherehand_amd import hand_model
+    from spherehand_amd.render import Hand3DHeatmapRender, HeatmapRender
+    g = golden("g7_network.npz")
+    hr = Hand3DHeatmapRender(hand_model.load_mesh()["bones"], 16)
+    hms, dms, xyz = hr(t(g["hm_T"]), t(g["hm_rand_f"]))
+    assert np.abs(hms.numpy() - g["hm_uv"]).max() <= 1e-5
+    assert np.abs(xyz.numpy() - g["hm_xyz"]).max() <= 1e-3
+    # the 0.05 mask is a threshold: allow the few cells within rounding of it to differ
+    mism = (dms.numpy() != 0) != (g["hm_d"] != 0)
+    assert mism.mean() < 1e-4
+    assert np.abs(dms.numpy() - g["hm_d"])[~mism].max() <= 1e-3
+    hms2, _, xyz2 = hr(t(g["hm_T"]))
+    assert np.abs(hms2.numpy() - g["hm_uv_nof"]).max() <= 1e-5 and np.abs(xyz2.numpy() - g["hm_xyz_nof"]).max() <= 1e-3
+    assert HeatmapRender(16)(torch.zeros(1, 2, 3))[0].shape == (1, 2, 16, 16)
+
+
+def test_collision_and_bone_length():
+    from spherehand_amd.render import BoneLengthLoss, CollisionLoss
+    g = golden("g7_network.npz")
+    col, bl = CollisionLoss(), BoneLengthLoss()
+    assert np.array_equal(np.stack([col.joint_1.numpy(), col.joint_2.numpy()]), g["collision_pairs"])
+    assert col.joint_1.numel() == 690                                                 # 330 + 360
+    assert np.array_equal(np.stack([bl.joint_1.numpy(), bl.joint_2.numpy()]), g["bone_pairs"])
+    assert np.allclose(np.stack([bl.min_length.numpy()[0], bl.max_length.numpy()[0]]), g["bone_min_max"], rtol=1e-6)
+    for crit, key in ((col, "collision"), (bl, "bone_length")):
+        j = t(g["geo_joints"]).requires_grad_(True)
+        v = crit(j)
+        v.backward()
+        assert abs(v.item() - float(g[key])) <= 1e-5 * max(1.0, abs(float(g[key])))
+        assert np.abs(j.grad.numpy() - g[key + "_grad"]).max() <= 1e-5 * max(1e-6, np.abs(g[key + "_grad"]).max())
+    assert float(g["bone_length"]) > 0
+
+
+def test_average_joint_error():
+    from spherehand_amd.criterion import average_joint_error
+    g = golden("g7_network.npz")
+    v = average_joint_error(t(g["metric_gt"]), t(g["metric_est"]))
+    assert abs(v.item() - float(g["metric"])) <= 1e-5 * float(g["metric"])
+
+
+def test_multitask_loss_wiring_cpu_terms():
+    """The terms that do not need the GPU kernels: weights, sums over stacks, the
+    synthetic branch, heat-map mean, collision, bone length, domain (weight 0)."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.criterion import MultiTaskLoss
+    g = golden("g7_network.npz")
+    crit = MultiTaskLoss(True, False, False, False, False, True, True, hand_model.load_mesh(), image_size=64)
+    assert sorted("%s=%r" % kv for kv in crit.weights.items()) == list(g["mt_weights"])
+    result = {k: [t(g["mt_res_" + k])] for k in
+              ("real_xyz", "real_uv_hms", "synt_uv_hms", "synt_xyz", "batch_synt_fea", "batch_real_fea")}
+    synt_target = {k: t(g["mt_synt_" + k]) for k in ("uv_hms", "d_hms", "xyz_pts")}
+    real_target = {"real_dms": None, "camera_poses": None, "inv_camera_poses": None, "is_mv": True}
+    terms, proj = crit(result, synt_target=synt_target, real_target=real_target)
+    assert proj == []
+    for k in ("synt_uv", "synt_d", "uv_hm_mean", "collision", "bone_length", "domain_loss"):
+        ref = float(g["mt_mv_" + k])
+        assert abs(float(terms[k]) - ref) <= 1e-5 * max(1.0, abs(ref)), k
+    assert "mv_projection" not in terms and "mv_consistency" not in terms
+
+
+def test_network_wrapper_shapes_and_scale_division():
+    from spherehand_amd.criterion import HeatmapEstimationNetwork
+    net = HeatmapEstimationNetwork(16, 0.01, 41, 1).eval()
+    with torch.no_grad():
+        r = net(real_dms=torch.rand(2, 3, 64, 64), synt_dms=torch.rand(4, 64, 64))
+        r_real = net(real_dms=torch.rand(2, 3, 64, 64))
+        r_synt = net(synt_dms=torch.rand(4, 64, 64))
+    assert r["real_xyz"][0].shape == (2, 3, 41, 3) and r["synt_xyz"][0].shape == (4, 41, 3)
+    assert r["real_uv_hms"][0].shape == (2, 3, 41, 16, 16) and r["batch_real_fea"][0].shape == (6, 256, 4, 4)
+    assert set(r_real) == {"real_uv_hms", "real_d_hms", "real_xyz"}
+    assert set(r_synt) == {"synt_uv_hms", "synt_d_hms", "synt_xyz"}
+
+
+def test_nyu_shard_roundtrip(tmp_path):
+    from spherehand_amd.datasets import create_nyu_dataset, write_nyu_shard
+    rs = np.random.RandomState(0)
+    for k, n in enumerate((5, 3)):
+        cams = np.tile(np.eye(4, dtype=np.float32), (n, 3, 1, 1))
+        cams[:, :, :3, 3] = rs.randn(n, 3, 3)
+        write_nyu_shard(str(tmp_path / ("mv_data_%d" % k)), rs.rand(n, 3, 64, 64), rs.randn(n, 3, 36, 3), cams)
+    ds = create_nyu_dataset(str(tmp_path))
+    assert len(ds) == 8
+    dms, joints, cam, inv = ds[6]
+    assert dms.shape == (3, 64, 64) and joints.shape == (3, 36, 3) and cam.shape == (3, 4, 4)
+    assert np.allclose(cam @ inv, np.eye(4), atol=1e-5)
+    with pytest.raises(FileNotFoundError):
+        create_nyu_dataset(str(tmp_path / "missing"))
