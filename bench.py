@@ -74,6 +74,23 @@ def cpu_baseline(spheres_host, grad_host, budget_s=10.0):
                       % (passes, el)}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary
+    (profiles/rNN_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    this same command, corrected as MI355X_MICROARCH.md prescribes).  PMC counters
+    cannot be read from inside the process, so this is the profiled value, not a
+    live one; None if no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return int(d[kernel]["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except (KeyError, ValueError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +192,7 @@ def main():
         dom, dom_us, dom_bytes = ("sphere_zbuf_bwd_kernel", bwd_us, bytes_bwd) if bwd_us >= fwd_us else \
             ("sphere_zbuf_fwd_kernel", fwd_us, bytes_fwd)
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
+        traffic, traffic_src = pmc_traffic(dom)
         out = {
             "metric": "depth crops/s (raster fwd+bwd, 128x128, batch 256)",
             "value": round(world * BATCH * args.steps / elapsed, 1),
@@ -193,7 +211,8 @@ def main():
                        "crops_per_gpu": BATCH, "image": [S, S], "spheres_per_crop": J,
                        "launch": args.launch, "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes,
                          "launch_us": {"fwd": round(fwd_us, 3), "bwd": round(bwd_us, 3)}},
         }
