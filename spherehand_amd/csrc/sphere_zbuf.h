@@ -46,10 +46,12 @@ constexpr int kPatchW = 16;   // lanes along x
 constexpr int kPatchH = 4;    // lanes along y
 constexpr int kRowPad = 16;   // LDS row padding (elements): patches may overhang the image edge
 constexpr int kPadRows = kPatchH - 1;  // ... and the region's last row
-// LDS header: spheres [64] float4 | work items [64] int4 | flags
+// LDS header: spheres [64] float4 | work items [64] int4 | ends [64] int | flags
 constexpr int kOffItems = 1024;
-constexpr int kOffFlags = 2048;
-constexpr int kHdrBytes = 2048 + 16;
+constexpr int kOffEnds = 2048;
+constexpr int kOffFlags = 2304;
+constexpr int kHdrBytes = 2304 + 16;
+constexpr int kMaxFastWidth = 8192;  // 16-bit fields of the work items
 
 __device__ __forceinline__ uint32_t depth_key(float d) {
   const uint32_t b = __float_as_uint(d);
@@ -80,24 +82,30 @@ __device__ __forceinline__ bool sphere_is_tame(const float4 s) {
 }
 
 // One work item = one sphere's pixel box clipped to the region, as a grid of
-// 16x4-pixel patches.  Conservative box: a hit needs |fl(xg - x)| <= |r|;
-// xg(u) = (u - half)*300/size  =>  u = xg*size/300 + half, evaluated in fp32
-// (error << 1 px for tame spheres) and widened by one pixel each side.
+// 16x4-pixel patches.  A hit needs |fl(xg - x)| <= |r| (sphere_tile.h), i.e. the
+// pixel centre inside [x - |r|, x + |r|] up to one rounding.  With
+// xg(u) = (u - half)*300/size  <=>  u = xg*size/300 + half the box is
+//   u in [ceil(ulo - eps), floor(uhi + eps)],
+// eps = 1e-3 px + 2e-6 relative: >> the fp32 error of the inverse map (<= 1e-5 px
+// near the image, 6e-8 relative far away), << a pixel, so the box is the tight
+// conservative one.  Non-tame spheres (NaN/Inf/huge) take the whole region.
 struct Item { int u0, v0, npx, npy; };
+
+__device__ __forceinline__ void axis_box(float c, float ar, float k, float half, float hi_clamp, int lo_lim,
+                                         int hi_lim, int &i0, int &i1) {
+  const float lo = (c - ar) * k + half, hi = (c + ar) * k + half;
+  const float eps = 1e-3f + 2e-6f * (fabsf(lo) + fabsf(hi));
+  i0 = max((int)ceilf(fminf(fmaxf(lo - eps, -2.f), hi_clamp)), lo_lim);
+  i1 = min((int)floorf(fminf(fmaxf(hi + eps, -2.f), hi_clamp)), hi_lim);
+}
 
 __device__ __forceinline__ Item sphere_item(const float4 s, const Axis &ax, const Axis &ay, int W, int r0,
                                             int r1) {
   int u0 = 0, u1 = W - 1, v0 = r0, v1 = r1 - 1;
   if (sphere_is_tame(s)) {
     const float ar = fabsf(s.w);
-    const float kx = ax.size / 300.0f, ky = ay.size / 300.0f;
-    const float ulo = (s.x - ar) * kx + ax.half, uhi = (s.x + ar) * kx + ax.half;
-    const float vlo = (s.y - ar) * ky + ay.half, vhi = (s.y + ar) * ky + ay.half;
-    const float wf = (float)W + 2.f, hf = (float)r1 + 2.f;
-    u0 = max((int)floorf(fminf(fmaxf(ulo, -2.f), wf)) - 1, 0);
-    u1 = min((int)ceilf(fminf(fmaxf(uhi, -2.f), wf)) + 1, W - 1);
-    v0 = max((int)floorf(fminf(fmaxf(vlo, -2.f), hf)) - 1, r0);
-    v1 = min((int)ceilf(fminf(fmaxf(vhi, -2.f), hf)) + 1, r1 - 1);
+    axis_box(s.x, ar, ax.size / 300.0f, ax.half, (float)W + 2.f, 0, W - 1, u0, u1);
+    axis_box(s.y, ar, ay.size / 300.0f, ay.half, (float)r1 + 2.f, r0, r1 - 1, v0, v1);
   }
   Item it;
   it.u0 = u0;
@@ -107,61 +115,125 @@ __device__ __forceinline__ Item sphere_item(const float4 s, const Axis &ax, cons
   return it;
 }
 
-// Wave 0: build the work list in LDS.  s_items[j] = (u0, v0, npx | npy<<16, first
-// patch index); returns the total patch count (valid in every lane of wave 0).
-__device__ __forceinline__ int build_work_list(const float4 s, bool valid, const Axis &ax, const Axis &ay,
-                                               int W, int r0, int r1, int4 *s_items, int lane) {
-  Item it = sphere_item(s, ax, ay, W, r0, r1);
-  const int cnt = valid ? it.npx * it.npy : 0;
-  int incl = cnt;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(incl, d);
-    if (lane >= d) incl += t;
-  }
-  s_items[lane] = make_int4(it.u0, it.v0, it.npx | (it.npy << 16), incl - cnt);
-  return __shfl(incl, 63);
-}
-
-// Iterate this wave's slice [i0, i1) of the patch list.  f(j, s, pu, pv, first,
-// last) is called per patch with the sphere index, its parameters and the
-// patch's top-left pixel; `first`/`last` mark the ends of a run on one sphere.
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float rfl(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-template <typename F>
-__device__ __forceinline__ void for_each_patch(const float4 *s_sph, const int4 *s_items, int J, int total,
-                                               int wave, int nwaves, int lane, F &&f) {
-  // everything that steers the loops is wave-uniform: keep it in SGPRs
-  wave = rfl(wave);
-  total = rfl(total);
-  const int i0 = (wave * total) / nwaves, i1 = ((wave + 1) * total) / nwaves;
-  if (i0 >= i1) return;
-  // first sphere whose patch range ends beyond i0 (ends are non-decreasing)
-  const int4 mine = s_items[lane];
-  const int my_end = mine.w + (mine.z & 0xffff) * (mine.z >> 16);
-  int j = __popcll(__ballot(lane < J && my_end <= i0));
-  int i = i0;
-  while (i < i1) {
-    const int4 itv = s_items[j];
-    const int u0 = rfl(itv.x), v0 = rfl(itv.y), zz = rfl(itv.z), start = rfl(itv.w);
-    const int npx = zz & 0xffff, cnt = npx * (zz >> 16);
-    const int p = i - start;
-    const int n = min(cnt - p, i1 - i);
-    if (n > 0) {
-      const float4 sv = s_sph[j];
-      const float4 s = make_float4(rfl(sv.x), rfl(sv.y), rfl(sv.z), rfl(sv.w));
-      int py = p / npx, px = p - py * npx;
-      for (int k = 0; k < n; k++) {
-        f(j, s, u0 + px * kPatchW, v0 + py * kPatchH, k == 0, k == n - 1);
-        if (++px == npx) { px = 0; ++py; }
+// The work list is a sequence of PATCH ROWS (npx patches side by side), sphere after
+// sphere, each row weighted by its estimated cost (row overhead + per-patch work) so
+// that equal slices of the cumulative weight are equal work.
+// Measured on MI355X (in-kernel clock64, one crop per CU): starting a sphere ~1300
+// cycles (broadcasts, column terms), a patch row ~350, each patch ~150.
+constexpr int kSphereCost = 26;
+constexpr int kRowCost = 7;
+constexpr int kPatchCost = 3;
+
+// Wave 0: build the list in LDS.  s_items[j] = (u0 | v0<<16, npx | nrows<<16, row
+// weight, weight prefix before sphere j); s_ends[j] = prefix after it; a sphere weighs
+// kSphereCost + nrows * row weight.  Returns the total weight (valid in every lane of
+// wave 0).
+__device__ __forceinline__ int build_work_list(const float4 s, bool valid, const Axis &ax, const Axis &ay,
+                                               int W, int r0, int r1, int4 *s_items, int *s_ends, int lane,
+                                               bool *too_big) {
+  const Item it = sphere_item(s, ax, ay, W, r0, r1);
+  const int nrows = (valid && it.npx > 0) ? it.npy : 0;
+  const int wt = kRowCost + kPatchCost * it.npx;
+  const int cost = nrows > 0 ? kSphereCost + nrows * wt : 0;
+  // inclusive scan over the 64 lanes: 4 DPP steps inside each row of 16, then the
+  // three row totals are added with SGPR broadcasts
+  int incl = cost;
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);  // row_shr:1
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);  // row_shr:2
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);  // row_shr:4
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);  // row_shr:8
+  const int r0s = rl(incl, 15), r1s = rl(incl, 31), r2s = rl(incl, 47);
+  const int row = lane >> 4;
+  incl += (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
+  s_items[lane] = make_int4(it.u0 | (it.v0 << 16), it.npx | (nrows << 16), wt, incl - cost);
+  s_ends[lane] = incl;
+  // fields are 16-bit; the launcher keeps W <= kMaxFastWidth, H <= 32768
+  *too_big = __ballot(valid && (it.u0 > 65535 || it.v0 > 65535 || it.npx > 65535 || nrows > 32767)) != 0ull;
+  return rl(incl, 63);
+}
+
+// Each wave keeps sphere j's record and work item in lane j's registers: a run on a
+// sphere starts with a few v_readlane (SGPR results), no LDS round trip.
+struct WaveList {
+  float4 sph;   // lane j: sphere j
+  int4 item;    // lane j: see build_work_list
+  int end;      // lane j: weight prefix after sphere j
+};
+
+__device__ __forceinline__ WaveList load_wave_list(const float4 *s_sph, const int4 *s_items, const int *s_ends,
+                                                   int lane) {
+  WaveList w;
+  w.sph = s_sph[lane];
+  w.item = s_items[lane];
+  w.end = s_ends[lane];
+  return w;
+}
+
+template <bool POW2>
+__device__ __forceinline__ float axis_coord_t(const Axis &a, int u);
+
+// Walk the patch rows whose weight position lies in [lo, hi) (wave-uniform), sphere by
+// sphere.  Per sphere the column terms c = r*r - dx*dx of the first two patch columns
+// are hoisted out of the row loop and dy*dy out of the column loop, so a patch costs
+// two subtractions and a compare before `body(j, s, ua, ub, v, qa, qb, has_b)` -- two
+// side-by-side patches per call, q = (r*r - dx*dx) - dy*dy in the reference's
+// association.  `end_sphere(j)` closes a run on sphere j.
+template <bool POW2, typename Body, typename EndSphere>
+__device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int hi, int lane, const Axis &ax,
+                                           const Axis &ay, Body &&body, EndSphere &&end_sphere) {
+  const int lx = lane & (kPatchW - 1), ly = lane >> 4;
+  int j = __popcll(__ballot(lane < J && w.end <= lo));   // prefixes are non-decreasing
+  while (j < J) {
+    const int wstart = rl(w.item.w, j);
+    if (wstart >= hi) break;
+    const int shape = rl(w.item.y, j), wt = rl(w.item.z, j);
+    const int npx = shape & 0xffff, nrows = shape >> 16;
+    // first row whose position wstart + kSphereCost + r*wt is at or after lo (a few
+    // scalar steps; an integer division would cost more than the rows it skips)
+    int r = 0, p = wstart + kSphereCost;
+    while (p < lo && r < nrows) { ++r; p += wt; }
+    if (r < nrows && p < hi) {
+      const int geom = rl(w.item.x, j);
+      const float4 s = make_float4(readlane_f(w.sph.x, j), readlane_f(w.sph.y, j), readlane_f(w.sph.z, j),
+                                   readlane_f(w.sph.w, j));
+      const float rr = s.w * s.w;
+      const int ua = (geom & 0xffff) + lx, ub = ua + kPatchW;
+      const int v0 = (int)((unsigned)geom >> 16) + ly;
+      const float dxa = axis_coord_t<POW2>(ax, ua) - s.x, dxb = axis_coord_t<POW2>(ax, ub) - s.x;
+      const float ca = rr - dxa * dxa, cb = rr - dxb * dxb;
+      for (; r < nrows && p < hi; ++r, p += wt) {
+        const int v = v0 + r * kPatchH;
+        const float dy = axis_coord_t<POW2>(ay, v) - s.y;
+        const float dy2 = dy * dy;
+        // the first two columns go to the body together: two independent chains the
+        // scheduler can interleave (a wave runs one dependent instruction stream)
+        body(j, s, ua, ub, v, ca - dy2, cb - dy2, npx >= 2);
+        for (int px = 2; px < npx; px += 2) {
+          const int u = ua + px * kPatchW;
+          const float dx0 = axis_coord_t<POW2>(ax, u) - s.x, dx1 = axis_coord_t<POW2>(ax, u + kPatchW) - s.x;
+          body(j, s, u, u + kPatchW, v, (rr - dx0 * dx0) - dy2, (rr - dx1 * dx1) - dy2, px + 1 < npx);
+        }
       }
-      i += n;
+      end_sphere(j);
     }
     ++j;
   }
+}
+
+// wave w of nwaves takes the w-th equal slice of the total weight
+template <bool POW2, typename Body, typename EndSphere>
+__device__ __forceinline__ void walk_my_slice(const WaveList &w, int J, int total, int wave, int nwaves, int lane,
+                                              const Axis &ax, const Axis &ay, Body &&body, EndSphere &&end_sphere) {
+  wave = rfl(wave);   // everything that steers the loops is wave-uniform: keep it in SGPRs
+  total = rfl(total);
+  const int lo = (int)(((long long)wave * total) / nwaves), hi = (int)(((long long)(wave + 1) * total) / nwaves);
+  if (lo < hi) walk_slice<POW2>(w, J, lo, hi, lane, ax, ay, body, end_sphere);
 }
 
 // image axis coordinate with the power-of-two case resolved at compile time
@@ -186,6 +258,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
   int4 *s_items = reinterpret_cast<int4 *>(smem + kOffItems);
+  int *s_ends = reinterpret_cast<int *>(smem + kOffEnds);
   int *s_flag = reinterpret_cast<int *>(smem + kOffFlags);
   Key *zbuf = reinterpret_cast<Key *>(smem + kHdrBytes);
 
@@ -208,9 +281,10 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
     // sphere with z <= 100 contributes z - sqrt(q) < 100, so min(100, hits) is exact.
     const unsigned long long bad = __ballot(valid && !(sphere_is_tame(s) && fabsf(s.z) < 1e30f));
     const unsigned long long low = __ballot(valid && s.z <= kBackground);
-    const int total = build_work_list(s, valid, ax, ay, W, r0, r1, s_items, lane);
+    bool too_big;
+    const int total = build_work_list(s, valid, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
     if (lane == 0) {
-      s_flag[0] = (bad != 0ull) || (low == 0ull);
+      s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
       s_flag[1] = total;
     }
   }
@@ -246,23 +320,28 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
   // A patch may overhang the box, the image's right edge or the region's last row:
   // the hit test is exact for ANY pixel, overhanging lanes land in LDS padding.
   {
-    const int lx = lane & (kPatchW - 1), ly = lane >> 4;
-    for_each_patch(s_sph, s_items, J, s_flag[1], wave, nwaves, lane,
-                   [&](int j, const float4 s, int pu, int pv, bool, bool) {
-                     const int u = pu + lx, v = pv + ly;
-                     const float dx = axis_coord_t<POW2>(ax, u) - s.x;
-                     const float dy = axis_coord_t<POW2>(ay, v) - s.y;
-                     const float q = (s.w * s.w - dx * dx) - dy * dy;
-                     if (q > kHitMin) {
-                       const float d = s.z - sqrt_rn(q);
-                       Key *cell = zbuf + (v - r0) * LW + u;
-                       if (OWNER)
-                         atomicMin(reinterpret_cast<unsigned long long *>(cell),
-                                   ((unsigned long long)depth_key(d) << 32) | (unsigned)j);
-                       else
-                         atomicMin(reinterpret_cast<unsigned int *>(cell), depth_key(d));
-                     }
-                   });
+    const WaveList wl = load_wave_list(s_sph, s_items, s_ends, lane);
+    walk_my_slice<POW2>(
+        wl, J, s_flag[1], wave, nwaves, lane, ax, ay,
+        [&](int j, const float4 s, int ua, int ub, int v, float qa, float qb, bool has_b) {
+          Key *row = zbuf + (v - r0) * LW;
+          auto put = [&](Key *cell, float d) {
+            if (OWNER)
+              atomicMin(reinterpret_cast<unsigned long long *>(cell),
+                        ((unsigned long long)depth_key(d) << 32) | (unsigned)j);
+            else
+              atomicMin(reinterpret_cast<unsigned int *>(cell), depth_key(d));
+          };
+          if (has_b) {  // wave-uniform; branch-free up to the atomics: both roots in flight together
+            const bool ha = qa > kHitMin, hb = qb > kHitMin;
+            const float da = s.z - sqrt_rn(fmaxf(qa, kHitMin)), db = s.z - sqrt_rn(fmaxf(qb, kHitMin));
+            if (ha) put(row + ua, da);
+            if (hb) put(row + ub, db);
+          } else if (qa > kHitMin) {
+            put(row + ua, s.z - sqrt_rn(qa));
+          }
+        },
+        [](int) {});
   }
   __syncthreads();
 
@@ -317,6 +396,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
   int4 *s_items = reinterpret_cast<int4 *>(smem + kOffItems);
+  int *s_ends = reinterpret_cast<int *>(smem + kOffEnds);
   int *s_flag = reinterpret_cast<int *>(smem + kOffFlags);
   float4 *s_part = reinterpret_cast<float4 *>(smem + kHdrBytes);
   const int LW = W + kRowPad;
@@ -328,8 +408,6 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   const float *gin = grad_depth + (size_t)n * H * W;
   const uint8_t *oin = argmin + (size_t)n * H * W;
   const Axis ax = make_axis(W), ay = make_axis(H);
-  const int lx = lane & (kPatchW - 1), ly = lane >> 4;
-
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
   if (wave == 0) {
     if (lane < J) sph = spheres[(size_t)n * J + lane];
@@ -341,7 +419,8 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     const int r1 = min(H, r0 + rows_per_region), rh = r1 - r0;
     if (r0 > 0) __syncthreads();  // the previous region's walk is done
     if (wave == 0) {
-      const int total = build_work_list(sph, lane < J, ax, ay, W, r0, r1, s_items, lane);
+      bool too_big;   // excluded by the launcher (W <= kMaxFastWidth)
+      const int total = build_work_list(sph, lane < J, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
       if (lane == 0) s_flag[1] = total;
     }
     // owner padding = "nobody": the walk may overhang the image edge / region end
@@ -367,33 +446,41 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     }
     __syncthreads();
 
+    // Static schedule: wave w walks the w-th of 16 equal-weight contiguous slices of the
+    // list (which wave sums which pixels must not depend on timing); at the end of a
+    // run on a sphere its register partials are reduced with one DPP wave sum per
+    // component into the wave's private LDS slot.
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for_each_patch(s_sph, s_items, J, s_flag[1], wave, kZWaves, lane,
-                   [&](int j, const float4 s, int pu, int pv, bool, bool last) {
-                     const int u = pu + lx, v = pv + ly;
-                     const int cell = (v - r0) * LW + u;
-                     if (obuf[cell] == (uint8_t)j) {
-                       const float g = gbuf[cell];
-                       const float dx = axis_coord_t<POW2>(ax, u) - s.x;
-                       const float dy = axis_coord_t<POW2>(ay, v) - s.y;
-                       const float q = (s.w * s.w - dx * dx) - dy * dy;
-                       const float w = g * __builtin_amdgcn_rsqf(q);  // g / sqrt(q), ~1e-7 rel.
-                       a0 = __builtin_fmaf(-w, dx, a0);
-                       a1 = __builtin_fmaf(-w, dy, a1);
-                       a2 += g;
-                       a3 -= w;
-                     }
-                     if (last) {  // end of this wave's run on sphere j: one wave sum per component
-                       const float sx = wave_sum_lane63(a0), sy = wave_sum_lane63(a1);
-                       const float sz = wave_sum_lane63(a2), sw = wave_sum_lane63(a3);
-                       if (lane == 63) {
-                         float4 t = s_part[wave * SHR_MAX_SPHERES + j];
-                         t.x += sx; t.y += sy; t.z += sz; t.w += sw;
-                         s_part[wave * SHR_MAX_SPHERES + j] = t;
-                       }
-                       a0 = a1 = a2 = a3 = 0.f;
-                     }
-                   });
+    const WaveList wl = load_wave_list(s_sph, s_items, s_ends, lane);
+    walk_my_slice<POW2>(
+        wl, J, s_flag[1], wave, kZWaves, lane, ax, ay,
+        [&](int j, const float4 s, int ua, int ub, int v, float qa, float qb, bool has_b) {
+          const int row = (v - r0) * LW;
+          auto take = [&](int u, float q) {
+            if (obuf[row + u] == (uint8_t)j) {
+              const float g = gbuf[row + u];
+              const float dx = axis_coord_t<POW2>(ax, u) - s.x;
+              const float dy = axis_coord_t<POW2>(ay, v) - s.y;
+              const float w = g * __builtin_amdgcn_rsqf(q);  // g / sqrt(q), ~1e-7 rel.
+              a0 = __builtin_fmaf(-w, dx, a0);
+              a1 = __builtin_fmaf(-w, dy, a1);
+              a2 += g;
+              a3 -= w;
+            }
+          };
+          take(ua, qa);
+          if (has_b) take(ub, qb);
+        },
+        [&](int j) {
+          const float sx = wave_sum_lane63(a0), sy = wave_sum_lane63(a1);
+          const float sz = wave_sum_lane63(a2), sw = wave_sum_lane63(a3);
+          if (lane == 63) {
+            float4 t = s_part[wave * SHR_MAX_SPHERES + j];
+            t.x += sx; t.y += sy; t.z += sz; t.w += sw;
+            s_part[wave * SHR_MAX_SPHERES + j] = t;
+          }
+          a0 = a1 = a2 = a3 = 0.f;
+        });
   }
   __syncthreads();
   // combine the waves' partials in wave order; d/dr = r * sum(-g/sqrt(q))

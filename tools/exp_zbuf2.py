@@ -22,8 +22,8 @@ def timeit(fn, reps=300):
         e1.record(); e1.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
     return round(best, 2)
-names = {0: "full", 1: "no raster", 2: "no writeout", 3: "init only", 4: "raster w/o sqrt+atomic", 8: "raster w/o atomic", 6: "no-hit raster, no writeout"}
-for rows in (64, 128, 32):
+names = {0: "full", 1: "no raster", 2: "no writeout", 3: "init only", 4: "no hits", 8: "no atomic", 16: "approx sqrt", 24: "approx sqrt+no atomic"}
+for rows in (128,):
     for arg in (None, owner.data_ptr()):
         row = {names[m]: timeit(lambda: lib.exp_zfwd_launch(spheres.data_ptr(), N, J, S, S, depth.data_ptr(), arg, rows, m, st)) for m in names}
         print("rows=%d owner=%s" % (rows, arg is not None), row)

@@ -27,3 +27,12 @@ print("block start skew (ticks): max-min over blocks", t[:, 0, 0].max() - t[:, 0
 print("raster per wave: mean %.0f max-in-block mean %.0f" % ((t[:, :, 4] - t[:, :, 3]).mean(), (t[:, :, 4] - t[:, :, 3]).max(1).mean()))
 print("patches per crop mean", t[:, 0, 7].mean())
 print("kernel span first start -> last end:", t[:, :, 6].max() - t[:, :, 0].min())
+r = (t[:, :, 4] - t[:, :, 3])
+print("raster cycles by wave index (mean over crops):", np.round(r.mean(0)).astype(int).tolist())
+print("raster cycles by wave index (max over crops): ", np.round(r.max(0)).astype(int).tolist())
+print("crop 0 per wave:", r[0].astype(int).tolist())
+print("crop 1 per wave:", r[1].astype(int).tolist())
+w = (t[:, :, 6] - t[:, :, 5])
+print("writeout cycles by wave (mean):", np.round(w.mean(0)).astype(int).tolist())
+i = (t[:, :, 2] - t[:, :, 1])
+print("init cycles by wave (mean):", np.round(i.mean(0)).astype(int).tolist())
