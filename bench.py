@@ -91,6 +91,32 @@ def pmc_traffic(kernel):
         return None, None
 
 
+def timed_steps(step, steps, warmup, dist, device):
+    """The driver's timing contract: `warmup` untimed steps, then exactly `steps` steps
+    bracketed by a barrier + device synchronize on both sides; returns the MAX over
+    ranks of the elapsed seconds (every rank gets the same number)."""
+    def fence():
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+    for _ in range(warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,24 +171,7 @@ def main():
             else:
                 fwd(sh); bwd(sh)
 
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        elapsed = timed_steps(step, args.steps, args.warmup, dist, dev)
 
         # per-kernel mean launch duration: HIP events on the launching stream
         # around R back-to-back launches of one kernel

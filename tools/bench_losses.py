@@ -1,0 +1,39 @@
+"""Secondary timings: MutualProjectionLoss fwd+bwd and its parts (not the headline metric)."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from spherehand_amd import hand_model, ops
+from spherehand_amd.datasets import SyntheticMultiviewDataset
+from spherehand_amd.multiview_utility import MutualProjectionLoss
+from spherehand_amd.render import DepthRender
+from spherehand_amd.util_modules import HandSynthesizer
+from spherehand_amd.joint_angle import sample_poses
+mesh = hand_model.load_mesh()
+def timeit(fn, reps=50):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e6
+for B, S in ((25, 64), (128, 128), (128, 256)):
+    ds = SyntheticMultiviewDataset(mesh, B, S, seed=0)
+    crit = MutualProjectionLoss(S, mesh).cuda()
+    real, cam, inv = ds.dms.cuda(), ds.cam.cuda(), ds.inv_cam.cuda()
+    joints = (ds.joints.cuda() + torch.randn_like(ds.joints.cuda())).requires_grad_(True)
+    def step():
+        joints.grad = None
+        loss, _ = crit(cam, inv, joints, real, True)
+        loss.backward()
+    t = timeit(step)
+    N = B * 9
+    d2m = timeit(lambda: ops.data_to_model(real.unsqueeze(1).expand(B, 3, 3, S, S).reshape(N, S, S).contiguous(),
+                                          torch.zeros(N, 41, 3, device="cuda"), crit.data_to_model_criterion.radiuses.view(-1), True))
+    print("MutualProjectionLoss fwd+bwd B=%d V=3 S=%d (%d crops): %.1f us/step = %.2f M crops/s ; data_to_model alone (incl. expand copy) %.1f us"
+          % (B, S, N, t, N / t, d2m))
+syn = HandSynthesizer(mesh, 64, 16, 1.0, 0.01).cuda()
+p = sample_poses(48, seed=0).cuda()
+print("HandSynthesizer B=48 S=64: %.1f us" % timeit(lambda: syn(p)))
+dr = DepthRender(mesh, 128).cuda()
+T = syn.hand_skeleton_transform(sample_poses(256, seed=1).cuda())
+print("DepthRender B=256 S=128: %.1f us  (%.0f crops/s)" % (timeit(lambda: dr(T), 20), 256 / timeit(lambda: dr(T), 20) * 1e6))
