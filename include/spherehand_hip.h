@@ -129,6 +129,15 @@ int shr_tri_raster_fwd(const float *face_vertices, int B, int F, int W, int H,
 int shr_tri_raster_indexed_fwd(const float *vertices, const int32_t *faces, int B,
                                int NV, int F, int W, int H, float *depth, void *stream);
 
+/* Fused DepthRender back end: raster + clamp(max) + bilinear resize src_size -> S, touching
+ * only the source pixels the resize reads.  Replaces the chain
+ * DepthRasterizationFunction.apply(640,640,...) / clamp / F.interpolate of
+ * mesh/render.py:284-287, :310-311.  vertices[B,NV,4] in src_size pixel space, faces[F,3]
+ * (winding already swapped for the right hand).  depth[B,S,S].  Needs 2*S <= src_size + 1
+ * (a down-sampling). */
+int shr_mesh_depth_fwd(const float *vertices, const int32_t *faces, int B, int NV, int F,
+                       int src_size, int S, float clamp_max, float *depth, void *stream);
+
 /* Skinning + orthographic camera -----------------------------------------------------
  * Replaces LinearBlendSkinning.forward (mesh/pointTransformation.py:39-46) and
  * OthographicalProjection.forward (:84-99).  T[B,NB,4,4]; the skin table is CSR by

@@ -34,6 +34,7 @@ SIGNATURES = {
     "shr_mutual_project_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "shr_tri_raster_fwd": ([_vp, _i, _i, _i, _i, _vp, _vp], _i),
     "shr_tri_raster_indexed_fwd": ([_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "shr_mesh_depth_fwd": ([_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp], _i),
     "shr_lbs_project": ([_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp], _i),
     "shr_fk_fwd": ([_vp, _i, _vp, _vp, _vp, _vp], _i),
     "shr_fk_bwd": ([_vp, _i, _vp, _vp, _vp, _vp, _vp], _i),

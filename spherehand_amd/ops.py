@@ -249,3 +249,18 @@ class ForwardKinematics(torch.autograd.Function):
             _lib.check(_lib.lib().shr_fk_bwd(_ptr(params), B, _ptr(offset), _ptr(offset_inv), _ptr(g), _ptr(out),
                                              _stream()), "shr_fk_bwd")
         return out, None, None
+
+
+def mesh_depth_fwd(vertices, faces, out_size, src_size=640, clamp_max=100.0):
+    """vertices [B,NV,4] (src_size pixel space) + faces [F,3] int32 -> depth [B,S,S]: triangle
+    raster at src_size, clamp(max), bilinear resize to S, fused (only the sampled pixels)."""
+    _check_input(vertices, "vertices")
+    _check_input(faces, "faces", torch.int32)
+    if vertices.dim() != 3 or vertices.shape[2] != 4 or faces.dim() != 2 or faces.shape[1] != 3:
+        raise RuntimeError("vertices must be [B,NV,4] and faces [F,3]")
+    B, NV = vertices.shape[0], vertices.shape[1]
+    with torch.cuda.device(vertices.device):
+        depth = torch.empty((B, out_size, out_size), dtype=torch.float32, device=vertices.device)
+        _lib.check(_lib.lib().shr_mesh_depth_fwd(_ptr(vertices), _ptr(faces), B, NV, faces.shape[0], src_size, out_size,
+                                                 clamp_max, _ptr(depth), _stream()), "shr_mesh_depth_fwd")
+    return depth

@@ -103,8 +103,9 @@ class DepthRasterizationFunction(torch.autograd.Function):
 
 class DepthRasterization(nn.Module):
     """mesh/render.py:289-312.  forward(vertices[B,NV,>=3]) -> [B,height,width]:
-    rasterize at 640x640, clamp, bilinear-downsample.  `np_faces` is NOT modified
-    (the reference swaps its columns in place for the right hand, :298-300)."""
+    rasterize at 640x640, clamp, bilinear-downsample -- by default as ONE fused kernel that
+    only rasterizes the source pixels the resize reads (`fused`).  `np_faces` is NOT
+    modified (the reference swaps its columns in place for the right hand, :298-300)."""
 
     def __init__(self, width, height, np_faces, right_hand=True):
         super().__init__()
@@ -116,10 +117,15 @@ class DepthRasterization(nn.Module):
         self.register_buffer('faces', torch.from_numpy(faces).view(-1))
         self.register_buffer('faces_i32', torch.from_numpy(faces.astype(np.int32)).contiguous())
         self.num_faces = len(faces)
+        self.fused = True     # False: explicit 640x640 raster, then torch clamp + interpolate
 
     def forward(self, vertices):
         num_batch = vertices.shape[0]
-        if vertices.is_cuda and vertices.shape[-1] == 4 and vertices.dtype == torch.float32:
+        on_kernel = vertices.is_cuda and vertices.shape[-1] == 4 and vertices.dtype == torch.float32
+        if on_kernel and self.fused and self.width == self.height and 2 * self.width <= 641:
+            # raster + clamp + resize in one pass over the sampled source pixels only
+            return ops.mesh_depth_fwd(vertices.contiguous(), self.faces_i32, self.height, 640, 100.0)
+        if on_kernel:
             # face gather fused into the rasterizer (no [B,F,3,3] intermediate)
             raw = ops.tri_raster_indexed_fwd(640, 640, vertices.contiguous(), self.faces_i32)
             rendered_dm = torch.clamp(raw, max=100.0).unsqueeze(1)

@@ -121,3 +121,40 @@ def test_depth_rasterization_module_paths_agree():
     b = torch.nn.functional.interpolate(DepthRasterizationFunction.apply(640, 640, fv).unsqueeze(1), size=(128, 128),
                                         mode="bilinear", align_corners=False).squeeze(1)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("S", [64, 128, 256, 96, 40])
+def test_fused_depth_render_equals_the_explicit_chain(S):
+    """Fused raster+clamp+resize vs the explicit 640x640 raster -> torch clamp -> F.interpolate.
+    The sampled raster values are the same numbers; only the 4-term bilinear sum may contract
+    differently inside torch's kernel (weights 0.25/0.75 at S=256): 1e-5 relative."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.render import DepthRasterization
+    g = golden("g2_mesh.npz")
+    r = DepthRasterization(S, S, hand_model.load_mesh()["faces"]).cuda()
+    verts = dev(g["verts"])
+    fused = r(verts)
+    r.fused = False
+    chain = r(verts)
+    assert fused.shape == (4, S, S)
+    assert (fused - chain).abs().max().item() <= 1e-5 * max(1.0, chain.abs().max().item())
+    if S in (64, 128):
+        assert torch.equal(fused, chain)              # weights 1 / 0.5: every product is exact
+    assert (fused < 100).float().mean().item() > 0.02
+
+
+def test_fused_depth_render_rand_f_and_batch():
+    from spherehand_amd import hand_model
+    from spherehand_amd.joint_angle import sample_poses
+    from spherehand_amd.kinematicsTransformation import HandTransformationMat
+    from spherehand_amd.render import DepthRender
+    mesh = hand_model.load_mesh()
+    fk = HandTransformationMat([b["offset_matrix"].astype(np.float32) for b in mesh["bones"]]).cuda()
+    T = fk(sample_poses(96, seed=9).cuda())
+    rf = torch.rand(96, device="cuda") * 0.2 + 0.9
+    for S in (64, 128):
+        render = DepthRender(mesh, S).cuda()
+        a = render(T, rf)
+        render.rasterizer.fused = False
+        b = render(T, rf)
+        assert torch.equal(a, b)
