@@ -71,6 +71,24 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
+// min / max over the 64 lanes, broadcast to every lane (same DPP butterfly; lanes whose
+// DPP source is invalid or masked combine with their own value)
+template <int CTRL, int ROW_MASK, bool IS_MIN>
+__device__ __forceinline__ float dpp_minmax(float v) {
+  const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+  return IS_MIN ? fminf(v, o) : fmaxf(v, o);
+}
+template <bool IS_MIN>
+__device__ __forceinline__ float wave_minmax_all(float v) {
+  v = dpp_minmax<0xB1, 0xF, IS_MIN>(v);
+  v = dpp_minmax<0x4E, 0xF, IS_MIN>(v);
+  v = dpp_minmax<0x141, 0xF, IS_MIN>(v);
+  v = dpp_minmax<0x140, 0xF, IS_MIN>(v);
+  v = dpp_minmax<0x142, 0xA, IS_MIN>(v);
+  v = dpp_minmax<0x143, 0xC, IS_MIN>(v);
+  return readlane_f(v, 63);
+}
+
 __device__ __forceinline__ bool is_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
 }  // namespace shr

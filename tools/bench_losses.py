@@ -27,10 +27,15 @@ for B, S in ((25, 64), (128, 128), (128, 256)):
         loss.backward()
     t = timeit(step)
     N = B * 9
-    d2m = timeit(lambda: ops.data_to_model(real.unsqueeze(1).expand(B, 3, 3, S, S).reshape(N, S, S).contiguous(),
-                                          torch.zeros(N, 41, 3, device="cuda"), crit.data_to_model_criterion.radiuses.view(-1), True))
-    print("MutualProjectionLoss fwd+bwd B=%d V=3 S=%d (%d crops): %.1f us/step = %.2f M crops/s ; data_to_model alone (incl. expand copy) %.1f us"
-          % (B, S, N, t, N / t, d2m))
+    with torch.no_grad():
+        _, pts = crit.mutual_projection(cam, inv, joints.detach())
+    obs = real.unsqueeze(1).expand(B, 3, 3, S, S).reshape(N, S, S).contiguous()
+    cen = pts.squeeze(-1).reshape(N, 41, 3).contiguous()
+    rad = crit.data_to_model_criterion.radiuses.view(-1)
+    d2m = timeit(lambda: ops.data_to_model(obs, cen, rad, True))
+    d2m0 = timeit(lambda: ops.data_to_model(obs, torch.zeros_like(cen), rad, True))
+    print("MutualProjectionLoss fwd+bwd B=%d V=3 S=%d (%d crops): %.1f us/step = %.2f M crops/s ; data_to_model kernel %.1f us "
+          "(all centres at the origin, no pruning possible: %.1f us)" % (B, S, N, t, N / t, d2m, d2m0))
 syn = HandSynthesizer(mesh, 64, 16, 1.0, 0.01).cuda()
 p = sample_poses(48, seed=0).cuda()
 print("HandSynthesizer B=48 S=64: %.1f us" % timeit(lambda: syn(p)))
