@@ -334,7 +334,8 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
           };
           if (has_b) {  // wave-uniform; branch-free up to the atomics: both roots in flight together
             const bool ha = qa > kHitMin, hb = qb > kHitMin;
-            const float da = s.z - sqrt_rn(fmaxf(qa, kHitMin)), db = s.z - sqrt_rn(fmaxf(qb, kHitMin));
+            // (the root of a non-hit lane's q may be NaN: never stored)
+            const float da = s.z - sqrt_rn(qa), db = s.z - sqrt_rn(qb);
             if (ha) put(row + ua, da);
             if (hb) put(row + ub, db);
           } else if (qa > kHitMin) {

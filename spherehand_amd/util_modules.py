@@ -111,11 +111,36 @@ class DepthNoise(nn.Module):
 
 
 class ResizeCropImage(nn.Module):
-    """Per-image anisotropic down-scale (nearest) pasted centred on a canvas of ones;
-    like the reference, only scales <= 1 in v are pasted (its paste sits under the
-    v-branch's else, network/util_modules.py:411-423)."""
+    """Per-image anisotropic down-scale (nearest neighbour) pasted centred on a canvas of
+    ones; like the reference, only scales <= 1 in v are pasted (its paste sits under the
+    v-branch's else, network/util_modules.py:411-423).  One batched gather on the device,
+    no per-image loop and no host synchronisation (the reference resizes image by image,
+    :392-423); `forward_loop` keeps that formulation for the tests."""
 
     def forward(self, depth_maps, u_scales, v_scales):
+        n, h, w = depth_maps.shape
+        dev = depth_maps.device
+        us, vs = u_scales.to(dev).double(), v_scales.to(dev).double()        # python-float arithmetic of the reference
+        new_h, new_w = (h * vs + 0.5).long(), (w * us + 0.5).long()          # int(x + 0.5)
+        big_u = us > 1
+        ou0 = torch.where(big_u, (new_w - w) // 2, torch.zeros_like(new_w))  # first resized column that is pasted
+        ncol = torch.where(big_u, torch.full_like(new_w, w), (w * us).long())
+        u0 = torch.where(big_u, torch.zeros_like(new_w), (w - new_w) // 2)   # first canvas column
+        nrow = (h * vs).long()
+        v0 = (h - new_h) // 2
+        rows = torch.arange(h, device=dev).view(1, h)
+        cols = torch.arange(w, device=dev).view(1, w)
+        r = rows - v0.view(n, 1)                                              # row in the resized image
+        c = cols - u0.view(n, 1) + ou0.view(n, 1)
+        row_ok = (r >= 0) & (r < nrow.view(n, 1)) & (vs <= 1).view(n, 1)
+        col_ok = (cols >= u0.view(n, 1)) & (cols < (u0 + ncol).view(n, 1))
+        # ATen nearest: src = min(floor(dst * (float)in/out), in - 1)
+        sr = torch.clamp((r.float() * (h / new_h.clamp(min=1).float()).view(n, 1)).floor().long(), 0, h - 1)
+        sc = torch.clamp((c.float() * (w / new_w.clamp(min=1).float()).view(n, 1)).floor().long(), 0, w - 1)
+        picked = depth_maps.gather(1, sr.view(n, h, 1).expand(n, h, w)).gather(2, sc.view(n, 1, w).expand(n, h, w))
+        return torch.where(row_ok.view(n, h, 1) & col_ok.view(n, 1, w), picked, torch.ones_like(depth_maps))
+
+    def forward_loop(self, depth_maps, u_scales, v_scales):
         h, w = depth_maps.shape[-2], depth_maps.shape[-1]
         out = torch.ones_like(depth_maps)
         for idx, (us, vs) in enumerate(zip(u_scales.tolist(), v_scales.tolist())):

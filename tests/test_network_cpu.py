@@ -131,3 +131,22 @@ def test_nyu_shard_roundtrip(tmp_path):
     assert np.allclose(cam @ inv, np.eye(4), atol=1e-5)
     with pytest.raises(FileNotFoundError):
         create_nyu_dataset(str(tmp_path / "missing"))
+
+
+def test_resize_crop_batched_equals_per_image_loop():
+    """The batched gather reproduces the reference's image-by-image F.interpolate + paste
+    (network/util_modules.py:383-424), including its 'v > 1 is not pasted' quirk."""
+    from spherehand_amd.util_modules import ResizeCropImage
+    m = ResizeCropImage()
+    g = torch.Generator().manual_seed(0)
+    for (n, h, w) in ((9, 64, 64), (5, 48, 80), (4, 128, 128)):
+        dms = torch.rand(n, h, w, generator=g)
+        us = torch.rand(n, generator=g) * 0.5 + 0.7          # 0.7 .. 1.2: both branches of u
+        vs = torch.rand(n, generator=g) * 0.45 + 0.65        # some > 1: left as ones
+        us[0], vs[0] = 1.0, 1.0
+        a, b = m(dms, us, vs), m.forward_loop(dms, us, vs)
+        assert torch.equal(a, b), (n, h, w)
+    scale = torch.rand(75, generator=g) * 0.2 + 0.75          # the training-time range (:99-101 of the wrapper)
+    dms = torch.rand(75, 64, 64, generator=g)
+    u, v = scale + torch.rand(75, generator=g) * 0.1 - 0.05, scale + torch.rand(75, generator=g) * 0.1 - 0.05
+    assert torch.equal(m(dms, u, v), m.forward_loop(dms, u, v))
