@@ -13,11 +13,11 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["zbuf", "general", "zbuf-small-lds"])
+@pytest.fixture(scope="module", params=["zbuf", "general", "zbuf-small-lds", "zbuf-4-waves"])
 def ops(request):
     """Every test runs on the fast LDS z-buffer kernels, on the general tile
-    kernels, and on the z-buffer kernels squeezed into 16 KB of LDS (many row
-    regions per crop)."""
+    kernels, on the z-buffer kernels squeezed into 16 KB of LDS (many row regions
+    per crop) and with 4-wave forward workgroups."""
     from spherehand_amd import ops as o
     assert torch.cuda.is_available()
     o.set_tuning(o.TUNE_FORCE_GENERAL, 1 if request.param == "general" else 0)
@@ -25,7 +25,9 @@ def ops(request):
     o.set_tuning(o.TUNE_FWD_LDS_BYTES, 16 * 1024 if small else 64 * 1024)
     o.set_tuning(o.TUNE_FWD_OWNER_LDS_BYTES, 24 * 1024 if small else 0)
     o.set_tuning(o.TUNE_BWD_LDS_BYTES, 16 * 1024 if small else 128 * 1024)
+    o.set_tuning(o.TUNE_FWD_WAVES, 4 if request.param == "zbuf-4-waves" else 16)
     yield o
+    o.set_tuning(o.TUNE_FWD_WAVES, 16)
     o.set_tuning(o.TUNE_FORCE_GENERAL, 0)
     o.set_tuning(o.TUNE_FWD_LDS_BYTES, 64 * 1024)
     o.set_tuning(o.TUNE_FWD_OWNER_LDS_BYTES, 0)
