@@ -1,45 +1,17 @@
-// data_to_model.hip -- data-to-model loss: observed depth pixels vs the sphere set.
-//
-// Replaces (reference file:line): mesh/render.py:123-142 DataToModelLoss.forward
-// and its autograd backward.  Per pixel p = (xg, yg, depth) with depth <= 99:
-//     e = min_j | ||p - c_j||_2 - r_j | ,  clamp(e, 0, 50)
-// loss_sum[n] = sum over the crop's pixels (background contributes 0; the
-// reference's scalar is sum_n loss_sum[n] / (N*H*W), mesh/render.py:142).
-// The loss is a plain sum, so its gradient w.r.t. the centres does not depend on
-// the upstream value: the same pass also emits
-//     grad_centres[n,j,:] = d loss_sum[n] / d c_j
-//                         = sum over pixels owned by j with e <= 50 of
-//                           -sign(dist - r_j) * (p - c_j) / dist
-// and the caller scales it by upstream / (N*H*W).
-//
-// The nearest surface can be ANY sphere (no culling is valid), but only ~15 % of
-// the pixels are foreground, so each 4096-pixel chunk is first compacted:
-//   1. coalesced 16-byte depth loads, foreground flags, deterministic block scan;
-//   2. foreground pixels packed into an LDS queue (lanes fully used from here);
-//   3. each wave bounds the J spheres against the bounding box of its 64 queue entries
-//      (lanes = spheres) and searches only the candidates that can be nearest (lanes =
-//      points) and adds the clamped distance;
-//   4. the gradient vectors of a wave's 64 points are summed per owner with DPP wave
-//      sums into the wave's private LDS row; rows are combined in wave order:
-//      deterministic, no atomics.
-// One workgroup per crop.  HBM: reads 4*H*W + 12*J + 4*J bytes per crop.
-
-#include "common.h"
-
+#include "../spherehand_amd/csrc/common.h"
 namespace shr {
-
 constexpr int kD2mThreads = 1024;
-constexpr int kD2mPix = 16;                           // a 4x4-pixel block per thread per chunk (4 x 16-byte loads in flight);
-                                                      // 1024 threads = 16384 px = a whole 128x128 crop
+constexpr int kD2mPix = 16;                           // pixels per thread per chunk (4 x 16-byte loads in flight)
+constexpr int kD2mChunk = kD2mPix * kD2mThreads;      // 16384 px: a whole 128x128 crop
 constexpr int kD2mQueue = 4096;                       // queue entries (64 KB); denser chunks take extra passes
 
 struct QEntry { float a, b, c; int d; };  // phase 2: (xg, yg, z, -) ; phase 3: (gx, gy, gz, owner)
 
 template <bool WANT_GRAD>
 __global__ void __launch_bounds__(kD2mThreads)
-data_to_model_kernel(const float *__restrict__ depth, const float *__restrict__ centres,
+exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
                      const float *__restrict__ radii, int J, int H, int W, float *__restrict__ loss_sum,
-                     float *__restrict__ grad_centres) {
+                     float *__restrict__ grad_centres, int mode) {
   __shared__ float4 s_c[SHR_MAX_SPHERES];     // (cx, cy, cz, r)
   __shared__ int s_wave_cnt[kD2mThreads / 64];
   __shared__ float s_wave_loss[kD2mThreads / 64];
@@ -54,61 +26,46 @@ data_to_model_kernel(const float *__restrict__ depth, const float *__restrict__ 
   }
   const float *dm = depth + (size_t)n * H * W;
   const Axis ax = make_axis(W), ay = make_axis(H);
+  const int npix = H * W;
   const bool row4 = (W % 4 == 0) && is_aligned16(dm);
 
   float loss = 0.f;
   if (WANT_GRAD) s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);   // 1024 = 16 waves x 64 spheres
 
-  // Threads own 4x4-pixel blocks (block id = chunk base + thread id, row-major over the
-  // ceil(W/4) x ceil(H/4) block grid): each of a thread's four 16-byte loads is contiguous
-  // with its neighbours' in x, and the queue (thread order, row-major inside a block) keeps
-  // neighbouring pixels together, so a wave's 64 entries have a tight bounding box (step 3).
-  const int nbx = (W + 3) >> 2, nby = (H + 3) >> 2;
-  const int nblocks = nbx * nby;
-  for (int base = 0; base < nblocks; base += kD2mThreads) {
-    // ---- 1. load the block (all four loads issued before the first use), flag foreground
-    const int blk = base + tid;
-    const int by = blk / nbx, bx = blk - by * nbx;
-    const int u0 = bx * 4, v0 = by * 4;
+  for (int base = 0; base < npix; base += kD2mChunk) {
+    // ---- 1. load 16 consecutive pixels (four 16-byte loads, all issued before the first
+    // use), flag foreground.  Consecutive pixels per thread keep the queue in scan order,
+    // so a wave's 64 entries are neighbours and their bounding box is tight (step 3).
     float z[kD2mPix];
     int cnt = 0;
     unsigned fgmask = 0;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-      const int v = v0 + g;
+      const int p0 = base + kD2mPix * tid + 4 * g;
       float4 t = make_float4(100.f, 100.f, 100.f, 100.f);
-      if (blk < nblocks && v < H) {
-        const float *rowp = dm + (size_t)v * W + u0;
-        if (row4) {
-          t = *reinterpret_cast<const float4 *>(rowp);
-        } else {
-          if (u0 + 0 < W) t.x = rowp[0];
-          if (u0 + 1 < W) t.y = rowp[1];
-          if (u0 + 2 < W) t.z = rowp[2];
-          if (u0 + 3 < W) t.w = rowp[3];
-        }
+      if (row4) {
+        if (p0 < npix) t = *reinterpret_cast<const float4 *>(dm + p0);
+      } else {
+        if (p0 + 0 < npix) t.x = dm[p0 + 0];
+        if (p0 + 1 < npix) t.y = dm[p0 + 1];
+        if (p0 + 2 < npix) t.z = dm[p0 + 2];
+        if (p0 + 3 < npix) t.w = dm[p0 + 3];
       }
       z[4 * g] = t.x; z[4 * g + 1] = t.y; z[4 * g + 2] = t.z; z[4 * g + 3] = t.w;
     }
 #pragma unroll
     for (int k = 0; k < kD2mPix; k++) {
-      const bool in = blk < nblocks && (v0 + (k >> 2)) < H && (u0 + (k & 3)) < W;
-      const bool fg = in && !(z[k] > 99.0f);  // mesh/render.py:138 background = d > 99
+      const int p = base + kD2mPix * tid + k;
+      const bool fg = (p < npix) && !(z[k] > 99.0f);  // mesh/render.py:138 background = d > 99
       fgmask |= (unsigned)fg << k;
       cnt += fg;
     }
-    // deterministic exclusive scan of cnt over the workgroup (queue order = thread order):
-    // 4 DPP steps inside each row of 16 lanes, then the row totals via SGPR broadcasts
+    // deterministic exclusive scan of cnt over the workgroup (queue order = thread order)
     int incl = cnt;
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);  // row_shr:1
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);  // row_shr:2
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);  // row_shr:4
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);  // row_shr:8
-    {
-      const int r0s = __builtin_amdgcn_readlane(incl, 15), r1s = __builtin_amdgcn_readlane(incl, 31);
-      const int r2s = __builtin_amdgcn_readlane(incl, 47);
-      const int row = lane >> 4;
-      incl += (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
     }
     if (base > 0) __syncthreads();  // previous chunk's queue fully consumed
     if (lane == 63) s_wave_cnt[wave] = incl;
@@ -126,18 +83,18 @@ data_to_model_kernel(const float *__restrict__ depth, const float *__restrict__ 
     // ---- 2. compact ---------------------------------------------------------------------
     {
       int slot = offset - q0;
-      const float xg0 = axis_coord(ax, u0), xg1 = axis_coord(ax, u0 + 1), xg2 = axis_coord(ax, u0 + 2),
-                  xg3 = axis_coord(ax, u0 + 3);
+      const int pfirst = base + kD2mPix * tid;
+      int v = pfirst / W, u = pfirst - v * W;   // one division per thread, then incremental
 #pragma unroll
-      for (int k = 0; k < kD2mPix; k++) {
+      for (int k = 0; k < kD2mPix; k++, u = (u + 1 == W) ? 0 : u + 1, v += (u == 0)) {
         if ((fgmask >> k) & 1u) {
           if (slot >= 0 && slot < kD2mQueue) {
             QEntry e;
-            e.a = (k & 3) == 0 ? xg0 : ((k & 3) == 1 ? xg1 : ((k & 3) == 2 ? xg2 : xg3));
-            e.b = axis_coord(ay, v0 + (k >> 2));
+            e.a = axis_coord(ax, u);
+            e.b = axis_coord(ay, v);
             e.c = z[k];
             e.d = 0;
-            s_q[slot] = e;
+            if (!(mode & 8)) s_q[slot] = e;
           }
           ++slot;
         }
@@ -153,7 +110,7 @@ data_to_model_kernel(const float *__restrict__ depth, const float *__restrict__ 
     // of 41).  Bounds carry a rounding slack; a NaN anywhere disables the pruning.
     {
       const float4 cj = lane < J ? s_c[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int i0 = wave * 64; i0 < total; i0 += kD2mThreads) {
+      if (!(mode & 1)) for (int i0 = wave * 64; i0 < total; i0 += kD2mThreads) {
         const int i = i0 + lane;
         const bool act = i < total;
         QEntry e = s_q[act ? i : i0];
@@ -171,7 +128,7 @@ data_to_model_kernel(const float *__restrict__ depth, const float *__restrict__ 
         const float ub = fmaxf(fabsf(dmin - cj.w), fabsf(dmax - cj.w));
         const float U = wave_minmax_all<true>(lane < J ? ub : inf);
         const bool pruned = (lb * 0.99999f - 1e-3f) > (U * 1.00001f + 1e-3f);   // false on NaN
-        unsigned long long cand = __ballot(lane < J && !pruned);
+        unsigned long long cand = __ballot(lane < J && (!pruned || (mode & 2)));
         float best = 0.f;
         int bj = 0;
         bool first = true;
@@ -203,7 +160,8 @@ data_to_model_kernel(const float *__restrict__ depth, const float *__restrict__ 
           }
           // the 64 neighbouring points have 2-4 distinct owners: one DPP wave sum per owner
           // into this wave's private LDS row (fixed order: deterministic)
-          unsigned long long todo = __ballot(owner >= 0);
+          unsigned long long todo = (mode & 4) ? 0ull : __ballot(owner >= 0);
+          if (mode & 4) loss += gx + gy + gz;
           while (todo) {
             const int j = __builtin_amdgcn_readlane(owner, __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo)));
             const bool mine = owner == j;
@@ -242,20 +200,9 @@ data_to_model_kernel(const float *__restrict__ depth, const float *__restrict__ 
   }
 }
 
-}  // namespace shr
-
-extern "C" int shr_data_to_model(const float *depth, const float *centres, const float *radii, int N, int J, int H,
-                                 int W, float *loss_sum, float *grad_centres, void *stream) {
-  using namespace shr;
-  if (N == 0) return SHR_OK;
-  if (!depth || !centres || !radii || !loss_sum || N < 0 || J <= 0 || H <= 0 || W <= 0) return SHR_EINVAL;
-  if (J > SHR_MAX_SPHERES || (long long)H * W > (1LL << 30)) return SHR_ETOOLARGE;
-  hipStream_t s = (hipStream_t)stream;
-  if (grad_centres)
-    hipLaunchKernelGGL(data_to_model_kernel<true>, dim3((unsigned)N), dim3(kD2mThreads), 0, s, depth, centres, radii,
-                       J, H, W, loss_sum, grad_centres);
-  else
-    hipLaunchKernelGGL(data_to_model_kernel<false>, dim3((unsigned)N), dim3(kD2mThreads), 0, s, depth, centres, radii,
-                       J, H, W, loss_sum, grad_centres);
+}
+extern "C" int exp_d2m_launch(const float *depth, const float *centres, const float *radii, int N, int J, int H, int W,
+                              float *loss_sum, float *grad, int mode, void *stream) {
+  hipLaunchKernelGGL(shr::exp_d2m<true>, dim3(N), dim3(1024), 0, (hipStream_t)stream, depth, centres, radii, J, H, W, loss_sum, grad, mode);
   return (int)hipGetLastError();
 }
