@@ -52,6 +52,11 @@ int shr_device_info(char *name_host, int name_len, int *num_cu_host);
 #define SHR_TUNE_BWD_LDS_BYTES 3
 #define SHR_TUNE_FORCE_GENERAL 4
 #define SHR_TUNE_FWD_WAVES 5  /* waves per forward workgroup, 1..16 */
+/* Shares of a crop's work list given to the four wave age groups of a 16-wave
+ * workgroup (waves 0-3, 4-7, 8-11, 12-15; the SIMD arbitration favours the oldest):
+ * one byte per group, oldest in the low byte, any scale (normalised internally). */
+#define SHR_TUNE_FWD_SHARES 6
+#define SHR_TUNE_BWD_SHARES 7
 int shr_set_tuning(int key, int value);
 /* Self-test: adds to *mismatches (device, caller-zeroed u64) the number of fp32
  * bit patterns in [lo_bits, hi_bits) where the rasterizer's internal square root

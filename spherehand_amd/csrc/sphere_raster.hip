@@ -15,6 +15,8 @@ struct Tuning {
   int bwd_lds_bytes = 128 * 1024;       // backward staging (grad f32 + owner u8)
   int force_general = 0;                // 1: always the tile kernels (tests)
   int fwd_waves = 16;                   // waves per forward workgroup
+  int fwd_shares = 0x28384858;          // work-list shares of the four wave age groups, oldest in the low byte (sum 256)
+  int bwd_shares = 0x2c3a4654;
 } g_tune;
 
 constexpr int kMaxLds = 160 * 1024;
@@ -64,7 +66,8 @@ int launch_zbuf_fwd_t(const float4 *sp, int N, int J, int H, int W, float *depth
   if (e != hipSuccess) return (int)e;
   const size_t lds = kHdrBytes + (size_t)(rows + kPadRows) * (W + kRowPad) * (OWNER ? 8 : 4);
   dim3 grid((unsigned)N, (unsigned)((H + rows - 1) / rows)), block(64 * g_tune.fwd_waves);
-  hipLaunchKernelGGL(k, grid, block, lds, s, sp, J, H, W, depth, argmin, rows, log2_if_pow2(W / 4));
+  hipLaunchKernelGGL(k, grid, block, lds, s, sp, J, H, W, depth, argmin, rows, log2_if_pow2(W / 4),
+                     g_tune.fwd_shares);
   return (int)hipGetLastError();
 }
 
@@ -85,7 +88,7 @@ int launch_zbuf_bwd_t(const float4 *sp, const float *grad, const uint8_t *argmin
   if (e != hipSuccess) return (int)e;
   const size_t lds = kHdrBytes + kPartBytes + (size_t)(rows + kPadRows) * (W + kRowPad) * 5;
   hipLaunchKernelGGL(k, dim3((unsigned)N), dim3(64 * kZWaves), lds, s, sp, grad, argmin, J, H, W, gs, rows,
-                     log2_if_pow2(W / 4));
+                     log2_if_pow2(W / 4), g_tune.bwd_shares);
   return (int)hipGetLastError();
 }
 
@@ -108,6 +111,25 @@ extern "C" int shr_set_tuning(int key, int value) {
       if (value < 1 || value > 16) return SHR_EINVAL;
       g_tune.fwd_waves = value;
       return SHR_OK;
+    case SHR_TUNE_FWD_SHARES:
+    case SHR_TUNE_BWD_SHARES: {
+      // four bytes, oldest group first; normalised to sum 256 with every group >= 1
+      int b[4], sum = 0;
+      for (int g = 0; g < 4; g++) { b[g] = (value >> (8 * g)) & 255; sum += b[g]; }
+      if (sum == 0) return SHR_EINVAL;
+      int acc = 0, packed = 0;
+      for (int g = 0; g < 4; g++) {
+        int v = g == 3 ? 256 - acc : (b[g] * 256 + sum / 2) / sum;
+        if (v < 1) v = 1;
+        if (g < 3 && acc + v > 256 - (3 - g)) v = 256 - (3 - g) - acc;
+        if (v > 255) v = 255;
+        acc += v;
+        packed |= v << (8 * g);
+      }
+      if (acc != 256) return SHR_EINVAL;
+      (key == SHR_TUNE_FWD_SHARES ? g_tune.fwd_shares : g_tune.bwd_shares) = packed;
+      return SHR_OK;
+    }
     default: return SHR_EINVAL;
   }
 }

@@ -46,6 +46,7 @@ constexpr int kPatchW = 16;   // lanes along x
 constexpr int kPatchH = 4;    // lanes along y
 constexpr int kRowPad = 16;   // LDS row padding (elements): patches may overhang the image edge
 constexpr int kPadRows = kPatchH - 1;  // ... and the region's last row
+constexpr int kBgWaves = 7;   // forward: waves that store the background rows before the first barrier
 // LDS header: spheres [64] float4 | work items [64] int4 | ends [64] int | flags
 constexpr int kOffItems = 1024;
 constexpr int kOffEnds = 2048;
@@ -183,10 +184,10 @@ __device__ __forceinline__ float axis_coord_t(const Axis &a, int u);
 // are hoisted out of the row loop and dy*dy out of the column loop, so a patch costs
 // two subtractions and a compare before `body(j, s, ua, ub, v, qa, qb, has_b)` -- two
 // side-by-side patches per call, q = (r*r - dx*dx) - dy*dy in the reference's
-// association.  `end_sphere(j)` closes a run on sphere j.
-template <bool POW2, typename Body, typename EndSphere>
+// association.  `end_sphere(j)` closes a run on sphere j; `row_hook()` runs once per patch row.
+template <bool POW2, typename Body, typename EndSphere, typename RowHook>
 __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int hi, int lane, const Axis &ax,
-                                           const Axis &ay, Body &&body, EndSphere &&end_sphere) {
+                                           const Axis &ay, Body &&body, EndSphere &&end_sphere, RowHook &&row_hook) {
   const int lx = lane & (kPatchW - 1), ly = lane >> 4;
   int j = __popcll(__ballot(lane < J && w.end <= lo));   // prefixes are non-decreasing
   while (j < J) {
@@ -211,6 +212,7 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
         const int v = v0 + r * kPatchH;
         const float dy = axis_coord_t<POW2>(ay, v) - s.y;
         const float dy2 = dy * dy;
+        row_hook();
         // the first two columns go to the body together: two independent chains the
         // scheduler can interleave (a wave runs one dependent instruction stream)
         body(j, s, ua, ub, v, ca - dy2, cb - dy2, npx >= 2);
@@ -226,14 +228,31 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
   }
 }
 
-// wave w of nwaves takes the w-th equal slice of the total weight
-template <bool POW2, typename Body, typename EndSphere>
-__device__ __forceinline__ void walk_my_slice(const WaveList &w, int J, int total, int wave, int nwaves, int lane,
-                                              const Axis &ax, const Axis &ay, Body &&body, EndSphere &&end_sphere) {
+// Wave w of nwaves takes the w-th contiguous slice of the total weight.  The SIMD's issue
+// arbitration favours its oldest wave, so with equal slices the 16 waves of a workgroup
+// finish in a staircase (wave 0-3 first, 12-15 last: measured 6.3 k vs 10.3 k cycles);
+// `shares` gives the four age groups (waves 4g..4g+3) their part of the list, one byte per
+// group, oldest first, summing to 256 (the launcher normalises).  Other workgroup sizes
+// split equally.
+template <bool POW2, typename Body, typename EndSphere, typename RowHook>
+__device__ __forceinline__ void walk_my_slice(const WaveList &w, int J, int total, int wave, int nwaves, int shares,
+                                              int lane, const Axis &ax, const Axis &ay, Body &&body,
+                                              EndSphere &&end_sphere, RowHook &&row_hook) {
   wave = rfl(wave);   // everything that steers the loops is wave-uniform: keep it in SGPRs
   total = rfl(total);
-  const int lo = (int)(((long long)wave * total) / nwaves), hi = (int)(((long long)(wave + 1) * total) / nwaves);
-  if (lo < hi) walk_slice<POW2>(w, J, lo, hi, lane, ax, ay, body, end_sphere);
+  int lo, hi;
+  if (nwaves == kZWaves) {
+    const int g = wave >> 2, k = wave & 3;
+    const int s0 = shares & 255, s1 = (shares >> 8) & 255, s2 = (shares >> 16) & 255, s3 = (shares >> 24) & 255;
+    const int sg = g == 0 ? s0 : (g == 1 ? s1 : (g == 2 ? s2 : s3));
+    const int before = 4 * ((g > 0 ? s0 : 0) + (g > 1 ? s1 : 0) + (g > 2 ? s2 : 0)) + k * sg;   // of 1024
+    lo = (int)(((long long)total * before) >> 10);
+    hi = wave == kZWaves - 1 ? total : (int)(((long long)total * (before + sg)) >> 10);
+  } else {
+    lo = (int)(((long long)wave * total) / nwaves);
+    hi = (int)(((long long)(wave + 1) * total) / nwaves);
+  }
+  if (lo < hi) walk_slice<POW2>(w, J, lo, hi, lane, ax, ay, body, end_sphere, row_hook);
 }
 
 // image axis coordinate with the power-of-two case resolved at compile time
@@ -246,14 +265,39 @@ __device__ __forceinline__ float axis_coord_t(const Axis &a, int u) {
 template <bool OWNER> struct KeyOf { using type = uint32_t; };
 template <> struct KeyOf<true> { using type = unsigned long long; };
 
+// Rows of the region that some sphere's pixel box touches, [cv0, cv1] inclusive (cv1 < cv0:
+// none).  Every other row is background whatever the spheres' depths.  Evaluated with lanes =
+// spheres by any wave from its own copy of the records: same instructions on the same inputs,
+// so every wave of the workgroup gets the same answer without an LDS exchange.  A crop that
+// takes the general path reports the whole region (nothing is known to be background).
+__device__ __forceinline__ void touched_rows(const float4 s, bool valid, const Axis &ay, int r0, int r1, int &cv0,
+                                             int &cv1) {
+  const bool tame = sphere_is_tame(s);
+  const unsigned long long bad = __ballot(valid && !(tame && fabsf(s.z) < 1e30f));
+  const unsigned long long low = __ballot(valid && s.z <= kBackground);
+  int v0 = r0, v1 = r1 - 1;
+  if (tame) axis_box(s.y, fabsf(s.w), ay.size / 300.0f, ay.half, (float)r1 + 2.f, r0, r1 - 1, v0, v1);
+  const bool on = valid && v1 >= v0;   // row numbers are < 2^24: exact in fp32
+  cv0 = (int)wave_minmax_all<true>(on ? (float)v0 : 1e9f);
+  cv1 = (int)wave_minmax_all<false>(on ? (float)v1 : -1e9f);
+  if (cv1 < cv0) { cv0 = r1; cv1 = r0 - 1; }
+  if (bad != 0ull || low == 0ull) { cv0 = r0; cv1 = r1 - 1; }
+}
+
 // ---------------------------------------------------------------------------
 // Forward.  grid = (N, nregions), block = 64 * nwaves (<= 1024), dynamic LDS = kHdrBytes +
 // (rows_per_region + kPadRows) * (W + kRowPad) * sizeof(key).
+//
+// Schedule of one workgroup (in-kernel clock64, batch 256 = one crop per CU): the sphere
+// read takes ~2 k cycles to arrive and wave 0 needs ~1.5 k more for the work list; the
+// other waves fill that time with the z-buffer initialisation and then with the
+// BACKGROUND ROWS: rows no sphere's box touches (half of a hand crop) are stored straight
+// from registers before the first barrier and never pass through LDS or the decode.
 template <bool OWNER, bool VEC4, bool POW2>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
                        float *__restrict__ depth, uint8_t *__restrict__ argmin, int rows_per_region,
-                       int w4_shift) {
+                       int w4_shift, int shares) {
   using Key = typename KeyOf<OWNER>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
@@ -271,24 +315,13 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
   const int LW = W + kRowPad;
   const Axis ax = make_axis(W), ay = make_axis(H);
 
-  if (wave == 0) {
-    const bool valid = lane < J;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) s = spheres[(size_t)n * J + lane];
-    s_sph[lane] = s;
-    // general path unless every sphere is tame and at least one has z <= 100: a pixel's
-    // minimum can exceed the background only where ALL J spheres hit it, and there the
-    // sphere with z <= 100 contributes z - sqrt(q) < 100, so min(100, hits) is exact.
-    const unsigned long long bad = __ballot(valid && !(sphere_is_tame(s) && fabsf(s.z) < 1e30f));
-    const unsigned long long low = __ballot(valid && s.z <= kBackground);
-    bool too_big;
-    const int total = build_work_list(s, valid, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
-    if (lane == 0) {
-      s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
-      s_flag[1] = total;
-    }
-  }
-  {  // background everywhere (pad rows/columns included)
+  // every wave keeps the crop's records in registers, lane j = sphere j (one 656-byte line
+  // set, served to the later waves by the L2)
+  const bool valid = lane < J;
+  float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) sph = spheres[(size_t)n * J + lane];
+
+  {  // background everywhere (pad rows/columns included); overlaps the read above
     const Key bg = OWNER ? (Key)(((unsigned long long)depth_key(kBackground) << 32) | SHR_ARGMIN_NONE)
                          : (Key)depth_key(kBackground);
     constexpr int per16 = 16 / sizeof(Key);
@@ -303,26 +336,101 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
     }
     for (int i = nvec * per16 + tid; i < ncell; i += nthr) zbuf[i] = bg;
   }
-  __syncthreads();
+
+  const int wave_s = rfl(wave);
+  const bool list_wave = wave_s == 0;
+  int cv0 = r0, cv1 = r1 - 1;
+  // Waves 1..kBgWaves store the background rows while wave 0 builds the list: they are the
+  // first to finish the z-buffer initialisation (the SIMD arbitration favours old waves) and
+  // a wave issues a wave-wide store every ~55 cycles, so ~6 stores apiece fit in wave 0's
+  // shadow.  The other waves learn the touched rows after the barrier.
+  const int nbgw = min(kBgWaves, nwaves - 1);
+  const bool bg_wave = nwaves == 1 || (wave_s >= 1 && wave_s <= nbgw);
+
+  if (list_wave) {
+    s_sph[lane] = sph;
+    // general path unless every sphere is tame and at least one has z <= 100: a pixel's
+    // minimum can exceed the background only where ALL J spheres hit it, and there the
+    // sphere with z <= 100 contributes z - sqrt(q) < 100, so min(100, hits) is exact.
+    const unsigned long long bad = __ballot(valid && !(sphere_is_tame(sph) && fabsf(sph.z) < 1e30f));
+    const unsigned long long low = __ballot(valid && sph.z <= kBackground);
+    bool too_big;   // excluded by the launcher (W <= kMaxFastWidth, H <= 32768)
+    const int total = build_work_list(sph, valid, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
+    if (lane == 0) {
+      s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
+      s_flag[1] = total;
+    }
+  }
 
   float *out = depth + (size_t)n * H * W;
   uint8_t *aout = OWNER ? argmin + (size_t)n * H * W : nullptr;
 
+  // The region is streamed in UNITS of 64 consecutive 16-byte chunks (a wave-wide store =
+  // whole rows or a row segment); whether a unit lies in background rows is a scalar test.
+  const int w4 = W >> 2;
+  const int nchunk = rh * w4;
+  const int nunits = (nchunk + 63) >> 6;
+  float4 *out4 = reinterpret_cast<float4 *>(out + (size_t)r0 * W);
+  uchar4 *aout4 = OWNER ? reinterpret_cast<uchar4 *>(aout + (size_t)r0 * W) : nullptr;
+  // units [0, ua) and [ub, nunits) lie entirely in background rows, [ua, ub) is touched
+  int ua = 0, ub = nunits;
+  if (VEC4 && bg_wave) {
+    touched_rows(sph, valid, ay, r0, r1, cv0, cv1);
+    if (cv1 < cv0) ua = ub = nunits;
+    else { ua = ((cv0 - r0) * w4) >> 6; ub = min(nunits, ((cv1 - r0 + 1) * w4 + 63) >> 6); }
+    ua = rfl(ua);
+    ub = rfl(ub);
+    if (wave_s == (nwaves == 1 ? 0 : 1) && lane == 0) { s_flag[2] = ua; s_flag[3] = ub; }   // for the other waves
+  }
+  // ---- background rows: stored by the waves that wait for the work list ---------------
+  const float4 bgd = make_float4(kBackground, kBackground, kBackground, kBackground);
+  const uchar4 bga = make_uchar4(SHR_ARGMIN_NONE, SHR_ARGMIN_NONE, SHR_ARGMIN_NONE, SHR_ARGMIN_NONE);
+  // owner bytes go out 16 at a time when rows allow it (a wave-wide store of 4-byte pieces
+  // occupies the write queue like a 16-byte one and carries a quarter of the data)
+  const bool own16 = OWNER && (W & 15) == 0 && is_aligned16(argmin);
+  auto store_background = [&](int first, int step) {
+    const int nbg = ua + (nunits - ub);
+    for (int t = first; t < nbg; t += step) {
+      const int u = t < ua ? t : t - ua + ub;
+      const int c = (u << 6) + lane;
+      if (c < nchunk) {
+        out4[c] = bgd;
+        if (OWNER && !own16) aout4[c] = bga;
+      }
+    }
+    if (own16) {   // 16-pixel pieces: unit u = pieces [16u, 16u + 16)
+      const int npiece = nchunk >> 2, pa = ua << 4, pb = ub << 4;
+      const int nbgp = min(pa, npiece) + max(npiece - pb, 0);
+      const uint4 bg16 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      static_assert(SHR_ARGMIN_NONE == 255, "background owner bytes");
+      uint4 *aout16 = reinterpret_cast<uint4 *>(aout + (size_t)r0 * W);
+      for (int t = first * 64 + lane; t < nbgp; t += step * 64) {
+        const int pc = t < pa ? t : t - pa + pb;
+        aout16[pc] = bg16;
+      }
+    }
+  };
+  if (VEC4 && bg_wave) store_background(nwaves == 1 ? 0 : wave_s - 1, nwaves == 1 ? 1 : nbgw);
+  __syncthreads();
+
   if (s_flag[0]) {  // workgroup-uniform: this crop needs the general path
     const int tiles_x = (W + kTileW - 1) / kTileW;
     const int t0 = (r0 / kTileH) * tiles_x, t1 = ((r1 + kTileH - 1) / kTileH) * tiles_x;
-    const float4 sph = lane < J ? s_sph[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     tile_forward<VEC4, OWNER>(sph, J, H, W, out, aout, tiles_x, t0 + wave, t1, nwaves, lane);
     return;
   }
+  if (VEC4) { ua = rfl(s_flag[2]); ub = rfl(s_flag[3]); }
 
   // ---- scan-convert the patch list -------------------------------------------------
   // A patch may overhang the box, the image's right edge or the region's last row:
   // the hit test is exact for ANY pixel, overhanging lanes land in LDS padding.
   {
-    const WaveList wl = load_wave_list(s_sph, s_items, s_ends, lane);
+    WaveList wl;
+    wl.sph = sph;
+    wl.item = s_items[lane];
+    wl.end = s_ends[lane];
     walk_my_slice<POW2>(
-        wl, J, s_flag[1], wave, nwaves, lane, ax, ay,
+        wl, J, s_flag[1], wave, nwaves, shares, lane, ax, ay,
         [&](int j, const float4 s, int ua, int ub, int v, float qa, float qb, bool has_b) {
           Key *row = zbuf + (v - r0) * LW;
           auto put = [&](Key *cell, float d) {
@@ -342,32 +450,31 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
             put(row + ua, s.z - sqrt_rn(qa));
           }
         },
-        [](int) {});
+        [](int) {}, []() {});
   }
   __syncthreads();
 
-  // ---- stream the region out ---------------------------------------------------------
+  // ---- stream the touched rows out ---------------------------------------------------
   if (VEC4) {
-    const int w4 = W >> 2;
-    const int nchunk = rh * w4;
-    for (int c = tid; c < nchunk; c += nthr) {
-      int v, u;
-      if (w4_shift >= 0) { v = c >> w4_shift; u = (c & (w4 - 1)) << 2; }
-      else { v = c / w4; u = (c - v * w4) << 2; }
-      const Key *cell = zbuf + v * LW + u;
+    for (int u = ua + wave_s; u < ub; u += nwaves) {
+      const int c = (u << 6) + lane;
+      if (c >= nchunk) continue;
+      int v, x;
+      if (POW2 || w4_shift >= 0) { v = c >> w4_shift; x = (c & (w4 - 1)) << 2; }
+      else { v = c / w4; x = (c - v * w4) << 2; }
+      const Key *cell = zbuf + v * LW + x;
       float4 o;
       if (OWNER) {
         const ulonglong2 k01 = reinterpret_cast<const ulonglong2 *>(cell)[0];
         const ulonglong2 k23 = reinterpret_cast<const ulonglong2 *>(cell)[1];
         o = make_float4(key_depth((uint32_t)(k01.x >> 32)), key_depth((uint32_t)(k01.y >> 32)),
                         key_depth((uint32_t)(k23.x >> 32)), key_depth((uint32_t)(k23.y >> 32)));
-        *reinterpret_cast<uchar4 *>(aout + (size_t)(r0 + v) * W + u) =
-            make_uchar4((uint8_t)k01.x, (uint8_t)k01.y, (uint8_t)k23.x, (uint8_t)k23.y);
+        aout4[c] = make_uchar4((uint8_t)k01.x, (uint8_t)k01.y, (uint8_t)k23.x, (uint8_t)k23.y);
       } else {
         const uint4 k = *reinterpret_cast<const uint4 *>(cell);
         o = make_float4(key_depth(k.x), key_depth(k.y), key_depth(k.z), key_depth(k.w));
       }
-      *reinterpret_cast<float4 *>(out + (size_t)(r0 + v) * W + u) = o;
+      out4[c] = o;
     }
   } else {
     for (int p = tid; p < rh * W; p += nthr) {
@@ -388,12 +495,14 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
 // kHdrBytes + 16*64*16 (wave x sphere partial sums) + (rows + kPadRows) * (W +
 // kRowPad) * (4 + 1).
 constexpr int kPartBytes = kZWaves * SHR_MAX_SPHERES * 16;
+constexpr int kStageBatch = 4;   // backward: units (16-byte chunks per lane) requested per wait while staging
+constexpr int kSpecUnits = 2;    // ... and units per wave requested before the touched rows are known
 
 template <bool VEC4, bool POW2>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restrict__ grad_depth,
                        const uint8_t *__restrict__ argmin, int J, int H, int W,
-                       float4 *__restrict__ grad_spheres, int rows_per_region, int w4_shift) {
+                       float4 *__restrict__ grad_spheres, int rows_per_region, int w4_shift, int shares) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
   int4 *s_items = reinterpret_cast<int4 *>(smem + kOffItems);
@@ -409,34 +518,129 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   const float *gin = grad_depth + (size_t)n * H * W;
   const uint8_t *oin = argmin + (size_t)n * H * W;
   const Axis ax = make_axis(W), ay = make_axis(H);
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int wave_s = rfl(wave);
+  // Every wave requests the crop's records (lane j = sphere j) with an explicit instruction so
+  // that the staging requests below can be queued behind it and awaited separately.
+  const float4 *rec = spheres + (size_t)n * J;
+  v4f sphv;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sphv) : "v"(rec + min(lane, J - 1)));
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (wave == 0) {
-    if (lane < J) sph = spheres[(size_t)n * J + lane];
-    s_sph[lane] = sph;
-  }
+  bool have_sph = false;
   s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // 1024 = 16 waves x 64 spheres
 
   for (int r0 = 0; r0 < H; r0 += rows_per_region) {
     const int r1 = min(H, r0 + rows_per_region), rh = r1 - r0;
     if (r0 > 0) __syncthreads();  // the previous region's walk is done
-    if (wave == 0) {
-      bool too_big;   // excluded by the launcher (W <= kMaxFastWidth)
-      const int total = build_work_list(sph, lane < J, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
-      if (lane == 0) s_flag[1] = total;
+
+    // ---- stage grad_depth + owner map --------------------------------------------------
+    // Reading is the bandwidth-bound part (82 KB per 128x128 crop arrive in ~8 k cycles when
+    // all CUs read), and only the rows some sphere's box touches are ever looked at (half of
+    // a hand crop).  Those rows are known once the records have arrived, so the staging is
+    // split: the central half of the region is requested at once, speculatively, together
+    // with the records; what the touched rows need beyond it is requested when the records
+    // are in.  Units = 64 consecutive 16-byte chunks, unit u belongs to wave u mod 16.
+    const int w4 = W >> 2;
+    const int nchunk = rh * w4;
+    const int nunits = (nchunk + 63) >> 6;
+    const float4 *gin4 = reinterpret_cast<const float4 *>(gin + (size_t)r0 * W);
+    const uchar4 *oin4 = reinterpret_cast<const uchar4 *>(oin + (size_t)r0 * W);
+    const int uc0 = nunits >> 2, uc1 = nunits - uc0;          // central units
+    const int k1 = (max(uc0 - wave_s, 0) + kZWaves - 1) >> 4;  // this wave's first central unit is wave + 16 k1
+    v4f g1[kSpecUnits];
+    uint32_t o1[kSpecUnits];
+    auto put_unit = [&](int u, const v4f g, uint32_t o) {
+      const int c = (u << 6) + lane;
+      if (c < nchunk) {
+        int v, x;
+        if (POW2 || w4_shift >= 0) { v = c >> w4_shift; x = (c & (w4 - 1)) << 2; }
+        else { v = c / w4; x = (c - v * w4) << 2; }
+        *reinterpret_cast<v4f *>(gbuf + v * LW + x) = g;
+        *reinterpret_cast<uint32_t *>(obuf + v * LW + x) = o;
+      }
+    };
+    if (VEC4) {
+#pragma unroll
+      for (int b = 0; b < kSpecUnits; b++) {
+        // (an absent unit re-reads the records: the count of requests in flight stays fixed)
+        const int u = wave_s + ((k1 + b) << 4);
+        const int c = min((u << 6) + lane, nchunk - 1);
+        const void *pg = u < uc1 ? static_cast<const void *>(gin4 + c) : static_cast<const void *>(rec);
+        const void *po = u < uc1 ? static_cast<const void *>(oin4 + c) : static_cast<const void *>(rec);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(g1[b]) : "v"(pg));
+        asm volatile("global_load_dword %0, %1, off" : "=v"(o1[b]) : "v"(po));
+      }
     }
     // owner padding = "nobody": the walk may overhang the image edge / region end
     for (int i = tid; i < rh * kRowPad; i += 1024) obuf[(i / kRowPad) * LW + W + (i % kRowPad)] = SHR_ARGMIN_NONE;
     for (int i = tid; i < kPadRows * LW; i += 1024) obuf[rh * LW + i] = SHR_ARGMIN_NONE;
+    if (!have_sph) {
+      if (VEC4) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(sphv) : "n"(2 * kSpecUnits) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(sphv) : : "memory");
+      if (lane < J) sph = make_float4(sphv.x, sphv.y, sphv.z, sphv.w);
+      have_sph = true;
+      if (wave_s == 0) s_sph[lane] = sph;
+    }
+    if (wave_s == 0) {
+      bool too_big;   // excluded by the launcher (W <= kMaxFastWidth)
+      const int total = build_work_list(sph, lane < J, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
+      if (lane == 0) s_flag[1] = total;
+    }
     if (VEC4) {
-      const int w4 = W >> 2;
-      const int nchunk = rh * w4;
-      for (int c = tid; c < nchunk; c += 1024) {
-        int v, u;
-        if (w4_shift >= 0) { v = c >> w4_shift; u = (c & (w4 - 1)) << 2; }
-        else { v = c / w4; u = (c - v * w4) << 2; }
-        const size_t src = (size_t)(r0 + v) * W + u;
-        *reinterpret_cast<float4 *>(gbuf + v * LW + u) = *reinterpret_cast<const float4 *>(gin + src);
-        *reinterpret_cast<uchar4 *>(obuf + v * LW + u) = *reinterpret_cast<const uchar4 *>(oin + src);
+      int cv0, cv1;
+      touched_rows(sph, lane < J, ay, r0, r1, cv0, cv1);
+      // a patch row may overhang its sphere's box by kPadRows rows: those owners are read too
+      int ua = nunits, ub = nunits;
+      if (cv1 >= cv0) { ua = ((cv0 - r0) * w4) >> 6; ub = min(nunits, ((min(cv1 + kPadRows, r1 - 1) - r0 + 1) * w4 + 63) >> 6); }
+      ua = rfl(ua);
+      ub = rfl(ub);
+      bool spec_stored = false;
+      for (int k = (max(ua - wave_s, 0) + kZWaves - 1) >> 4; wave_s + (k << 4) < ub; k += kStageBatch) {
+        // The requests and their wait are ONE asm statement: the compiler treats an asm
+        // result as available at once and may copy it before a separate wait.  A slot
+        // without a unit re-reads the records (no control flow around the statement).
+        static_assert(kStageBatch == 4, "the staging statement below names four slots");
+        v4f g2[kStageBatch];
+        uint32_t o2[kStageBatch];
+        bool ok[kStageBatch];
+        const void *pg[kStageBatch], *po[kStageBatch];
+#pragma unroll
+        for (int b = 0; b < kStageBatch; b++) {
+          const int kk = k + b, u = wave_s + (kk << 4);
+          ok[b] = u < ub && !(kk >= k1 && kk < k1 + kSpecUnits && u < uc1);   // wave-uniform
+          const int c = min((u << 6) + lane, nchunk - 1);
+          pg[b] = ok[b] ? static_cast<const void *>(gin4 + c) : static_cast<const void *>(rec);
+          po[b] = ok[b] ? static_cast<const void *>(oin4 + c) : static_cast<const void *>(rec);
+        }
+        asm volatile(
+            "global_load_dwordx4 %0, %8, off\n\tglobal_load_dword %4, %12, off\n\t"
+            "global_load_dwordx4 %1, %9, off\n\tglobal_load_dword %5, %13, off\n\t"
+            "global_load_dwordx4 %2, %10, off\n\tglobal_load_dword %6, %14, off\n\t"
+            "global_load_dwordx4 %3, %11, off\n\tglobal_load_dword %7, %15, off\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(g2[0]), "=&v"(g2[1]), "=&v"(g2[2]), "=&v"(g2[3]), "=&v"(o2[0]), "=&v"(o2[1]), "=&v"(o2[2]),
+              "=&v"(o2[3])
+            : "v"(pg[0]), "v"(pg[1]), "v"(pg[2]), "v"(pg[3]), "v"(po[0]), "v"(po[1]), "v"(po[2]), "v"(po[3])
+            : "memory");
+        if (!spec_stored) {
+#pragma unroll
+          for (int b = 0; b < kSpecUnits; b++) {
+            const int u = wave_s + ((k1 + b) << 4);
+            if (u < uc1) put_unit(u, g1[b], o1[b]);
+          }
+          spec_stored = true;
+        }
+#pragma unroll
+        for (int b = 0; b < kStageBatch; b++)
+          if (ok[b]) put_unit(wave_s + ((k + b) << 4), g2[b], o2[b]);
+      }
+      if (!spec_stored) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int b = 0; b < kSpecUnits; b++) {
+          const int u = wave_s + ((k1 + b) << 4);
+          if (u < uc1) put_unit(u, g1[b], o1[b]);
+        }
       }
     } else {
       for (int p = tid; p < rh * W; p += 1024) {
@@ -454,7 +658,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const WaveList wl = load_wave_list(s_sph, s_items, s_ends, lane);
     walk_my_slice<POW2>(
-        wl, J, s_flag[1], wave, kZWaves, lane, ax, ay,
+        wl, J, s_flag[1], wave, kZWaves, shares, lane, ax, ay,
         [&](int j, const float4 s, int ua, int ub, int v, float qa, float qb, bool has_b) {
           const int row = (v - r0) * LW;
           auto take = [&](int u, float q) {
@@ -481,7 +685,8 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
             s_part[wave * SHR_MAX_SPHERES + j] = t;
           }
           a0 = a1 = a2 = a3 = 0.f;
-        });
+        },
+        []() {});
   }
   __syncthreads();
   // combine the waves' partials in wave order; d/dr = r * sum(-g/sqrt(q))
