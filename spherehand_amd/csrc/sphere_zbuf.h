@@ -262,6 +262,24 @@ __device__ __forceinline__ float axis_coord_t(const Axis &a, int u) {
   return POW2 ? t * a.mul : (t * 300.0f) / a.size;
 }
 
+// Streaming stores (no reuse on this GPU: the depth map is read next by another kernel,
+// possibly on another XCD): written through instead of left dirty in the L2 for the
+// end-of-kernel write-back.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_store(float4 *p, const float4 v) {
+  v4f_t t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<v4f_t *>(p));
+}
+__device__ __forceinline__ void stream_store(uint4 *p, const uint4 v) {
+  v4u_t t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<v4u_t *>(p));
+}
+__device__ __forceinline__ void stream_store(uchar4 *p, const uchar4 v) {
+  const uint32_t t = (uint32_t)v.x | ((uint32_t)v.y << 8) | ((uint32_t)v.z << 16) | ((uint32_t)v.w << 24);
+  __builtin_nontemporal_store(t, reinterpret_cast<uint32_t *>(p));
+}
+
 template <bool OWNER> struct KeyOf { using type = uint32_t; };
 template <> struct KeyOf<true> { using type = unsigned long long; };
 
@@ -394,8 +412,8 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
       const int u = t < ua ? t : t - ua + ub;
       const int c = (u << 6) + lane;
       if (c < nchunk) {
-        out4[c] = bgd;
-        if (OWNER && !own16) aout4[c] = bga;
+        stream_store(out4 + c, bgd);
+        if (OWNER && !own16) stream_store(aout4 + c, bga);
       }
     }
     if (own16) {   // 16-pixel pieces: unit u = pieces [16u, 16u + 16)
@@ -406,7 +424,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
       uint4 *aout16 = reinterpret_cast<uint4 *>(aout + (size_t)r0 * W);
       for (int t = first * 64 + lane; t < nbgp; t += step * 64) {
         const int pc = t < pa ? t : t - pa + pb;
-        aout16[pc] = bg16;
+        stream_store(aout16 + pc, bg16);
       }
     }
   };
@@ -469,12 +487,12 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
         const ulonglong2 k23 = reinterpret_cast<const ulonglong2 *>(cell)[1];
         o = make_float4(key_depth((uint32_t)(k01.x >> 32)), key_depth((uint32_t)(k01.y >> 32)),
                         key_depth((uint32_t)(k23.x >> 32)), key_depth((uint32_t)(k23.y >> 32)));
-        aout4[c] = make_uchar4((uint8_t)k01.x, (uint8_t)k01.y, (uint8_t)k23.x, (uint8_t)k23.y);
+        stream_store(aout4 + c, make_uchar4((uint8_t)k01.x, (uint8_t)k01.y, (uint8_t)k23.x, (uint8_t)k23.y));
       } else {
         const uint4 k = *reinterpret_cast<const uint4 *>(cell);
         o = make_float4(key_depth(k.x), key_depth(k.y), key_depth(k.z), key_depth(k.w));
       }
-      out4[c] = o;
+      stream_store(out4 + c, o);
     }
   } else {
     for (int p = tid; p < rh * W; p += nthr) {
