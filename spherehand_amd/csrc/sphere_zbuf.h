@@ -82,15 +82,21 @@ __device__ __forceinline__ bool sphere_is_tame(const float4 s) {
   return fabsf(s.x) < 1e6f && fabsf(s.y) < 1e6f && fabsf(s.w) < 1e6f;  // false for NaN/Inf
 }
 
-// One work item = one sphere's pixel box clipped to the region, as a grid of
-// 16x4-pixel patches.  A hit needs |fl(xg - x)| <= |r| (sphere_tile.h), i.e. the
-// pixel centre inside [x - |r|, x + |r|] up to one rounding.  With
-// xg(u) = (u - half)*300/size  <=>  u = xg*size/300 + half the box is
+// One work item = one sphere's pixel box clipped to the region.  A hit needs
+// |fl(xg - x)| <= |r| (sphere_tile.h), i.e. the pixel centre inside [x - |r|, x + |r|] up
+// to one rounding.  With xg(u) = (u - half)*300/size  <=>  u = xg*size/300 + half the box is
 //   u in [ceil(ulo - eps), floor(uhi + eps)],
 // eps = 1e-3 px + 2e-6 relative: >> the fp32 error of the inverse map (<= 1e-5 px
 // near the image, 6e-8 relative far away), << a pixel, so the box is the tight
 // conservative one.  Non-tame spheres (NaN/Inf/huge) take the whole region.
-struct Item { int u0, v0, npx, npy; };
+//
+// The box is visited in CHUNKS of 64 lanes packed row-major over its own width:
+// pw = min(width, 64) lanes per row, ph = 64 / pw rows per chunk (a 12-px-wide finger
+// sphere: 5 rows x 12 = 60 busy lanes; a 19-px palm sphere: 3 x 19 = 57), ncx =
+// ceil(width / 64) column segments for boxes wider than a wave.  Fixed 16x4 patches
+// left 43 % of the box lanes idle on hand crops (230 patch visits per crop against
+// 172 chunks) and paid a row loop on top.
+struct Item { int u0, v0, u1, v1, pw, ph, ncx, nchunks; };
 
 __device__ __forceinline__ void axis_box(float c, float ar, float k, float half, float hi_clamp, int lo_lim,
                                          int hi_lim, int &i0, int &i1) {
@@ -109,10 +115,19 @@ __device__ __forceinline__ Item sphere_item(const float4 s, const Axis &ax, cons
     axis_box(s.y, ar, ay.size / 300.0f, ay.half, (float)r1 + 2.f, r0, r1 - 1, v0, v1);
   }
   Item it;
-  it.u0 = u0;
-  it.v0 = v0;
-  it.npx = (u1 >= u0) ? ((u1 - u0) / kPatchW + 1) : 0;
-  it.npy = (v1 >= v0) ? ((v1 - v0) / kPatchH + 1) : 0;
+  it.u0 = u0; it.v0 = v0; it.u1 = u1; it.v1 = v1;
+  const int w = u1 - u0 + 1, h = v1 - v0 + 1;
+  if (w <= 0 || h <= 0) {
+    it.pw = 1; it.ph = 1; it.ncx = 0; it.nchunks = 0;
+  } else {
+    // (small integer quotients through fp32: the exact quotient is never within 1/128 of
+    // the wrong integer, the division error is 2^-24 relative)
+    it.pw = min(w, kWave);
+    it.ph = (int)(64.0f / (float)it.pw);
+    it.ncx = w > kWave ? (w + kWave - 1) >> 6 : 1;
+    const int ngr = (int)(((float)(h + it.ph - 1) + 0.5f) / (float)it.ph);
+    it.nchunks = ngr * it.ncx;
+  }
   return it;
 }
 
@@ -122,26 +137,26 @@ __device__ __forceinline__ float rfl(float v) {
 }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-// The work list is a sequence of PATCH ROWS (npx patches side by side), sphere after
-// sphere, each row weighted by its estimated cost (row overhead + per-patch work) so
-// that equal slices of the cumulative weight are equal work.
-// Measured on MI355X (in-kernel clock64, one crop per CU): starting a sphere ~1300
-// cycles (broadcasts, column terms), a patch row ~350, each patch ~150.
-constexpr int kSphereCost = 26;
-constexpr int kRowCost = 7;
-constexpr int kPatchCost = 3;
+// The work list is the sequence of chunks, sphere after sphere, on a weight axis where a
+// chunk is 2^kChunkShift long and starting a sphere (broadcasts, lane layout, column terms)
+// kSphereCost: equal slices of the axis are equal work.
+constexpr int kChunkShift = 3;
+constexpr int kChunkCost = 1 << kChunkShift;
+constexpr int kSphereCostFwd = 20;
+constexpr int kSphereCostBwd = 36;   // ... plus four wave reductions when a run on a sphere ends
 
-// Wave 0: build the list in LDS.  s_items[j] = (u0 | v0<<16, npx | nrows<<16, row
-// weight, weight prefix before sphere j); s_ends[j] = prefix after it; a sphere weighs
-// kSphereCost + nrows * row weight.  Returns the total weight (valid in every lane of
-// wave 0).
+// Wave 0: build the list in LDS.  s_items[j] = (u0 | v0<<16, v1 | ph<<16, pw | ncx<<8 |
+// u1<<16, weight prefix before sphere j); s_ends[j] = prefix after it; a sphere weighs
+// kSphereCost + nchunks * kChunkCost (nothing when it touches no pixel).  Returns the total
+// weight (valid in every lane of wave 0).  Field widths: the launcher keeps W <= 8192 and
+// H <= 32768.
+template <int kSphereCost>
 __device__ __forceinline__ int build_work_list(const float4 s, bool valid, const Axis &ax, const Axis &ay,
                                                int W, int r0, int r1, int4 *s_items, int *s_ends, int lane,
                                                bool *too_big) {
   const Item it = sphere_item(s, ax, ay, W, r0, r1);
-  const int nrows = (valid && it.npx > 0) ? it.npy : 0;
-  const int wt = kRowCost + kPatchCost * it.npx;
-  const int cost = nrows > 0 ? kSphereCost + nrows * wt : 0;
+  const int nchunks = valid ? it.nchunks : 0;
+  const int cost = nchunks > 0 ? kSphereCost + nchunks * kChunkCost : 0;
   // inclusive scan over the 64 lanes: 4 DPP steps inside each row of 16, then the
   // three row totals are added with SGPR broadcasts
   int incl = cost;
@@ -152,10 +167,11 @@ __device__ __forceinline__ int build_work_list(const float4 s, bool valid, const
   const int r0s = rl(incl, 15), r1s = rl(incl, 31), r2s = rl(incl, 47);
   const int row = lane >> 4;
   incl += (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
-  s_items[lane] = make_int4(it.u0 | (it.v0 << 16), it.npx | (nrows << 16), wt, incl - cost);
+  s_items[lane] = make_int4(it.u0 | (it.v0 << 16), (it.v1 & 0xffff) | (it.ph << 16),
+                            it.pw | (it.ncx << 8) | ((it.u1 & 0xffff) << 16), incl - cost);
   s_ends[lane] = incl;
-  // fields are 16-bit; the launcher keeps W <= kMaxFastWidth, H <= 32768
-  *too_big = __ballot(valid && (it.u0 > 65535 || it.v0 > 65535 || it.npx > 65535 || nrows > 32767)) != 0ull;
+  *too_big = __ballot(valid && nchunks > 0 && (it.ncx > 255 || it.u1 > 65535 || it.v1 > 65535 ||
+                                               nchunks > (1 << 24))) != 0ull;
   return rl(incl, 63);
 }
 
@@ -179,47 +195,64 @@ __device__ __forceinline__ WaveList load_wave_list(const float4 *s_sph, const in
 template <bool POW2>
 __device__ __forceinline__ float axis_coord_t(const Axis &a, int u);
 
-// Walk the patch rows whose weight position lies in [lo, hi) (wave-uniform), sphere by
-// sphere.  Per sphere the column terms c = r*r - dx*dx of the first two patch columns
-// are hoisted out of the row loop and dy*dy out of the column loop, so a patch costs
-// two subtractions and a compare before `body(j, s, ua, ub, v, qa, qb, has_b)` -- two
-// side-by-side patches per call, q = (r*r - dx*dx) - dy*dy in the reference's
-// association.  `end_sphere(j)` closes a run on sphere j; `row_hook()` runs once per patch row.
-template <bool POW2, typename Body, typename EndSphere, typename RowHook>
+// Walk the chunks whose weight position lies in [lo, hi) (wave-uniform), sphere by
+// sphere.  Per sphere the lane layout (lx, ly) and the column term c = r*r - dx*dx are
+// set up once; a chunk then costs its row coordinate, dy*dy and one subtraction before
+// `body(j, s, cell_a, cell_b, dx, dy_a, dy_b, q_a, q_b, has_b)` -- two consecutive chunks
+// per call (independent dependency chains), q = (r*r - dx*dx) - dy*dy in the reference's
+// association, cell = (v - r0) * LW + u the pixel's index in the region's LDS arrays.
+// Lanes that have no pixel in a chunk (beyond the last row, the packing remainder, or
+// past the box's right edge in a column segment) get q = -1: no hit.  `end_sphere(j)`
+// closes a run on sphere j.
+template <bool POW2, int kSphereCost, typename Body, typename EndSphere>
 __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int hi, int lane, const Axis &ax,
-                                           const Axis &ay, Body &&body, EndSphere &&end_sphere, RowHook &&row_hook) {
-  const int lx = lane & (kPatchW - 1), ly = lane >> 4;
+                                           const Axis &ay, int r0, int LW, Body &&body, EndSphere &&end_sphere) {
+  const float lane_mid = (float)lane + 0.5f;
   int j = __popcll(__ballot(lane < J && w.end <= lo));   // prefixes are non-decreasing
   while (j < J) {
     const int wstart = rl(w.item.w, j);
     if (wstart >= hi) break;
-    const int shape = rl(w.item.y, j), wt = rl(w.item.z, j);
-    const int npx = shape & 0xffff, nrows = shape >> 16;
-    // first row whose position wstart + kSphereCost + r*wt is at or after lo (a few
-    // scalar steps; an integer division would cost more than the rows it skips)
-    int r = 0, p = wstart + kSphereCost;
-    while (p < lo && r < nrows) { ++r; p += wt; }
-    if (r < nrows && p < hi) {
-      const int geom = rl(w.item.x, j);
+    const int wend = rl(w.end, j);
+    const int base = wstart + kSphereCost;
+    // chunk c sits at base + c * kChunkCost and belongs to the slice that holds that position
+    int c = lo <= base ? 0 : (lo - base + kChunkCost - 1) >> kChunkShift;
+    const int c_end = min((wend - base) >> kChunkShift, (hi - base + kChunkCost - 1) >> kChunkShift);
+    if (wend > wstart && c < c_end) {
+      const int geom = rl(w.item.x, j), rows = rl(w.item.y, j), cols = rl(w.item.z, j);
       const float4 s = make_float4(readlane_f(w.sph.x, j), readlane_f(w.sph.y, j), readlane_f(w.sph.z, j),
                                    readlane_f(w.sph.w, j));
+      const int u0 = geom & 0xffff, v0 = (int)((unsigned)geom >> 16);
+      const int v1 = rows & 0xffff, ph = rows >> 16;
+      const int pw = cols & 0xff, ncx = (cols >> 8) & 0xff, u1 = (int)((unsigned)cols >> 16);
       const float rr = s.w * s.w;
-      const int ua = (geom & 0xffff) + lx, ub = ua + kPatchW;
-      const int v0 = (int)((unsigned)geom >> 16) + ly;
-      const float dxa = axis_coord_t<POW2>(ax, ua) - s.x, dxb = axis_coord_t<POW2>(ax, ub) - s.x;
-      const float ca = rr - dxa * dxa, cb = rr - dxb * dxb;
-      for (; r < nrows && p < hi; ++r, p += wt) {
-        const int v = v0 + r * kPatchH;
-        const float dy = axis_coord_t<POW2>(ay, v) - s.y;
-        const float dy2 = dy * dy;
-        row_hook();
-        // the first two columns go to the body together: two independent chains the
-        // scheduler can interleave (a wave runs one dependent instruction stream)
-        body(j, s, ua, ub, v, ca - dy2, cb - dy2, npx >= 2);
-        for (int px = 2; px < npx; px += 2) {
-          const int u = ua + px * kPatchW;
-          const float dx0 = axis_coord_t<POW2>(ax, u) - s.x, dx1 = axis_coord_t<POW2>(ax, u + kPatchW) - s.x;
-          body(j, s, u, u + kPatchW, v, (rr - dx0 * dx0) - dy2, (rr - dx1 * dx1) - dy2, px + 1 < npx);
+      // lane -> (lx, ly) inside a chunk: ly = lane / pw through fp32 ((lane + 1/2) / pw is
+      // at least 1/128 away from an integer, v_rcp_f32 is good to 1 ulp)
+      const int ly = (int)(lane_mid * __builtin_amdgcn_rcpf((float)pw));
+      const int lx = lane - ly * pw;
+      const bool packed = ly < ph;
+      if (ncx == 1) {
+        const int u = u0 + lx;
+        const float dx = axis_coord_t<POW2>(ax, u) - s.x;
+        const float ca = rr - dx * dx;
+        int v = v0 + c * ph + ly;
+        int cell = (v - r0) * LW + u;
+        const int dcell = ph * LW;
+        for (; c < c_end; c += 2, v += 2 * ph, cell += 2 * dcell) {
+          const float dya = axis_coord_t<POW2>(ay, v) - s.y, dyb = axis_coord_t<POW2>(ay, v + ph) - s.y;
+          float qa = ca - dya * dya, qb = ca - dyb * dyb;
+          qa = (packed && v <= v1) ? qa : -1.f;
+          qb = (packed && v + ph <= v1) ? qb : -1.f;
+          body(j, s, cell, cell + dcell, dx, dya, dyb, qa, qb, c + 1 < c_end);
+        }
+      } else {   // a box wider than a wave: pw = 64, ph = 1, chunk = (row c / ncx, segment c % ncx)
+        for (; c < c_end; ++c) {
+          const int g = rfl((int)(((float)c + 0.5f) / (float)ncx));
+          const int u = u0 + ((c - g * ncx) << 6) + lane, v = v0 + g;
+          const float dx = axis_coord_t<POW2>(ax, u) - s.x;
+          const float dy = axis_coord_t<POW2>(ay, v) - s.y;
+          float q = (rr - dx * dx) - dy * dy;
+          q = u <= u1 ? q : -1.f;
+          body(j, s, (v - r0) * LW + u, 0, dx, dy, 0.f, q, -1.f, false);
         }
       }
       end_sphere(j);
@@ -234,10 +267,10 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
 // `shares` gives the four age groups (waves 4g..4g+3) their part of the list, one byte per
 // group, oldest first, summing to 256 (the launcher normalises).  Other workgroup sizes
 // split equally.
-template <bool POW2, typename Body, typename EndSphere, typename RowHook>
+template <bool POW2, int kSphereCost, typename Body, typename EndSphere>
 __device__ __forceinline__ void walk_my_slice(const WaveList &w, int J, int total, int wave, int nwaves, int shares,
-                                              int lane, const Axis &ax, const Axis &ay, Body &&body,
-                                              EndSphere &&end_sphere, RowHook &&row_hook) {
+                                              int lane, const Axis &ax, const Axis &ay, int r0, int LW, Body &&body,
+                                              EndSphere &&end_sphere) {
   wave = rfl(wave);   // everything that steers the loops is wave-uniform: keep it in SGPRs
   total = rfl(total);
   int lo, hi;
@@ -252,7 +285,7 @@ __device__ __forceinline__ void walk_my_slice(const WaveList &w, int J, int tota
     lo = (int)(((long long)wave * total) / nwaves);
     hi = (int)(((long long)(wave + 1) * total) / nwaves);
   }
-  if (lo < hi) walk_slice<POW2>(w, J, lo, hi, lane, ax, ay, body, end_sphere, row_hook);
+  if (lo < hi) walk_slice<POW2, kSphereCost>(w, J, lo, hi, lane, ax, ay, r0, LW, body, end_sphere);
 }
 
 // image axis coordinate with the power-of-two case resolved at compile time
@@ -373,7 +406,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
     const unsigned long long bad = __ballot(valid && !(sphere_is_tame(sph) && fabsf(sph.z) < 1e30f));
     const unsigned long long low = __ballot(valid && sph.z <= kBackground);
     bool too_big;   // excluded by the launcher (W <= kMaxFastWidth, H <= 32768)
-    const int total = build_work_list(sph, valid, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
+    const int total = build_work_list<kSphereCostFwd>(sph, valid, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
     if (lane == 0) {
       s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
       s_flag[1] = total;
@@ -447,10 +480,9 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
     wl.sph = sph;
     wl.item = s_items[lane];
     wl.end = s_ends[lane];
-    walk_my_slice<POW2>(
-        wl, J, s_flag[1], wave, nwaves, shares, lane, ax, ay,
-        [&](int j, const float4 s, int ua, int ub, int v, float qa, float qb, bool has_b) {
-          Key *row = zbuf + (v - r0) * LW;
+    walk_my_slice<POW2, kSphereCostFwd>(
+        wl, J, s_flag[1], wave, nwaves, shares, lane, ax, ay, r0, LW,
+        [&](int j, const float4 s, int cell_a, int cell_b, float, float, float, float qa, float qb, bool has_b) {
           auto put = [&](Key *cell, float d) {
             if (OWNER)
               atomicMin(reinterpret_cast<unsigned long long *>(cell),
@@ -462,13 +494,13 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
             const bool ha = qa > kHitMin, hb = qb > kHitMin;
             // (the root of a non-hit lane's q may be NaN: never stored)
             const float da = s.z - sqrt_rn(qa), db = s.z - sqrt_rn(qb);
-            if (ha) put(row + ua, da);
-            if (hb) put(row + ub, db);
+            if (ha) put(zbuf + cell_a, da);
+            if (hb) put(zbuf + cell_b, db);
           } else if (qa > kHitMin) {
-            put(row + ua, s.z - sqrt_rn(qa));
+            put(zbuf + cell_a, s.z - sqrt_rn(qa));
           }
         },
-        [](int) {}, []() {});
+        [](int) {});
   }
   __syncthreads();
 
@@ -601,7 +633,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     }
     if (wave_s == 0) {
       bool too_big;   // excluded by the launcher (W <= kMaxFastWidth)
-      const int total = build_work_list(sph, lane < J, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
+      const int total = build_work_list<kSphereCostBwd>(sph, lane < J, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
       if (lane == 0) s_flag[1] = total;
     }
     if (VEC4) {
@@ -674,16 +706,19 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     // run on a sphere its register partials are reduced with one DPP wave sum per
     // component into the wave's private LDS slot.
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int cell_max = (rh + kPadRows) * LW - 1;
     const WaveList wl = load_wave_list(s_sph, s_items, s_ends, lane);
-    walk_my_slice<POW2>(
-        wl, J, s_flag[1], wave, kZWaves, shares, lane, ax, ay,
-        [&](int j, const float4 s, int ua, int ub, int v, float qa, float qb, bool has_b) {
-          const int row = (v - r0) * LW;
-          auto take = [&](int u, float q) {
-            if (obuf[row + u] == (uint8_t)j) {
-              const float g = gbuf[row + u];
-              const float dx = axis_coord_t<POW2>(ax, u) - s.x;
-              const float dy = axis_coord_t<POW2>(ay, v) - s.y;
+    walk_my_slice<POW2, kSphereCostBwd>(
+        wl, J, s_flag[1], wave, kZWaves, shares, lane, ax, ay, r0, LW,
+        [&](int j, const float4 s, int cell_a, int cell_b, float dx, float dya, float dyb, float qa, float qb,
+            bool has_b) {
+          auto take = [&](int cell, float dy, float q) {
+            // lanes without a pixel (q = -1) may point past the region: clamped, and never counted
+            // (a branch-free form with all four LDS reads in flight measured slower: most chunks
+            // own nothing and skip the arithmetic)
+            cell = min(cell, cell_max);
+            if (obuf[cell] == (uint8_t)j && q > 0.f) {
+              const float g = gbuf[cell];
               const float w = g * __builtin_amdgcn_rsqf(q);  // g / sqrt(q), ~1e-7 rel.
               a0 = __builtin_fmaf(-w, dx, a0);
               a1 = __builtin_fmaf(-w, dy, a1);
@@ -691,8 +726,8 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
               a3 -= w;
             }
           };
-          take(ua, qa);
-          if (has_b) take(ub, qb);
+          take(cell_a, dya, qa);
+          if (has_b) take(cell_b, dyb, qb);
         },
         [&](int j) {
           const float sx = wave_sum_lane63(a0), sy = wave_sum_lane63(a1);
@@ -703,8 +738,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
             s_part[wave * SHR_MAX_SPHERES + j] = t;
           }
           a0 = a1 = a2 = a3 = 0.f;
-        },
-        []() {});
+        });
   }
   __syncthreads();
   // combine the waves' partials in wave order; d/dr = r * sum(-g/sqrt(q))
