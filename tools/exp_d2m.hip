@@ -1,9 +1,11 @@
 #include "../spherehand_amd/csrc/common.h"
 namespace shr {
-constexpr int kD2mThreads = 1024;
-constexpr int kD2mPix = 16;                           // pixels per thread per chunk (4 x 16-byte loads in flight)
-constexpr int kD2mChunk = kD2mPix * kD2mThreads;      // 16384 px: a whole 128x128 crop
-constexpr int kD2mQueue = 4096;                       // queue entries (64 KB); denser chunks take extra passes
+constexpr int kD2mThreads = 512;   // 8 waves: two workgroups per CU overlap one crop's loads with the other's search
+constexpr int kD2mPix = 16;                           // a 4x4-pixel block per thread per chunk (4 x 16-byte loads in flight);
+                                                      // 1024 threads = 16384 px = a whole 128x128 crop
+constexpr int kD2mQueue = 2048;                       // queue entries (32 KB); denser chunks take extra passes
+
+constexpr int kD2mSeeds = 3;                           // best-first visits before the candidate set is fixed
 
 struct QEntry { float a, b, c; int d; };  // phase 2: (xg, yg, z, -) ; phase 3: (gx, gy, gz, owner)
 
@@ -15,7 +17,7 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
   __shared__ float4 s_c[SHR_MAX_SPHERES];     // (cx, cy, cz, r)
   __shared__ int s_wave_cnt[kD2mThreads / 64];
   __shared__ float s_wave_loss[kD2mThreads / 64];
-  __shared__ QEntry s_q[kD2mQueue];           // 64 KB
+  __shared__ QEntry s_q[kD2mQueue];           // 32 KB
   __shared__ float4 s_part[(kD2mThreads / 64) * SHR_MAX_SPHERES];   // [wave][sphere] gradient partials
 
   const int n = blockIdx.x;
@@ -26,46 +28,73 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
   }
   const float *dm = depth + (size_t)n * H * W;
   const Axis ax = make_axis(W), ay = make_axis(H);
-  const int npix = H * W;
   const bool row4 = (W % 4 == 0) && is_aligned16(dm);
 
   float loss = 0.f;
   if (WANT_GRAD) s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);   // 1024 = 16 waves x 64 spheres
 
-  for (int base = 0; base < npix; base += kD2mChunk) {
-    // ---- 1. load 16 consecutive pixels (four 16-byte loads, all issued before the first
-    // use), flag foreground.  Consecutive pixels per thread keep the queue in scan order,
-    // so a wave's 64 entries are neighbours and their bounding box is tight (step 3).
+  // Threads own 4x4-pixel blocks (block id = chunk base + thread id, row-major over the
+  // ceil(W/4) x ceil(H/4) block grid): each of a thread's four 16-byte loads is contiguous
+  // with its neighbours' in x, and the queue (thread order, row-major inside a block) keeps
+  // neighbouring pixels together, so a wave's 64 entries have a tight bounding box (step 3).
+  const int nbx = (W + 3) >> 2, nby = (H + 3) >> 2;
+  const int nblocks = nbx * nby;
+  for (int base = 0; base < nblocks; base += kD2mThreads) {
+    // ---- 1. load the block (all four loads issued before the first use), flag foreground
+    const int blk = base + tid;
+    const int by = blk / nbx, bx = blk - by * nbx;
+    const int u0 = bx * 4, v0 = by * 4;
     float z[kD2mPix];
     int cnt = 0;
     unsigned fgmask = 0;
+    if (row4) {
+      // unconditional, clamped: the four requests go out back to back (one round trip); what
+      // lies outside the image is masked below
+      const int bc = min(blk, nblocks - 1);
+      const int byc = bc / nbx, bxc = bc - byc * nbx;
+      const float4 *p0 = reinterpret_cast<const float4 *>(dm + (size_t)min(byc * 4 + 0, H - 1) * W) + bxc;
+      const float4 *p1 = reinterpret_cast<const float4 *>(dm + (size_t)min(byc * 4 + 1, H - 1) * W) + bxc;
+      const float4 *p2 = reinterpret_cast<const float4 *>(dm + (size_t)min(byc * 4 + 2, H - 1) * W) + bxc;
+      const float4 *p3 = reinterpret_cast<const float4 *>(dm + (size_t)min(byc * 4 + 3, H - 1) * W) + bxc;
+      const float4 t0 = *p0, t1 = *p1, t2 = *p2, t3 = *p3;
+      z[0] = t0.x; z[1] = t0.y; z[2] = t0.z; z[3] = t0.w;
+      z[4] = t1.x; z[5] = t1.y; z[6] = t1.z; z[7] = t1.w;
+      z[8] = t2.x; z[9] = t2.y; z[10] = t2.z; z[11] = t2.w;
+      z[12] = t3.x; z[13] = t3.y; z[14] = t3.z; z[15] = t3.w;
+    } else {
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int p0 = base + kD2mPix * tid + 4 * g;
-      float4 t = make_float4(100.f, 100.f, 100.f, 100.f);
-      if (row4) {
-        if (p0 < npix) t = *reinterpret_cast<const float4 *>(dm + p0);
-      } else {
-        if (p0 + 0 < npix) t.x = dm[p0 + 0];
-        if (p0 + 1 < npix) t.y = dm[p0 + 1];
-        if (p0 + 2 < npix) t.z = dm[p0 + 2];
-        if (p0 + 3 < npix) t.w = dm[p0 + 3];
+      for (int g = 0; g < 4; g++) {
+        const int v = v0 + g;
+        float4 t = make_float4(100.f, 100.f, 100.f, 100.f);
+        if (blk < nblocks && v < H) {
+          const float *rowp = dm + (size_t)v * W + u0;
+          if (u0 + 0 < W) t.x = rowp[0];
+          if (u0 + 1 < W) t.y = rowp[1];
+          if (u0 + 2 < W) t.z = rowp[2];
+          if (u0 + 3 < W) t.w = rowp[3];
+        }
+        z[4 * g] = t.x; z[4 * g + 1] = t.y; z[4 * g + 2] = t.z; z[4 * g + 3] = t.w;
       }
-      z[4 * g] = t.x; z[4 * g + 1] = t.y; z[4 * g + 2] = t.z; z[4 * g + 3] = t.w;
     }
 #pragma unroll
     for (int k = 0; k < kD2mPix; k++) {
-      const int p = base + kD2mPix * tid + k;
-      const bool fg = (p < npix) && !(z[k] > 99.0f);  // mesh/render.py:138 background = d > 99
+      const bool in = blk < nblocks && (v0 + (k >> 2)) < H && (u0 + (k & 3)) < W;
+      const bool fg = in && !(z[k] > 99.0f);  // mesh/render.py:138 background = d > 99
       fgmask |= (unsigned)fg << k;
       cnt += fg;
     }
-    // deterministic exclusive scan of cnt over the workgroup (queue order = thread order)
+    // deterministic exclusive scan of cnt over the workgroup (queue order = thread order):
+    // 4 DPP steps inside each row of 16 lanes, then the row totals via SGPR broadcasts
     int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d);
-      if (lane >= d) incl += t;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);  // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);  // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);  // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);  // row_shr:8
+    {
+      const int r0s = __builtin_amdgcn_readlane(incl, 15), r1s = __builtin_amdgcn_readlane(incl, 31);
+      const int r2s = __builtin_amdgcn_readlane(incl, 47);
+      const int row = lane >> 4;
+      incl += (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
     }
     if (base > 0) __syncthreads();  // previous chunk's queue fully consumed
     if (lane == 63) s_wave_cnt[wave] = incl;
@@ -83,15 +112,15 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
     // ---- 2. compact ---------------------------------------------------------------------
     {
       int slot = offset - q0;
-      const int pfirst = base + kD2mPix * tid;
-      int v = pfirst / W, u = pfirst - v * W;   // one division per thread, then incremental
+      const float xg0 = axis_coord(ax, u0), xg1 = axis_coord(ax, u0 + 1), xg2 = axis_coord(ax, u0 + 2),
+                  xg3 = axis_coord(ax, u0 + 3);
 #pragma unroll
-      for (int k = 0; k < kD2mPix; k++, u = (u + 1 == W) ? 0 : u + 1, v += (u == 0)) {
+      for (int k = 0; k < kD2mPix; k++) {
         if ((fgmask >> k) & 1u) {
           if (slot >= 0 && slot < kD2mQueue) {
             QEntry e;
-            e.a = axis_coord(ax, u);
-            e.b = axis_coord(ay, v);
+            e.a = (k & 3) == 0 ? xg0 : ((k & 3) == 1 ? xg1 : ((k & 3) == 2 ? xg2 : xg3));
+            e.b = axis_coord(ay, v0 + (k >> 2));
             e.c = z[k];
             e.d = 0;
             if (!(mode & 8)) s_q[slot] = e;
@@ -103,11 +132,11 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
     __syncthreads();
     // ---- 3. nearest-surface search per foreground pixel ------------------------------
     // A wave takes 64 consecutive queue entries (neighbouring pixels in scan order).  With
-    // lanes = spheres it bounds a_j = | ||p - c_j|| - r_j | over the points' bounding box:
-    // a_j in [lb_j, ub_j]; every point's minimum is <= U = min_j ub_j, so a sphere with
-    // lb_j > U cannot be nearest for any of the 64 points (strictly, so index ties are
-    // unaffected).  Then lanes = points walk the surviving candidates only (typically 4-8
-    // of 41).  Bounds carry a rounding slack; a NaN anywhere disables the pruning.
+    // lanes = spheres it bounds a_j = | ||p - c_j|| - r_j | from below over the points' bounding
+    // box (lb_j), then lanes = points visit the few spheres with the smallest lb_j first, after
+    // which the running minima are millimetres (the points lie on the model's surface) and
+    // only spheres whose lb_j is below the largest of them remain candidates (10-15 of 41).
+    // Bounds carry a rounding slack; a NaN anywhere disables the pruning.
     {
       const float4 cj = lane < J ? s_c[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
       if (!(mode & 1)) for (int i0 = wave * 64; i0 < total; i0 += kD2mThreads) {
@@ -125,23 +154,46 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
         const float dmin = __builtin_amdgcn_sqrtf((nx * nx + ny * ny) + nz * nz);
         const float dmax = __builtin_amdgcn_sqrtf((fx * fx + fy * fy) + fz * fz);
         const float lb = fmaxf(fmaxf(dmin - cj.w, cj.w - dmax), 0.f);
-        const float ub = fmaxf(fabsf(dmin - cj.w), fabsf(dmax - cj.w));
-        const float U = wave_minmax_all<true>(lane < J ? ub : inf);
-        const bool pruned = (lb * 0.99999f - 1e-3f) > (U * 1.00001f + 1e-3f);   // false on NaN
-        unsigned long long cand = __ballot(lane < J && (!pruned || (mode & 2)));
+        const bool odd = __ballot((e.a != e.a) || (e.b != e.b) || (e.c != e.c) || (lane < J && lb != lb)) != 0ull;
         float best = 0.f;
         int bj = 0;
-        bool first = true;
-        while (cand) {
-          const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(cand));
-          cand &= cand - 1;
+        auto surface_distance = [&](int j) {   // lanes = points, sphere j's record through SGPRs
           const float cx = readlane_f(cj.x, j), cy = readlane_f(cj.y, j), cz = readlane_f(cj.z, j);
           const float cr = readlane_f(cj.w, j);
           const float dx = e.a - cx, dy = e.b - cy, dz = e.c - cz;
           const float dist = __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz);  // <= 1 ulp: loss is continuous
-          const float a = fabsf(dist - cr);
-          if (first || ((best == best) && (a < best || a != a))) { best = a; bj = j; }   // torch.min: NaN wins, ties keep first
-          first = false;
+          return fabsf(dist - cr);
+        };
+        if (odd) {   // a NaN somewhere: every sphere, in index order (torch.min: NaN wins, ties keep first)
+          for (int j = 0; j < J; j++) {
+            const float a = surface_distance(j);
+            if (j == 0 || ((best == best) && (a < best || a != a))) { best = a; bj = j; }
+          }
+        } else {
+          // Two stages.  (1) Best first: visit the kD2mSeeds unvisited spheres with the smallest
+          // lower bounds; the largest of the 64 running minima (`reach`) is then small, the
+          // points lie on the model's surface.  (2) No sphere whose lower bound (discounted
+          // for rounding) exceeds `reach` can reach, or tie, any point's minimum: the others
+          // are visited in a plain loop.
+          float rem = lane < J ? lb * 0.99999f - 1e-3f : inf;
+          float reach = inf;
+          best = inf;
+          for (int it = 0; it < ((mode & 16) ? 0 : kD2mSeeds); it++) {
+            const float m = wave_minmax_all<true>(rem);
+            if (!(m <= reach) || m == inf) break;
+            const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(__ballot(rem == m)));
+            if (lane == j) rem = inf;
+            const float a = surface_distance(j);
+            if (a < best || (a == best && j < bj)) { best = a; bj = j; }   // ties keep the first index
+            reach = wave_minmax_all<false>(act ? best : -inf) * 1.00001f + 1e-3f;
+          }
+          unsigned long long cand = (mode & 2) ? 0ull : __ballot(rem <= reach && rem != inf);
+          while (cand) {
+            const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(cand));
+            cand &= cand - 1;
+            const float a = surface_distance(j);
+            if (a < best || (a == best && j < bj)) { best = a; bj = j; }
+          }
         }
         if (act) loss += fminf(fmaxf(best, 0.f), 50.f);
         if (WANT_GRAD) {
@@ -203,6 +255,6 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
 }
 extern "C" int exp_d2m_launch(const float *depth, const float *centres, const float *radii, int N, int J, int H, int W,
                               float *loss_sum, float *grad, int mode, void *stream) {
-  hipLaunchKernelGGL(shr::exp_d2m<true>, dim3(N), dim3(1024), 0, (hipStream_t)stream, depth, centres, radii, J, H, W, loss_sum, grad, mode);
+  hipLaunchKernelGGL(shr::exp_d2m<true>, dim3(N), dim3(shr::kD2mThreads), 0, (hipStream_t)stream, depth, centres, radii, J, H, W, loss_sum, grad, mode);
   return (int)hipGetLastError();
 }

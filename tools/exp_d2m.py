@@ -31,5 +31,5 @@ def timeit(fn, reps=30):
         e1.record(); e1.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
     return round(best, 1)
-names = {0: "full", 1: "load+scan+compact only", 9: "load+scan only (no queue stores)", 2: "no pruning", 4: "no owner reduction", 6: "no pruning, no reduction"}
+names = {0: "full", 1: "load+scan+compact only", 2: "no stage-2 candidates", 18: "box phase only (no seeds, no candidates)", 4: "no owner reduction", 22: "box phase only, no reduction"}
 print({names[m]: timeit(lambda: lib.exp_d2m_launch(obs.data_ptr(), cen.data_ptr(), rad.data_ptr(), N, 41, S, S, ls.data_ptr(), gr.data_ptr(), m, st)) for m in names})
