@@ -146,10 +146,11 @@ extern "C" int shr_sphere_raster_fwd(const float *spheres, int N, int J, int H, 
   const float4 *sp = reinterpret_cast<const float4 *>(spheres);
 
   const long long row_bytes = (long long)(W + kRowPad) * (argmin ? 8 : 4);
-  // Measured (MI355X, 128x128): up to ~2 crops per CU one whole-crop workgroup per CU wins
-  // (10.7 vs 11.8 us at N=256); with more crops two 80-KB workgroups per CU overlap one
-  // crop's stream-out with another's scan conversion (7.6 vs 9.1 us per 256 crops at N=9216).
-  const int owner_cap = g_tune.fwd_owner_lds_bytes ? g_tune.fwd_owner_lds_bytes : (N <= 512 ? kMaxLds : 80 * 1024);
+  // Measured (MI355X, 128x128): one whole-crop workgroup per CU beats two 80-KB half-crop
+  // workgroups at every batch size (N = 256: 8.8 vs 10.7 us; N = 9216: 6.1 vs 6.6 us per 256
+  // crops): a half-crop workgroup repeats the prologue and splits the spheres that straddle
+  // the cut.
+  const int owner_cap = g_tune.fwd_owner_lds_bytes ? g_tune.fwd_owner_lds_bytes : kMaxLds;
   const int rows = g_tune.force_general
                        ? 0
                        : pick_rows(H, row_bytes, argmin ? owner_cap : g_tune.fwd_lds_bytes,

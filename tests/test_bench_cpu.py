@@ -28,5 +28,8 @@ def test_bench_constants_and_traffic_lookup():
     fwd = 4 * 128 * 128 + 128 * 128 + 16 * 41
     bwd = 4 * 128 * 128 + 128 * 128 + 16 * 41 + 16 * 41
     assert fwd + bwd == 165808
+    # the forward must write every byte; the backward may read fewer (it skips untouched rows)
+    traffic, src = bench.pmc_traffic("sphere_zbuf_fwd_kernel")
+    assert traffic is None or (traffic > 0.9 * 256 * fwd and src.startswith("profiles/"))
     traffic, src = bench.pmc_traffic("sphere_zbuf_bwd_kernel")
-    assert traffic is None or (traffic > 0.9 * 256 * bwd and src.startswith("profiles/"))
+    assert traffic is None or (0.3 * 256 * bwd < traffic < 1.5 * 256 * bwd and src.startswith("profiles/"))
