@@ -1,29 +1,5 @@
-// mesh_depth.hip -- fused DepthRender back end: triangle raster + clamp + bilinear resize
-// in one pass, rasterizing ONLY the source pixels the resize reads.
-//
-// Replaces the chain DepthRasterizationFunction.apply(640, 640, ...) -> clamp(max=100) ->
-// F.interpolate(size=(S,S), mode='bilinear', align_corners=False) of
-// mesh/render.py:284-287, :310-311 (kernel: mesh/cuda_kernel/depth_rasterization_cuda_kernel.cu:18-113).
-//
-// The reference rasterizes 640x640 (1.64 MB per crop) and then keeps 1 source pixel in
-// 25 (S = 128), 4 in 100 (S = 64) or 16 in 25 (S = 256).  Here each workgroup owns a tile
-// of TO x TO OUTPUT pixels; every output pixel has 2 x 2 source "slots" (x0/x1 x y0/y1 of
-// ATen's bilinear source index), kept in LDS as order-preserving integer keys.  Lanes =
-// faces: each lane sets its face up exactly like the reference kernel (tri_raster.hip:
-// cull, sort by x, inverse barycentric matrix), finds the output pixels whose slots fall in
-// the face's box, and for those source pixels repeats the reference's per-column span test
-// and per-pixel arithmetic verbatim, finishing with a native LDS integer min (order
-// independent, hence deterministic).  Epilogue: clamp, ATen's bilinear formula, coalesced
-// stores of the S x S result.  HBM traffic per crop: the vertices (162 KB, L2-shared by the
-// crop's tiles) + 4*S*S written, instead of >= 3 x 1.64 MB.
-//
-// Zero-weight slots are not rasterized (0 * finite = 0 contributes nothing); the only
-// input on which this differs from the reference chain is a raster value of -inf next to a
-// sampled pixel (an exactly zero 1/z denominator), where the reference's 0 * -inf is NaN.
-#include "common.h"
-
+#include "../spherehand_amd/csrc/common.h"
 namespace shr {
-
 __device__ __forceinline__ uint32_t mkey(float d) {
   const uint32_t b = __float_as_uint(d);
   return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
@@ -114,8 +90,9 @@ constexpr int kMeshFaces = 4;      // faces per thread and round (one round for 
 //      pixel) with every lane busy and bounded work per lane.
 template <int TO, int SL>
 __global__ void __launch_bounds__(1024)
-mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ faces, int NV, int F, int src,
-                  int S, float clamp_max, float *__restrict__ depth) {
+exp_mesh(const float4 *__restrict__ vertices, const int *__restrict__ faces, int NV, int F, int src,
+                  int S, float clamp_max, float *__restrict__ depth, long long *tb) {
+  long long tA = 0, tS = 0, tB = 0, tW = 0; int nitems = 0; const long long T0 = clock64();
   __shared__ uint32_t s_z[SL * TO][SL * TO + 1];   // [SL*dy + sy][SL*dx + sx], +1: bank spread
   __shared__ int s_queue[kMeshQueue];
   __shared__ int s_wave_cnt[16];
@@ -149,6 +126,7 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
 
   for (int f0 = 0; f0 < F; f0 += 1024 * kMeshFaces) {
     // ---- A. cull, count work items, block scan ---------------------------------------------
+    const long long a0 = clock64();
     int nk[kMeshFaces], dx0[kMeshFaces];
     unsigned colmask[kMeshFaces];   // bit i: output column dx0 + i holds a sampled source column of the face
     int n = 0;
@@ -175,6 +153,7 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
       }
       n += nk[k];
     }
+    const long long a1 = clock64(); tA += a1 - a0;
     int incl = n;   // inclusive scan over the workgroup: DPP inside rows of 16, SGPR row totals, LDS wave totals
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
@@ -195,6 +174,7 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
       if (w < wave) off += c;
       total += c;
     }
+    tS += clock64() - a1; nitems += total;
     for (int w0 = 0; w0 < total; w0 += kMeshQueue) {
       if (w0 > 0) __syncthreads();
       {
@@ -218,6 +198,7 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
       }
       __syncthreads();
       // ---- B. rasterize the queued items (order is irrelevant: integer minima) ---------------
+      const long long b0 = clock64();
       const int count = min(kMeshQueue, total - w0);
       for (int q = tid; q < count; q += blockDim.x) {
         const int item = s_queue[q];
@@ -279,8 +260,10 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
           }
         }
       }
+      const long long b1 = clock64(); tB += b1 - b0;
     }
   }
+  const long long e0 = clock64();
   __syncthreads();
 
   // ---- clamp + bilinear (mesh/render.py:286, :311; ATen upsample_bilinear2d) ---------------
@@ -301,34 +284,16 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
       out[(size_t)y * S + x] = ly.l0 * (lx.l0 * v[0][0] + lx.l1 * v[0][1]) + ly.l1 * (lx.l0 * v[1][0] + lx.l1 * v[1][1]);
     }
   }
-}
-
-}  // namespace shr
-
-extern "C" int shr_mesh_depth_fwd(const float *vertices, const int32_t *faces, int B, int NV, int F, int src_size,
-                                  int S, float clamp_max, float *depth, void *stream) {
-  using namespace shr;
-  if (B == 0) return SHR_OK;
-  if (!vertices || (!faces && F > 0) || !depth || B < 0 || NV <= 0 || F < 0 || src_size <= 0 || S <= 0)
-    return SHR_EINVAL;
-  if (((uintptr_t)vertices & 15u) != 0) return SHR_EINVAL;
-  if (B > 65535 || S > 16384 || src_size > (1 << 20) || 2 * S > src_size + 1 || F > (1 << 24))
-    return SHR_ETOOLARGE;  // down-sampling only; work items pack the face index in 25 bits
-  hipStream_t s = (hipStream_t)stream;
-  const float4 *v4 = reinterpret_cast<const float4 *>(vertices);
-  // odd integer ratio: src = ratio * d + (ratio - 1) / 2 exactly, bilinear weights (1, 0)
-  const bool single = (src_size % S == 0) && (((src_size / S) & 1) == 1);
-#define MESH_LAUNCH(TO, SL)                                                                                      \
-  do {                                                                                                           \
-    const int t = (S + (TO) - 1) / (TO);                                                                         \
-    hipLaunchKernelGGL((mesh_depth_kernel<TO, SL>), dim3((unsigned)(t * t), (unsigned)B), dim3(1024), 0, s, v4,  \
-                       faces, NV, F, src_size, S, clamp_max, depth);                                             \
-  } while (0)
-  if (single) {
-    if (S > 64) MESH_LAUNCH(128, 1); else MESH_LAUNCH(64, 1);
-  } else {
-    if (S > 32) MESH_LAUNCH(64, 2); else MESH_LAUNCH(32, 2);
+  if (lane == 0) {
+    long long *t = tb + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave) * 8;
+    t[0] = tA; t[1] = tS; t[2] = tB; t[3] = e0 - T0; t[4] = clock64() - T0; t[5] = nitems;
   }
-#undef MESH_LAUNCH
+}
+}
+extern "C" int exp_mesh_launch(const float *vertices, const int *faces, int B, int NV, int F, int src, int S, float *depth,
+                               long long *tb, void *stream) {
+  using namespace shr;
+  if (S == 128) hipLaunchKernelGGL((exp_mesh<128, 1>), dim3(1, B), dim3(1024), 0, (hipStream_t)stream, (const float4 *)vertices, faces, NV, F, src, S, 100.f, depth, tb);
+  else hipLaunchKernelGGL((exp_mesh<64, 2>), dim3(((S + 63) / 64) * ((S + 63) / 64), B), dim3(1024), 0, (hipStream_t)stream, (const float4 *)vertices, faces, NV, F, src, S, 100.f, depth, tb);
   return (int)hipGetLastError();
 }
