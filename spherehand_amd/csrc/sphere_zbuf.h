@@ -44,8 +44,8 @@ namespace shr {
 constexpr int kZWaves = 16;   // 1024 threads
 constexpr int kPatchW = 16;   // lanes along x
 constexpr int kPatchH = 4;    // lanes along y
-constexpr int kRowPad = 16;   // LDS row padding (elements): patches may overhang the image edge
-constexpr int kPadRows = kPatchH - 1;  // ... and the region's last row
+constexpr int kRowPad = 8;    // LDS row padding (elements): chunk rows start in different banks (no lane writes there)
+constexpr int kPadRows = 0;   // rows after the region's last (none: a chunk never overhangs its box)
 constexpr int kBgWaves = 7;   // forward: waves that store the background rows before the first barrier
 // LDS header: spheres [64] float4 | work items [64] int4 | ends [64] int | flags
 constexpr int kOffItems = 1024;
