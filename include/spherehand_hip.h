@@ -102,6 +102,31 @@ int shr_sphere_raster_bwd(const float *spheres, const float *grad_depth,
 int shr_data_to_model(const float *depth, const float *centres, const float *radii,
                       int N, int J, int H, int W, float *loss_sum,
                       float *grad_centres, void *stream);
+/* Same, crop n reading the depth image depth + depth_index[n]*H*W: the V*V view pairs
+ * of mesh/multiview_utility.py:98-105 share V observed images, the reference's
+ * expand().reshape() copy (9x the images) is not needed. */
+int shr_data_to_model_indexed(const float *depth, const int32_t *depth_index,
+                              const float *centres, const float *radii,
+                              int N, int J, int H, int W, float *loss_sum,
+                              float *grad_centres, void *stream);
+
+/* Fused render-and-compare: the model->data term of mesh/multiview_utility.py:98-101 and
+ * :107-113 (MSELoss(BallRender(...).min(), observed)) with its whole backward, one
+ * launch: e = raster(spheres[n]) - target[target_index ? target_index[n] : n],
+ *   sse_partial[n*R + r]              = sum of e*e over region r of crop n,
+ *   grad_spheres_partial[(n*R+r)*J+j] = d(sum e*e)/d(x, y, z, radius) of sphere j,
+ *   depth[N,H,W] (optional, may be NULL) = the rendered depth.
+ * R = shr_sphere_raster_mse_regions(H, W) row regions per crop (1 up to 128x128; 0 = image
+ * rows too wide for the kernel); the caller sums the R partials (fixed order: deterministic)
+ * and applies MSELoss's 1/(N*H*W) and its weights.  Requires W % 4 == 0 and 16-byte
+ * aligned spheres / target / depth / grad buffers (SHR_EINVAL otherwise: compose
+ * shr_sphere_raster_fwd and _bwd).  Results equal that composition: bit-identical depth,
+ * gradients and sums to fp32 summation order. */
+int shr_sphere_raster_mse_regions(int H, int W);
+int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W,
+                          const float *target, const int32_t *target_index,
+                          float *depth, float *sse_partial,
+                          float *grad_spheres_partial, void *stream);
 
 /* View-to-view projection of the sphere centres ---------------------------------
  * Replaces MutualTransformation + the projection in MutualProjection.forward

@@ -39,9 +39,9 @@ struct QEntry { float a, b, c; int d; };  // phase 2: (xg, yg, z, -) ; phase 3: 
 
 template <bool WANT_GRAD>
 __global__ void __launch_bounds__(kD2mThreads)
-data_to_model_kernel(const float *__restrict__ depth, const float *__restrict__ centres,
-                     const float *__restrict__ radii, int J, int H, int W, float *__restrict__ loss_sum,
-                     float *__restrict__ grad_centres) {
+data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ depth_index,
+                     const float *__restrict__ centres, const float *__restrict__ radii, int J, int H, int W,
+                     float *__restrict__ loss_sum, float *__restrict__ grad_centres) {
   __shared__ float4 s_c[SHR_MAX_SPHERES];     // (cx, cy, cz, r)
   __shared__ int s_wave_cnt[kD2mThreads / 64];
   __shared__ float s_wave_loss[kD2mThreads / 64];
@@ -54,7 +54,7 @@ data_to_model_kernel(const float *__restrict__ depth, const float *__restrict__ 
     const float *c = centres + ((size_t)n * J + tid) * 3;
     s_c[tid] = make_float4(c[0], c[1], c[2], radii[tid]);
   }
-  const float *dm = depth + (size_t)n * H * W;
+  const float *dm = depth + (size_t)(depth_index ? depth_index[n] : n) * H * W;
   const Axis ax = make_axis(W), ay = make_axis(H);
   const bool row4 = (W % 4 == 0) && is_aligned16(dm);
 
@@ -287,18 +287,32 @@ data_to_model_kernel(const float *__restrict__ depth, const float *__restrict__ 
 
 }  // namespace shr
 
-extern "C" int shr_data_to_model(const float *depth, const float *centres, const float *radii, int N, int J, int H,
-                                 int W, float *loss_sum, float *grad_centres, void *stream) {
+namespace {
+int launch_d2m(const float *depth, const int32_t *depth_index, const float *centres, const float *radii, int N, int J,
+               int H, int W, float *loss_sum, float *grad_centres, void *stream) {
   using namespace shr;
   if (N == 0) return SHR_OK;
   if (!depth || !centres || !radii || !loss_sum || N < 0 || J <= 0 || H <= 0 || W <= 0) return SHR_EINVAL;
   if (J > SHR_MAX_SPHERES || (long long)H * W > (1LL << 30)) return SHR_ETOOLARGE;
   hipStream_t s = (hipStream_t)stream;
   if (grad_centres)
-    hipLaunchKernelGGL(data_to_model_kernel<true>, dim3((unsigned)N), dim3(kD2mThreads), 0, s, depth, centres, radii,
-                       J, H, W, loss_sum, grad_centres);
+    hipLaunchKernelGGL(data_to_model_kernel<true>, dim3((unsigned)N), dim3(kD2mThreads), 0, s, depth, depth_index,
+                       centres, radii, J, H, W, loss_sum, grad_centres);
   else
-    hipLaunchKernelGGL(data_to_model_kernel<false>, dim3((unsigned)N), dim3(kD2mThreads), 0, s, depth, centres, radii,
-                       J, H, W, loss_sum, grad_centres);
+    hipLaunchKernelGGL(data_to_model_kernel<false>, dim3((unsigned)N), dim3(kD2mThreads), 0, s, depth, depth_index,
+                       centres, radii, J, H, W, loss_sum, grad_centres);
   return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int shr_data_to_model(const float *depth, const float *centres, const float *radii, int N, int J, int H,
+                                 int W, float *loss_sum, float *grad_centres, void *stream) {
+  return launch_d2m(depth, nullptr, centres, radii, N, J, H, W, loss_sum, grad_centres, stream);
+}
+
+extern "C" int shr_data_to_model_indexed(const float *depth, const int32_t *depth_index, const float *centres,
+                                         const float *radii, int N, int J, int H, int W, float *loss_sum,
+                                         float *grad_centres, void *stream) {
+  if (!depth_index && N > 0) return SHR_EINVAL;
+  return launch_d2m(depth, depth_index, centres, radii, N, J, H, W, loss_sum, grad_centres, stream);
 }

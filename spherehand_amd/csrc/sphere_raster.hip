@@ -208,3 +208,50 @@ extern "C" int shr_sphere_raster_bwd(const float *spheres, const float *grad_dep
     hipLaunchKernelGGL((sphere_tile_bwd_kernel<false>), grid, block, 0, s, sp, grad_depth, J, H, W, gs, tiles_x, ntiles);
   return (int)hipGetLastError();
 }
+
+namespace {
+int mse_rows(int H, int W) {
+  using namespace shr;
+  if (H <= 0 || W <= 0 || W > kMaxFastWidth || H > 32768) return 0;
+  return pick_rows(H, (long long)(W + kRowPad) * 8, kMaxLds, kHdrBytes + kPartBytes);
+}
+}  // namespace
+
+extern "C" int shr_sphere_raster_mse_regions(int H, int W) {
+  const int rows = mse_rows(H, W);
+  return rows > 0 ? (H + rows - 1) / rows : 0;
+}
+
+extern "C" int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W, const float *target,
+                                     const int32_t *target_index, float *depth, float *sse_partial,
+                                     float *grad_spheres_partial, void *stream) {
+  using namespace shr;
+  if (N == 0) return SHR_OK;
+  if (!spheres || !target || !sse_partial || !grad_spheres_partial || N < 0 || J <= 0 || H <= 0 || W <= 0)
+    return SHR_EINVAL;
+  if (J > SHR_MAX_SPHERES || (long long)H * W > (1LL << 30)) return SHR_ETOOLARGE;
+  if ((W % 4) != 0 || ((((uintptr_t)spheres | (uintptr_t)target | (uintptr_t)depth | (uintptr_t)grad_spheres_partial)) & 15u) != 0)
+    return SHR_EINVAL;   // 16-byte rows only: compose shr_sphere_raster_fwd / _bwd otherwise
+  const int rows = mse_rows(H, W);
+  if (rows <= 0 || (H + rows - 1) / rows > 65535) return SHR_ETOOLARGE;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = kHdrBytes + kPartBytes + (size_t)rows * (W + kRowPad) * 8;
+  dim3 grid((unsigned)N, (unsigned)((H + rows - 1) / rows));
+  static bool attr_a = false, attr_b = false;
+  if (is_pow2(W) && is_pow2(H)) {
+    auto k = sphere_zbuf_mse_kernel<true>;
+    const hipError_t e = allow_big_lds(k, &attr_a);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), J, H, W, target,
+                       target_index, depth, sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), rows,
+                       log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares);
+  } else {
+    auto k = sphere_zbuf_mse_kernel<false>;
+    const hipError_t e = allow_big_lds(k, &attr_b);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), J, H, W, target,
+                       target_index, depth, sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), rows,
+                       log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares);
+  }
+  return (int)hipGetLastError();
+}

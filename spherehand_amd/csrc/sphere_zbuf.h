@@ -753,4 +753,272 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   }
 }
 
+// ---------------------------------------------------------------------------
+// Fused render-and-compare: depth = raster(spheres), e = depth - target, per-crop
+// sum(e*e) and d sum(e*e) / d spheres in ONE kernel.  Replaces, for the model->data
+// term of mesh/multiview_utility.py:98-101 / :107-113, the chain rasterize -> MSELoss
+// -> MSELoss backward -> rasterizer backward: no owner map, no gradient image and no
+// difference image ever reach HBM (read 4 S^2 of target, write 4 S^2 of depth if it is
+// wanted; the unfused chain moves >= 50 bytes per pixel).
+//
+// grid = (N, nregions), block = 1024, dynamic LDS = kHdrBytes + kPartBytes + rows * (W +
+// kRowPad) * 8.  The forward's schedule up to the z-buffer, then
+//   convert  every pixel: e = d - t, the thread's running sum of e*e; touched rows rewrite
+//            their z-buffer cell as (bits(2e) << 32 | owner);
+//   walk     the backward's walk, reading gradient and owner from that cell;
+// outputs are PER REGION (sse[n * R + region], grad[(n * R + region) * J + j]) and summed
+// by the caller (R = 1 up to 128x128).  A crop that needs the general path evaluates its
+// tiles like sphere_tile_bwd_kernel with the gradient formed in registers.
+constexpr int kSphereCostMse = 28;
+
+template <bool POW2>
+__global__ void __launch_bounds__(1024)
+sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, const float *__restrict__ target,
+                       const int *__restrict__ target_index, float *__restrict__ depth,
+                       float *__restrict__ sse_out, float4 *__restrict__ grad_out, int rows_per_region,
+                       int w4_shift, int shares_fwd, int shares_bwd) {
+  using Key = unsigned long long;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4 *s_sph = reinterpret_cast<float4 *>(smem);
+  int4 *s_items = reinterpret_cast<int4 *>(smem + kOffItems);
+  int *s_ends = reinterpret_cast<int *>(smem + kOffEnds);
+  int *s_flag = reinterpret_cast<int *>(smem + kOffFlags);
+  float4 *s_part = reinterpret_cast<float4 *>(smem + kHdrBytes);
+  Key *zbuf = reinterpret_cast<Key *>(smem + kHdrBytes + kPartBytes);
+
+  const int n = blockIdx.x, region = blockIdx.y, nregions = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = region * rows_per_region;
+  const int r1 = min(H, r0 + rows_per_region);
+  const int rh = r1 - r0;
+  const int LW = W + kRowPad;
+  const Axis ax = make_axis(W), ay = make_axis(H);
+  const float *tgt = target + (size_t)(target_index ? target_index[n] : n) * H * W + (size_t)r0 * W;
+  float *out = depth ? depth + (size_t)n * H * W + (size_t)r0 * W : nullptr;
+
+  const bool valid = lane < J;
+  float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) sph = spheres[(size_t)n * J + lane];
+  s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // 1024 = 16 waves x 64 spheres
+  {  // background everywhere
+    const Key bg = ((Key)depth_key(kBackground) << 32) | SHR_ARGMIN_NONE;
+    const int nvec = (rh * LW) >> 1;
+    const ulonglong2 v = make_ulonglong2(bg, bg);
+    for (int i = tid; i < nvec; i += 1024) reinterpret_cast<ulonglong2 *>(zbuf)[i] = v;
+    if (tid == 0 && ((rh * LW) & 1)) zbuf[rh * LW - 1] = bg;
+  }
+
+  const int wave_s = rfl(wave);
+  const int w4 = W >> 2;
+  const int nchunk = rh * w4;
+  const int nunits = (nchunk + 63) >> 6;
+  const float4 *tgt4 = reinterpret_cast<const float4 *>(tgt);
+  float4 *out4 = reinterpret_cast<float4 *>(out);
+  int ua = 0, ub = nunits;
+  const bool bg_wave = wave_s >= 1 && wave_s <= kBgWaves;
+  if (bg_wave) {   // rows no sphere touches: depth = background, stored while wave 0 builds the list
+    int cv0, cv1;
+    touched_rows(sph, valid, ay, r0, r1, cv0, cv1);
+    if (cv1 < cv0) ua = ub = nunits;
+    else { ua = ((cv0 - r0) * w4) >> 6; ub = min(nunits, ((cv1 - r0 + 1) * w4 + 63) >> 6); }
+    ua = rfl(ua);
+    ub = rfl(ub);
+    if (wave_s == 1 && lane == 0) { s_flag[2] = ua; s_flag[3] = ub; }
+    if (out) {
+      const float4 bgd = make_float4(kBackground, kBackground, kBackground, kBackground);
+      const int nbg = ua + (nunits - ub);
+      for (int t = wave_s - 1; t < nbg; t += kBgWaves) {
+        const int u = t < ua ? t : t - ua + ub;
+        const int c = (u << 6) + lane;
+        if (c < nchunk) stream_store(out4 + c, bgd);
+      }
+    }
+  }
+  if (wave_s == 0) {
+    s_sph[lane] = sph;
+    const unsigned long long bad = __ballot(valid && !(sphere_is_tame(sph) && fabsf(sph.z) < 1e30f));
+    const unsigned long long low = __ballot(valid && sph.z <= kBackground);
+    bool too_big;
+    const int total = build_work_list<kSphereCostMse>(sph, valid, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
+    if (lane == 0) {
+      s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
+      s_flag[1] = total;
+    }
+  }
+  __syncthreads();
+  const bool general = s_flag[0] != 0;
+  ua = rfl(s_flag[2]);
+  ub = rfl(s_flag[3]);
+
+  float sse = 0.f;
+  if (!general) {
+    // ---- scan-convert (forward) ------------------------------------------------------------
+    WaveList wl;
+    wl.sph = sph;
+    wl.item = s_items[lane];
+    wl.end = s_ends[lane];
+    walk_my_slice<POW2, kSphereCostMse>(
+        wl, J, s_flag[1], wave, kZWaves, shares_fwd, lane, ax, ay, r0, LW,
+        [&](int j, const float4 s, int cell_a, int cell_b, float, float, float, float qa, float qb, bool has_b) {
+          auto put = [&](Key *cell, float d) { atomicMin(cell, ((Key)depth_key(d) << 32) | (unsigned)j); };
+          if (has_b) {
+            const bool ha = qa > kHitMin, hb = qb > kHitMin;
+            const float da = s.z - sqrt_rn(qa), db = s.z - sqrt_rn(qb);
+            if (ha) put(zbuf + cell_a, da);
+            if (hb) put(zbuf + cell_b, db);
+          } else if (qa > kHitMin) {
+            put(zbuf + cell_a, s.z - sqrt_rn(qa));
+          }
+        },
+        [](int) {});
+    __syncthreads();
+
+    // ---- convert: error, its square, gradient image in place ---------------------------------
+    for (int u = wave_s; u < nunits; u += kZWaves) {
+      const int c = (u << 6) + lane;
+      if (c >= nchunk) continue;
+      const float4 t = tgt4[c];
+      if (u < ua || u >= ub) {   // background rows (already stored)
+        const float e0 = kBackground - t.x, e1 = kBackground - t.y, e2 = kBackground - t.z, e3 = kBackground - t.w;
+        sse += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+        continue;
+      }
+      int v, x;
+      if (POW2 || w4_shift >= 0) { v = c >> w4_shift; x = (c & (w4 - 1)) << 2; }
+      else { v = c / w4; x = (c - v * w4) << 2; }
+      ulonglong2 *cell = reinterpret_cast<ulonglong2 *>(zbuf + v * LW + x);
+      ulonglong2 k01 = cell[0], k23 = cell[1];
+      const float4 d = make_float4(key_depth((uint32_t)(k01.x >> 32)), key_depth((uint32_t)(k01.y >> 32)),
+                                   key_depth((uint32_t)(k23.x >> 32)), key_depth((uint32_t)(k23.y >> 32)));
+      if (out) stream_store(out4 + c, d);
+      const float e0 = d.x - t.x, e1 = d.y - t.y, e2 = d.z - t.z, e3 = d.w - t.w;
+      sse += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+      k01.x = ((Key)__float_as_uint(2.f * e0) << 32) | (k01.x & 0xffu);
+      k01.y = ((Key)__float_as_uint(2.f * e1) << 32) | (k01.y & 0xffu);
+      k23.x = ((Key)__float_as_uint(2.f * e2) << 32) | (k23.x & 0xffu);
+      k23.y = ((Key)__float_as_uint(2.f * e3) << 32) | (k23.y & 0xffu);
+      cell[0] = k01;
+      cell[1] = k23;
+    }
+    __syncthreads();
+
+    // ---- walk (backward): static slices, per-run DPP sums into the wave's LDS row ------------
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int cell_max = rh * LW - 1;
+    walk_my_slice<POW2, kSphereCostMse>(
+        wl, J, s_flag[1], wave, kZWaves, shares_bwd, lane, ax, ay, r0, LW,
+        [&](int j, const float4 s, int cell_a, int cell_b, float dx, float dya, float dyb, float qa, float qb,
+            bool has_b) {
+          auto take = [&](int cell, float dy, float q) {
+            const Key k = zbuf[min(cell, cell_max)];
+            if ((uint8_t)k == (uint8_t)j && q > 0.f) {
+              const float g = __uint_as_float((uint32_t)(k >> 32));
+              const float w = g * __builtin_amdgcn_rsqf(q);
+              a0 = __builtin_fmaf(-w, dx, a0);
+              a1 = __builtin_fmaf(-w, dy, a1);
+              a2 += g;
+              a3 -= w;
+            }
+          };
+          take(cell_a, dya, qa);
+          if (has_b) take(cell_b, dyb, qb);
+        },
+        [&](int j) {
+          const float sx = wave_sum_lane63(a0), sy = wave_sum_lane63(a1);
+          const float sz = wave_sum_lane63(a2), sw = wave_sum_lane63(a3);
+          if (lane == 63) {
+            float4 t = s_part[wave * SHR_MAX_SPHERES + j];
+            t.x += sx; t.y += sy; t.z += sz; t.w += sw;
+            s_part[wave * SHR_MAX_SPHERES + j] = t;
+          }
+          a0 = a1 = a2 = a3 = 0.f;
+        });
+  } else {
+    // ---- general path: the region's 32x8 tiles, owners and gradient in registers --------------
+    // (rows_per_region is a multiple of the tile height whenever there are several regions)
+    const int tiles_x = (W + kTileW - 1) / kTileW;
+    const int t0 = (r0 / kTileH) * tiles_x, t1 = ((r1 + kTileH - 1) / kTileH) * tiles_x;
+    float4 *acc = s_part + wave * SHR_MAX_SPHERES;
+    const float *tfull = tgt - (size_t)r0 * W;
+    float *ofull = out ? out - (size_t)r0 * W : nullptr;
+    for (int tile = t0 + wave; tile < t1; tile += kZWaves) {
+      const TileGeom g = tile_geom(tile, tiles_x, ax, ay, lane);
+      const unsigned long long mask = tile_candidates(sph, valid, g, ax, ay, H, W);
+      float best[4], bsq[4];
+      int owner[4];
+      tile_min<true>(mask, J, sph, g, best, owner, bsq);
+      const bool row_ok = g.v < H;
+      const size_t base = (size_t)g.v * W + g.u0;
+      float gk[4] = {0.f, 0.f, 0.f, 0.f};
+      if (row_ok && g.u0 < W) {   // W % 4 == 0 on this path
+        const float4 t = *reinterpret_cast<const float4 *>(tfull + base);
+        const float e0 = best[0] - t.x, e1 = best[1] - t.y, e2 = best[2] - t.z, e3 = best[3] - t.w;
+        sse += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+        gk[0] = 2.f * e0; gk[1] = 2.f * e1; gk[2] = 2.f * e2; gk[3] = 2.f * e3;
+        if (ofull) *reinterpret_cast<float4 *>(ofull + base) = make_float4(best[0], best[1], best[2], best[3]);
+      }
+      float px[4], py[4], pz[4], pw[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const bool in = row_ok && (g.u0 + k < W) && owner[k] != SHR_ARGMIN_NONE;
+        if (!in) owner[k] = SHR_ARGMIN_NONE;
+        const float w = in ? gk[k] / bsq[k] : 0.f;
+        pz[k] = in ? gk[k] : 0.f;
+        pw[k] = -w;
+        const float4 o = s_sph[in ? owner[k] : 0];
+        px[k] = -(w * (g.xg[k] - o.x));
+        py[k] = -(w * (g.yg - o.y));
+      }
+      unsigned long long m = mask;
+      while (m) {
+        const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+        m &= m - 1;
+        float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const bool mine = owner[k] == j;
+          any |= mine;
+          sx += mine ? px[k] : 0.f;
+          sy += mine ? py[k] : 0.f;
+          sz += mine ? pz[k] : 0.f;
+          sw += mine ? pw[k] : 0.f;
+        }
+        if (__ballot(any) == 0) continue;
+        sx = wave_sum_lane63(sx);
+        sy = wave_sum_lane63(sy);
+        sz = wave_sum_lane63(sz);
+        sw = wave_sum_lane63(sw);
+        if (lane == 63) {
+          float4 a = acc[j];
+          a.x += sx; a.y += sy; a.z += sz; a.w += sw;
+          acc[j] = a;
+        }
+      }
+    }
+  }
+
+  // ---- reductions: waves in order --------------------------------------------------------------
+  sse = wave_sum_lane63(sse);
+  __syncthreads();
+  float *s_wsum = reinterpret_cast<float *>(s_items);   // the work list is done with
+  if (lane == 63) s_wsum[wave] = sse;
+  __syncthreads();
+  const size_t slot = (size_t)n * nregions + region;
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kZWaves; w++) t += s_wsum[w];
+    sse_out[slot] = t;
+  }
+  if (tid < J) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int w = 0; w < kZWaves; w++) {
+      const float4 a = s_part[w * SHR_MAX_SPHERES + tid];
+      t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+    }
+    t.w = t.w * s_sph[tid].w;
+    grad_out[slot * J + tid] = t;
+  }
+}
+
 }  // namespace shr

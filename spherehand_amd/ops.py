@@ -94,23 +94,99 @@ class SphereDepthRaster(torch.autograd.Function):
         return sphere_raster_bwd(spheres, grad_depth.contiguous(), owner), None, None
 
 
-def data_to_model(depth, centres, radii, want_grad=False):
+def _check_index(index, n, m, name):
+    if index.dtype != torch.int32 or index.dim() != 1 or index.numel() != n or not index.is_cuda or not index.is_contiguous():
+        raise RuntimeError("%s must be a contiguous int32 CUDA tensor with one entry per crop" % name)
+    # (values are image numbers in [0, %d): the caller builds them, they are not read back here)
+
+
+def sphere_raster_mse_supported(spheres, target, H, W):
+    """True when shr_sphere_raster_mse takes these buffers (16-byte rows, image fits the kernel)."""
+    return (W % 4 == 0 and spheres.data_ptr() % 16 == 0 and target.data_ptr() % 16 == 0
+            and _lib.lib().shr_sphere_raster_mse_regions(int(H), int(W)) > 0)
+
+
+def sphere_raster_mse(spheres, target, target_index=None, want_depth=True):
+    """spheres [N,J,4], target [M,H,W] (crop n compares with image target_index[n], or n)
+    -> (depth [N,H,W] or None, sse [N], grad_spheres [N,J,4]) with sse[n] = sum over the
+    crop of (depth - target)^2 and grad_spheres = d sse[n] / d (x,y,z,r): the fused
+    render-and-compare kernel, no owner map / gradient image in HBM."""
+    _check_input(spheres, "spheres")
+    _check_input(target, "target")
+    if spheres.dim() != 3 or spheres.shape[2] != 4 or target.dim() != 3:
+        raise RuntimeError("spheres must be [N,J,4] and target [M,H,W]")
+    N, J, _ = spheres.shape
+    H, W = target.shape[1:]
+    if target_index is None and target.shape[0] != N:
+        raise RuntimeError("target must hold one image per crop unless target_index is given")
+    if target_index is not None:
+        _check_index(target_index, N, target.shape[0], "target_index")
+    R = _lib.lib().shr_sphere_raster_mse_regions(int(H), int(W))
+    if R <= 0:
+        raise RuntimeError("image rows too wide for the fused kernel (compose sphere_raster_fwd / _bwd)")
+    with torch.cuda.device(spheres.device):
+        depth = torch.empty((N, H, W), dtype=torch.float32, device=spheres.device) if want_depth else None
+        sse = torch.empty((N, R), dtype=torch.float32, device=spheres.device)
+        grad = torch.empty((N, R, J, 4), dtype=torch.float32, device=spheres.device)
+        _lib.check(_lib.lib().shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(target), _ptr(target_index),
+                                                    _ptr(depth), _ptr(sse), _ptr(grad), _stream()),
+                   "shr_sphere_raster_mse")
+        if R > 1:
+            sse, grad = sse.sum(1), grad.sum(1)
+        else:
+            sse, grad = sse.view(N), grad.view(N, J, 4)
+    return depth, sse, grad
+
+
+class SphereRasterSSE(torch.autograd.Function):
+    """(spheres [N,J,4], target [M,H,W], target_index [N] int32 or None) -> (sse [N], depth
+    [N,H,W]): per-crop sum of squared differences between the rendered spheres and an
+    observed depth image, with the rendered depth as a second, non-differentiable output.
+    The backward only scales the gradient the fused kernel already produced."""
+
+    @staticmethod
+    def forward(ctx, spheres, target, target_index=None):
+        spheres = spheres.contiguous()
+        depth, sse, grad = sphere_raster_mse(spheres, target.contiguous(), target_index)
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(depth)
+        ctx.set_materialize_grads(False)    # no zero image for the depth output's "gradient"
+        return sse, depth
+
+    @staticmethod
+    def backward(ctx, grad_sse, _grad_depth):
+        (grad,) = ctx.saved_tensors
+        if grad_sse is None:
+            return None, None, None
+        return grad * grad_sse.view(-1, 1, 1), None, None
+
+
+def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
     """depth [N,H,W], centres [N,J,3], radii [J] -> loss_sum [N] (and the unit
-    gradient d loss_sum[n]/d centres [N,J,3])."""
+    gradient d loss_sum[n]/d centres [N,J,3]).  With depth_index [N] int32, depth is
+    [M,H,W] and crop n reads image depth_index[n]."""
     _check_input(depth, "depth")
     _check_input(centres, "centres")
     _check_input(radii, "radii")
-    if depth.dim() != 3 or centres.dim() != 3 or centres.shape[2] != 3 or centres.shape[0] != depth.shape[0]:
+    if depth.dim() != 3 or centres.dim() != 3 or centres.shape[2] != 3:
         raise RuntimeError("depth must be [N,H,W] and centres [N,J,3]")
-    N, H, W = depth.shape
+    if depth_index is None and centres.shape[0] != depth.shape[0]:
+        raise RuntimeError("depth must be [N,H,W] and centres [N,J,3]")
+    N, (H, W) = centres.shape[0], depth.shape[1:]
     J = centres.shape[1]
     if radii.numel() != J:
         raise RuntimeError("radii must have J entries")
     with torch.cuda.device(depth.device):
         loss_sum = torch.empty(N, dtype=torch.float32, device=depth.device)
         grad = torch.empty((N, J, 3), dtype=torch.float32, device=depth.device) if want_grad else None
-        _lib.check(_lib.lib().shr_data_to_model(_ptr(depth), _ptr(centres), _ptr(radii), N, J, H, W,
-                                                _ptr(loss_sum), _ptr(grad), _stream()), "shr_data_to_model")
+        if depth_index is None:
+            _lib.check(_lib.lib().shr_data_to_model(_ptr(depth), _ptr(centres), _ptr(radii), N, J, H, W,
+                                                    _ptr(loss_sum), _ptr(grad), _stream()), "shr_data_to_model")
+        else:
+            _check_index(depth_index, N, depth.shape[0], "depth_index")
+            _lib.check(_lib.lib().shr_data_to_model_indexed(_ptr(depth), _ptr(depth_index), _ptr(centres), _ptr(radii),
+                                                            N, J, H, W, _ptr(loss_sum), _ptr(grad), _stream()),
+                       "shr_data_to_model_indexed")
     return (loss_sum, grad) if want_grad else loss_sum
 
 
@@ -120,22 +196,22 @@ class DataToModel(torch.autograd.Function):
     backward only scales it."""
 
     @staticmethod
-    def forward(ctx, depth, centres, radii):
+    def forward(ctx, depth, centres, radii, depth_index=None):
         depth = depth.contiguous()
         centres = centres.contiguous()
-        count = float(depth.numel())
+        count = float(centres.shape[0] * depth.shape[-2] * depth.shape[-1])   # pixels of the N crops
         if ctx.needs_input_grad[1]:
-            loss_sum, grad = data_to_model(depth, centres, radii, want_grad=True)
+            loss_sum, grad = data_to_model(depth, centres, radii, want_grad=True, depth_index=depth_index)
             ctx.save_for_backward(grad)
             ctx.count = count
         else:
-            loss_sum = data_to_model(depth, centres, radii)
+            loss_sum = data_to_model(depth, centres, radii, depth_index=depth_index)
         return (loss_sum.double().sum() / count).float()
 
     @staticmethod
     def backward(ctx, grad_out):
         (grad,) = ctx.saved_tensors
-        return None, grad * (grad_out / ctx.count), None
+        return None, grad * (grad_out / ctx.count), None, None
 
 
 class MutualProject(torch.autograd.Function):

@@ -133,3 +133,76 @@ def test_config5_per_gpu_shard_properties(oracle):
     gs = ops.sphere_raster_bwd(spheres, g, owner)
     fg_sum = (g.double() * (d < 100)).sum(dim=(1, 2))
     assert (gs[:, :, 2].double().sum(1) - fg_sum).abs().max().item() < 5e-3
+
+
+def _random_spheres(rs, n, j=41, spread=80.0):
+    sp = np.zeros((n, j, 4), np.float32)
+    sp[..., 0:2] = rs.uniform(-spread, spread, (n, j, 2))
+    sp[..., 2] = rs.uniform(-60, 60, (n, j))
+    sp[..., 3] = rs.uniform(6, 26, (n, j))
+    return sp
+
+
+@pytest.mark.parametrize("S,H", [(64, 64), (128, 128), (256, 256), (96, 72), (320, 200)])
+def test_fused_render_and_compare_equals_composition(S, H):
+    """shr_sphere_raster_mse == raster fwd + (depth - target)^2 + raster bwd (the unfused chain)."""
+    from spherehand_amd import ops
+    rs = np.random.RandomState(S + H)
+    n, m = 14, 5
+    sp = _random_spheres(rs, n)
+    sp[3, 7, 0] = np.nan                         # general path: NaN sphere
+    sp[5, :, 2] = 150.0                          # general path: no sphere in front of the background
+    sp[6, :, 0] = 1e4                            # nothing on screen
+    target = np.full((m, H, S), 100.0, np.float32)
+    target[:, H // 4: 3 * H // 4, S // 4: 3 * S // 4] = rs.uniform(-50, 50, (m, H // 2, S // 2))
+    index = rs.randint(0, m, n).astype(np.int32)
+    spd, tgd, ixd = dev(sp), dev(target), dev(index)
+    assert ops.sphere_raster_mse_supported(spd, tgd, H, S)
+    depth, sse, grad = ops.sphere_raster_mse(spd, tgd, ixd)
+    d_ref, owner = ops.sphere_raster_fwd(spd, H, S, want_argmin=True)
+    assert np.array_equal(bits(depth.cpu().numpy()), bits(d_ref.cpu().numpy()))          # NaNs included
+    e = d_ref - tgd[ixd.long()]
+    sse_ref = (e.double() ** 2).sum((1, 2)).cpu().numpy()
+    g_ref = np.zeros((n, 41, 4), np.float32)
+    fast = [k for k in range(n) if k not in (3, 5)]
+    g_ref[fast] = ops.sphere_raster_bwd(spd[fast].contiguous(), (2 * e)[fast].contiguous(), owner[fast].contiguous()).cpu().numpy()
+    g_ref[[3, 5]] = ops.sphere_raster_bwd(spd[[3, 5]].contiguous(), (2 * e)[[3, 5]].contiguous()).cpu().numpy()   # owners recomputed
+    s_, g_ = sse.cpu().numpy(), grad.cpu().numpy()
+    ok = np.isfinite(sse_ref)
+    assert np.array_equal(np.isfinite(s_), ok)
+    assert np.abs(s_[ok] - sse_ref[ok]).max() <= 2e-5 * np.abs(sse_ref[ok]).max()
+    okg = np.isfinite(g_ref)
+    assert np.array_equal(np.isfinite(g_), okg)
+    assert np.abs(g_[okg] - g_ref[okg]).max() <= 2e-5 * np.abs(g_ref[okg]).max() + 1e-3
+    # without the depth output
+    none, sse2, grad2 = ops.sphere_raster_mse(spd, tgd, ixd, want_depth=False)
+    assert none is None and torch.equal(torch.nan_to_num(sse2), torch.nan_to_num(sse))
+    assert torch.equal(torch.nan_to_num(grad2), torch.nan_to_num(grad))
+
+
+@pytest.mark.parametrize("is_mv", [True, False])
+def test_fused_mutual_projection_loss_equals_reference_wiring(is_mv):
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    g = golden("g4_mutual_projection.npz")
+    crit = MutualProjectionLoss(64, list(g["radii"])).cuda()
+    out = {}
+    for fused in (True, False):
+        crit.fused = fused
+        joints = dev(g["joints"]).requires_grad_(True)
+        loss, proj = crit(dev(g["cam"]), dev(g["inv_cam"]), joints, dev(g["real_dms"]), is_mv)
+        loss.backward()
+        out[fused] = (loss.item(), proj.detach().cpu().numpy(), joints.grad.cpu().numpy())
+    assert abs(out[True][0] - out[False][0]) <= 2e-6 * abs(out[False][0])
+    assert np.array_equal(bits(out[True][1]), bits(out[False][1]))
+    assert np.abs(out[True][2] - out[False][2]).max() <= 2e-5 * np.abs(out[False][2]).max()
+
+
+def test_data_to_model_indexed_equals_expanded():
+    from spherehand_amd import ops
+    g = golden("g5_data_to_model.npz")
+    dms, joints, radii = dev(g["a_dms"]), dev(g["a_joints"]), dev(g["a_radii"])
+    n = joints.shape[0]
+    index = torch.arange(n - 1, -1, -1, dtype=torch.int32, device="cuda")
+    a, ga = ops.data_to_model(dms, joints, radii, want_grad=True, depth_index=index)
+    b, gb = ops.data_to_model(dms[index.long()].contiguous(), joints, radii, want_grad=True)
+    assert torch.equal(a, b) and torch.equal(ga, gb)

@@ -42,3 +42,13 @@ print("HandSynthesizer B=48 S=64: %.1f us" % timeit(lambda: syn(p)))
 dr = DepthRender(mesh, 128).cuda()
 T = syn.hand_skeleton_transform(sample_poses(256, seed=1).cuda())
 print("DepthRender B=256 S=128: %.1f us  (%.0f crops/s)" % (timeit(lambda: dr(T), 20), 256 / timeit(lambda: dr(T), 20) * 1e6))
+# fused render-and-compare vs the separate forward + backward launches (batch 256, 128x128)
+import bench
+sph, grad = bench.make_inputs(0, torch.device("cuda:0"))
+tgt = torch.full((256, 128, 128), 100.0, device="cuda"); tgt[:, 32:96, 32:96] = 0.0
+d0, ow = ops.sphere_raster_fwd(sph, 128, 128, want_argmin=True)
+def unfused():
+    d, o = ops.sphere_raster_fwd(sph, 128, 128, want_argmin=True)
+    ops.sphere_raster_bwd(sph, grad, o)
+print("batch 256 @128x128: fwd + bwd launches %.1f us ; fused render-and-compare (sse + gradient + depth) %.1f us ; without the depth output %.1f us"
+      % (timeit(unfused, 200), timeit(lambda: ops.sphere_raster_mse(sph, tgt), 200), timeit(lambda: ops.sphere_raster_mse(sph, tgt, want_depth=False), 200)))
