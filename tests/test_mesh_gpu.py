@@ -158,3 +158,35 @@ def test_fused_depth_render_rand_f_and_batch():
         render.rasterizer.fused = False
         b = render(T, rf)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("S", [64, 128, 256, 200])
+def test_fused_depth_render_large_and_odd_faces(S):
+    """Synthetic soup the hand mesh never produces: faces wider than 32 sampled columns, faces
+    covering the whole image, slivers, faces partly or wholly outside, > 4096 faces (several
+    rounds), > 3584 work items per round -- against the explicit 640x640 chain."""
+    from spherehand_amd import ops
+    rs = np.random.RandomState(S)
+    B, NV, F = 3, 6000, 9000
+    v = np.zeros((B, NV, 4), np.float32)
+    v[..., 0:2] = rs.uniform(-80, 720, (B, NV, 2))
+    v[..., 2] = rs.uniform(-60, 140, (B, NV))
+    v[..., 3] = 1
+    v[:, 1::3, 0:2] = v[:, 0::3, 0:2] + rs.uniform(-14, 14, (B, NV // 3, 2))     # vertex triples: small faces
+    v[:, 2::3, 0:2] = v[:, 0::3, 0:2] + rs.uniform(-14, 14, (B, NV // 3, 2))
+    t = rs.randint(0, NV // 3, F)
+    faces = np.stack([3 * t, 3 * t + 1, 3 * t + 2], 1).astype(np.int32)
+    big = rs.rand(F) < 0.03                                                       # arbitrary vertices: huge faces
+    faces[big] = rs.randint(0, NV, (int(big.sum()), 3))
+    faces[0] = (0, 1, 2); v[:, 0, 0:3] = (-50, -50, 90); v[:, 1, 0:3] = (700, -40, 95); v[:, 2, 0:3] = (300, 720, 99)   # whole image
+    faces[1] = (2, 1, 0)                                                                                               # its back face
+    faces[2] = (3, 4, 5); v[:, 3, 0:3] = (10, 300, 50); v[:, 4, 0:3] = (630, 300.4, 50); v[:, 5, 0:3] = (320, 301, 50)   # sliver
+    vd, fd = dev(v), dev(faces)
+    fused = ops.mesh_depth_fwd(vd, fd, S, 640, 100.0)
+    raw = ops.tri_raster_indexed_fwd(640, 640, vd, fd)
+    chain = torch.nn.functional.interpolate(torch.clamp(raw, max=100.0).unsqueeze(1), size=(S, S), mode="bilinear",
+                                            align_corners=False).squeeze(1)
+    assert (fused < 100).float().mean().item() > 0.5
+    assert (fused - chain).abs().max().item() <= 1e-5 * max(1.0, chain.abs().max().item())
+    if S in (64, 128):
+        assert torch.equal(fused, chain)

@@ -206,3 +206,19 @@ def test_data_to_model_indexed_equals_expanded():
     a, ga = ops.data_to_model(dms, joints, radii, want_grad=True, depth_index=index)
     b, gb = ops.data_to_model(dms[index.long()].contiguous(), joints, radii, want_grad=True)
     assert torch.equal(a, b) and torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize("J", [1, 7, 64])
+def test_fused_render_and_compare_sphere_counts(J):
+    from spherehand_amd import ops
+    rs = np.random.RandomState(J)
+    sp = _random_spheres(rs, 9, J)
+    target = rs.uniform(-40, 100, (9, 64, 64)).astype(np.float32)
+    spd, tgd = dev(sp), dev(target)
+    depth, sse, grad = ops.sphere_raster_mse(spd, tgd)
+    d_ref, owner = ops.sphere_raster_fwd(spd, 64, 64, want_argmin=True)
+    assert torch.equal(depth, d_ref)
+    e = d_ref - tgd
+    g_ref = ops.sphere_raster_bwd(spd, (2 * e).contiguous(), owner)
+    assert (sse.double() - (e.double() ** 2).sum((1, 2))).abs().max().item() <= 2e-5 * sse.abs().max().item()
+    assert (grad - g_ref).abs().max().item() <= 2e-5 * g_ref.abs().max().item() + 1e-3
