@@ -188,7 +188,8 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
         const float dmin = __builtin_amdgcn_sqrtf((nx * nx + ny * ny) + nz * nz);
         const float dmax = __builtin_amdgcn_sqrtf((fx * fx + fy * fy) + fz * fz);
         const float lb = fmaxf(fmaxf(dmin - cj.w, cj.w - dmax), 0.f);
-        const bool odd = __ballot((e.a != e.a) || (e.b != e.b) || (e.c != e.c) || (lane < J && lb != lb)) != 0ull;
+        const bool odd = __ballot((e.a != e.a) || (e.b != e.b) || (e.c != e.c) ||
+                                  (lane < J && (lb != lb || cj.x != cj.x || cj.y != cj.y || cj.z != cj.z || cj.w != cj.w))) != 0ull;
         float best = 0.f;
         int bj = 0;
         auto surface_distance = [&](int j) {   // lanes = points, sphere j's record through SGPRs
@@ -229,7 +230,7 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
             if (a < best || (a == best && j < bj)) { best = a; bj = j; }
           }
         }
-        if (act) loss += fminf(fmaxf(best, 0.f), 50.f);
+        if (act) loss += (best != best) ? best : fminf(fmaxf(best, 0.f), 50.f);   // torch.clamp keeps NaN
         if (WANT_GRAD) {
           float gx = 0.f, gy = 0.f, gz = 0.f;
           int owner = -1;

@@ -79,3 +79,38 @@ def test_data_to_model_module_autograd():
     # list-of-radii constructor (mesh/render.py:114-115)
     crit2 = DataToModelLoss(64, 64, list(g["a_radii"])).cuda()
     assert abs(crit2(dev(g["a_dms"]), dev(g["a_joints"])).item() - loss.item()) < 1e-9
+
+
+@pytest.mark.parametrize("fit", ["good", "bad", "nan", "far"])
+def test_data_to_model_fits_and_nan_vs_oracle(oracle, fit):
+    """A well fitting model, a badly fitting one, a NaN sphere (torch.min / clamp propagate it: that crop's
+    loss is NaN) and a model far from every pixel (everything clamps at 50, no gradient)."""
+    from spherehand_amd import ops
+    rs = np.random.RandomState(len(fit))
+    n, J, S = 6, 41, 64
+    sp = np.zeros((n, J, 4), np.float32)
+    sp[..., 0:2] = rs.uniform(-70, 70, (n, J, 2))
+    sp[..., 2] = rs.uniform(-40, 40, (n, J))
+    sp[..., 3] = rs.uniform(8, 24, J)[None]
+    depth = ops.sphere_raster_fwd(dev(sp), S, S).cpu().numpy()                     # observed = the model rendered
+    depth = np.where(depth < 99, depth + rs.normal(0, 2.0, depth.shape).astype(np.float32), depth).astype(np.float32)
+    centres = sp[..., 0:3].copy()
+    if fit == "bad":
+        centres += rs.normal(0, 25.0, centres.shape).astype(np.float32)
+    elif fit == "nan":
+        centres[2, 5, 1] = np.nan
+    elif fit == "far":
+        centres[..., 2] += 400.0
+    else:
+        centres += rs.normal(0, 1.0, centres.shape).astype(np.float32)
+    radii = sp[0, :, 3].copy()
+    loss, grad = [t.cpu().numpy() for t in ops.data_to_model(dev(depth), dev(centres), dev(radii), want_grad=True)]
+    ref = oracle.data_to_model_fwd(depth, centres, radii)
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(loss), ok) and (fit != "nan" or not ok[2])
+    assert np.abs(loss[ok] - ref[ok]).max() <= 2e-5 * np.abs(ref[ok]).max()
+    if fit == "far":
+        assert np.allclose(loss, 50.0 * (depth <= 99).sum((1, 2)), rtol=1e-6) and np.abs(grad).max() == 0
+    if fit in ("good", "bad"):
+        gref = oracle.data_to_model_bwd(depth, centres, radii) * (n * S * S)         # oracle returns d mean / d centres
+        assert np.abs(grad - gref).max() <= 2e-5 * np.abs(gref).max() + 1e-4
