@@ -26,6 +26,8 @@ names = ["T1 staging issued+list", "T2 after barrier (staged)", "T3 walk done", 
 for i, nm in enumerate(names, 1):
     d = t[:, :, i] - t[:, :, 0]
     print("%-26s mean %8.0f  min %8.0f  max %8.0f" % (nm, d.mean(), d.min(), d.max()))
+d = t[:, :, 5] - t[:, :, 0]
+print("%-26s mean %8.0f  min %8.0f  max %8.0f" % ("TS records arrived", d.mean(), d.min(), d.max()))
 w = t[:, :, 3] - t[:, :, 2]
 print("walk cycles by wave (mean):", np.round(w.mean(0)).astype(int).tolist())
 s1 = t[:, :, 1] - t[:, :, 0]
