@@ -16,18 +16,22 @@
 //             made monotonic; with OWNER the sphere index is packed in the low
 //             word of a 64-bit key, so ds_min_u64 also yields the first-index
 //             owner on exact depth ties).  Wave 0 turns the spheres into a work
-//             list of 16x4-pixel patches (lanes = spheres: pixel box, patch
-//             count, prefix sum); the 16 waves then take equal contiguous slices
-//             of that list (lanes = pixels): exact reference arithmetic per
-//             pixel, one LDS atomic min per hit.  Finally the z-buffer is decoded
-//             and streamed out with full-line 16-byte stores -- the only HBM
-//             traffic besides the 16*J-byte sphere read.
-//   backward  one workgroup per crop.  grad_depth and the forward's owner map are
-//             staged into LDS with coalesced 16-byte loads; the waves walk the
-//             same balanced patch list, accumulate the four partials of the
-//             pixels a sphere owns in registers, one DPP wave-sum per (wave,
-//             sphere) segment into a private LDS slot, slots combined in wave
-//             order: deterministic, no float atomics.
+//             list of row-packed 64-lane chunks (lanes = spheres: pixel box,
+//             packing, prefix sum) while waves 1-7 store the rows no sphere
+//             touches straight from registers; the 16 waves then take contiguous
+//             slices of the list (lanes = pixels): exact reference arithmetic per
+//             pixel, one LDS atomic min per hit.  Finally the touched rows are
+//             decoded and streamed out with full-line 16-byte nt stores -- the
+//             only HBM traffic besides the 16*J-byte sphere read.
+//   backward  one workgroup per crop.  The rows some sphere touches of grad_depth
+//             and of the forward's owner map are staged into LDS (the central half
+//             speculatively with the records, the rest once they are in); the
+//             waves walk the same chunk list in static slices, accumulate the
+//             four partials of the pixels a sphere owns in registers, one DPP
+//             wave-sum per (wave, sphere) run into a private LDS slot, slots
+//             combined in wave order: deterministic, no float atomics.
+//   fused     forward + (depth - target)^2 + backward in one kernel for the
+//             model->data term of MutualProjectionLoss (sphere_zbuf_mse_kernel).
 //
 // Exactness: the per-pixel arithmetic is the reference's operation sequence
 // (common.h, -ffp-contract=off; sqrt_rn() is a correctly rounded square root).
@@ -42,8 +46,6 @@
 namespace shr {
 
 constexpr int kZWaves = 16;   // 1024 threads
-constexpr int kPatchW = 16;   // lanes along x
-constexpr int kPatchH = 4;    // lanes along y
 constexpr int kRowPad = 8;    // LDS row padding (elements): chunk rows start in different banks (no lane writes there)
 constexpr int kPadRows = 0;   // rows after the region's last (none: a chunk never overhangs its box)
 constexpr int kBgWaves = 7;   // forward: waves that store the background rows before the first barrier
