@@ -49,6 +49,8 @@ constexpr int kZWaves = 16;   // 1024 threads
 constexpr int kRowPad = 8;    // LDS row padding (elements): chunk rows start in different banks (no lane writes there)
 constexpr int kPadRows = 0;   // rows after the region's last (none: a chunk never overhangs its box)
 constexpr int kBgWaves = 7;   // forward: waves that store the background rows before the first barrier
+// (storing them after the barrier instead, with smaller list shares for those waves, moves the barrier from 4.6 k
+// to 3.8 k cycles but the stores then cost the scan conversion more than that: measured 8.9 vs 8.6 us)
 // LDS header: spheres [64] float4 | work items [64] int4 | ends [64] int | flags
 constexpr int kOffItems = 1024;
 constexpr int kOffEnds = 2048;
@@ -108,13 +110,14 @@ __device__ __forceinline__ void axis_box(float c, float ar, float k, float half,
   i1 = min((int)floorf(fminf(fmaxf(hi + eps, -2.f), hi_clamp)), hi_lim);
 }
 
-__device__ __forceinline__ Item sphere_item(const float4 s, const Axis &ax, const Axis &ay, int W, int r0,
-                                            int r1) {
+// (kx, ky = size / 300 per axis: wave-uniform, computed by the caller before the records arrive)
+__device__ __forceinline__ Item sphere_item(const float4 s, const Axis &ax, const Axis &ay, float kx, float ky, int W,
+                                            int r0, int r1) {
   int u0 = 0, u1 = W - 1, v0 = r0, v1 = r1 - 1;
   if (sphere_is_tame(s)) {
     const float ar = fabsf(s.w);
-    axis_box(s.x, ar, ax.size / 300.0f, ax.half, (float)W + 2.f, 0, W - 1, u0, u1);
-    axis_box(s.y, ar, ay.size / 300.0f, ay.half, (float)r1 + 2.f, r0, r1 - 1, v0, v1);
+    axis_box(s.x, ar, kx, ax.half, (float)W + 2.f, 0, W - 1, u0, u1);
+    axis_box(s.y, ar, ky, ay.half, (float)r1 + 2.f, r0, r1 - 1, v0, v1);
   }
   Item it;
   it.u0 = u0; it.v0 = v0; it.u1 = u1; it.v1 = v1;
@@ -122,12 +125,15 @@ __device__ __forceinline__ Item sphere_item(const float4 s, const Axis &ax, cons
   if (w <= 0 || h <= 0) {
     it.pw = 1; it.ph = 1; it.ncx = 0; it.nchunks = 0;
   } else {
-    // (small integer quotients through fp32: the exact quotient is never within 1/128 of
-    // the wrong integer, the division error is 2^-24 relative)
+    // Small integer quotients through v_rcp_f32 (1 ulp): floor(64 / pw) -- the exact quotient is an
+    // integer or at least 1/64 below the next one, so + 0.01 then truncation is exact; ceil(h / ph) =
+    // floor((h + ph - 1 + 0.5) / ph) -- at least 1/128 from an integer, the error stays below that
+    // for h < 16384 (taller boxes take the IEEE division).
     it.pw = min(w, kWave);
-    it.ph = (int)(64.0f / (float)it.pw);
+    it.ph = (int)(64.0f * __builtin_amdgcn_rcpf((float)it.pw) + 0.01f);
     it.ncx = w > kWave ? (w + kWave - 1) >> 6 : 1;
-    const int ngr = (int)(((float)(h + it.ph - 1) + 0.5f) / (float)it.ph);
+    const float hh = (float)(h + it.ph - 1) + 0.5f;
+    const int ngr = h < 16384 ? (int)(hh * __builtin_amdgcn_rcpf((float)it.ph)) : (int)(hh / (float)it.ph);
     it.nchunks = ngr * it.ncx;
   }
   return it;
@@ -154,9 +160,9 @@ constexpr int kSphereCostBwd = 36;   // ... plus four wave reductions when a run
 // H <= 32768.
 template <int kSphereCost>
 __device__ __forceinline__ int build_work_list(const float4 s, bool valid, const Axis &ax, const Axis &ay,
-                                               int W, int r0, int r1, int4 *s_items, int *s_ends, int lane,
-                                               bool *too_big) {
-  const Item it = sphere_item(s, ax, ay, W, r0, r1);
+                                               float kx, float ky, int W, int r0, int r1, int4 *s_items,
+                                               int *s_ends, int lane, bool *too_big) {
+  const Item it = sphere_item(s, ax, ay, kx, ky, W, r0, r1);
   const int nchunks = valid ? it.nchunks : 0;
   const int cost = nchunks > 0 ? kSphereCost + nchunks * kChunkCost : 0;
   // inclusive scan over the 64 lanes: 4 DPP steps inside each row of 16, then the
@@ -323,13 +329,13 @@ template <> struct KeyOf<true> { using type = unsigned long long; };
 // spheres by any wave from its own copy of the records: same instructions on the same inputs,
 // so every wave of the workgroup gets the same answer without an LDS exchange.  A crop that
 // takes the general path reports the whole region (nothing is known to be background).
-__device__ __forceinline__ void touched_rows(const float4 s, bool valid, const Axis &ay, int r0, int r1, int &cv0,
-                                             int &cv1) {
+__device__ __forceinline__ void touched_rows(const float4 s, bool valid, const Axis &ay, float ky, int r0, int r1,
+                                             int &cv0, int &cv1) {
   const bool tame = sphere_is_tame(s);
   const unsigned long long bad = __ballot(valid && !(tame && fabsf(s.z) < 1e30f));
   const unsigned long long low = __ballot(valid && s.z <= kBackground);
   int v0 = r0, v1 = r1 - 1;
-  if (tame) axis_box(s.y, fabsf(s.w), ay.size / 300.0f, ay.half, (float)r1 + 2.f, r0, r1 - 1, v0, v1);
+  if (tame) axis_box(s.y, fabsf(s.w), ky, ay.half, (float)r1 + 2.f, r0, r1 - 1, v0, v1);
   const bool on = valid && v1 >= v0;   // row numbers are < 2^24: exact in fp32
   cv0 = (int)wave_minmax_all<true>(on ? (float)v0 : 1e9f);
   cv1 = (int)wave_minmax_all<false>(on ? (float)v1 : -1e9f);
@@ -367,6 +373,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
   const int rh = r1 - r0;
   const int LW = W + kRowPad;
   const Axis ax = make_axis(W), ay = make_axis(H);
+  const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
 
   // every wave keeps the crop's records in registers, lane j = sphere j (one 656-byte line
   // set, served to the later waves by the L2)
@@ -408,7 +415,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
     const unsigned long long bad = __ballot(valid && !(sphere_is_tame(sph) && fabsf(sph.z) < 1e30f));
     const unsigned long long low = __ballot(valid && sph.z <= kBackground);
     bool too_big;   // excluded by the launcher (W <= kMaxFastWidth, H <= 32768)
-    const int total = build_work_list<kSphereCostFwd>(sph, valid, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
+    const int total = build_work_list<kSphereCostFwd>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
     if (lane == 0) {
       s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
       s_flag[1] = total;
@@ -428,7 +435,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
   // units [0, ua) and [ub, nunits) lie entirely in background rows, [ua, ub) is touched
   int ua = 0, ub = nunits;
   if (VEC4 && bg_wave) {
-    touched_rows(sph, valid, ay, r0, r1, cv0, cv1);
+    touched_rows(sph, valid, ay, ky, r0, r1, cv0, cv1);
     if (cv1 < cv0) ua = ub = nunits;
     else { ua = ((cv0 - r0) * w4) >> 6; ub = min(nunits, ((cv1 - r0 + 1) * w4 + 63) >> 6); }
     ua = rfl(ua);
@@ -570,6 +577,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   const float *gin = grad_depth + (size_t)n * H * W;
   const uint8_t *oin = argmin + (size_t)n * H * W;
   const Axis ax = make_axis(W), ay = make_axis(H);
+  const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
   typedef float v4f __attribute__((ext_vector_type(4)));
   const int wave_s = rfl(wave);
   // Every wave requests the crop's records (lane j = sphere j) with an explicit instruction so
@@ -635,12 +643,12 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     }
     if (wave_s == 0) {
       bool too_big;   // excluded by the launcher (W <= kMaxFastWidth)
-      const int total = build_work_list<kSphereCostBwd>(sph, lane < J, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
+      const int total = build_work_list<kSphereCostBwd>(sph, lane < J, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
       if (lane == 0) s_flag[1] = total;
     }
     if (VEC4) {
       int cv0, cv1;
-      touched_rows(sph, lane < J, ay, r0, r1, cv0, cv1);
+      touched_rows(sph, lane < J, ay, ky, r0, r1, cv0, cv1);
       // a patch row may overhang its sphere's box by kPadRows rows: those owners are read too
       int ua = nunits, ub = nunits;
       if (cv1 >= cv0) { ua = ((cv0 - r0) * w4) >> 6; ub = min(nunits, ((min(cv1 + kPadRows, r1 - 1) - r0 + 1) * w4 + 63) >> 6); }
@@ -795,6 +803,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
   const int rh = r1 - r0;
   const int LW = W + kRowPad;
   const Axis ax = make_axis(W), ay = make_axis(H);
+  const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
   const float *tgt = target + (size_t)(target_index ? target_index[n] : n) * H * W + (size_t)r0 * W;
   float *out = depth ? depth + (size_t)n * H * W + (size_t)r0 * W : nullptr;
 
@@ -820,7 +829,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
   const bool bg_wave = wave_s >= 1 && wave_s <= kBgWaves;
   if (bg_wave) {   // rows no sphere touches: depth = background, stored while wave 0 builds the list
     int cv0, cv1;
-    touched_rows(sph, valid, ay, r0, r1, cv0, cv1);
+    touched_rows(sph, valid, ay, ky, r0, r1, cv0, cv1);
     if (cv1 < cv0) ua = ub = nunits;
     else { ua = ((cv0 - r0) * w4) >> 6; ub = min(nunits, ((cv1 - r0 + 1) * w4 + 63) >> 6); }
     ua = rfl(ua);
@@ -841,7 +850,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
     const unsigned long long bad = __ballot(valid && !(sphere_is_tame(sph) && fabsf(sph.z) < 1e30f));
     const unsigned long long low = __ballot(valid && sph.z <= kBackground);
     bool too_big;
-    const int total = build_work_list<kSphereCostMse>(sph, valid, ax, ay, W, r0, r1, s_items, s_ends, lane, &too_big);
+    const int total = build_work_list<kSphereCostMse>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
     if (lane == 0) {
       s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
       s_flag[1] = total;
