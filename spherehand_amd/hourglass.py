@@ -10,6 +10,8 @@ stem + stacks) so that its checkpoints (`network_state_dict` with keys
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .ops import group_norm_relu
+
 
 class Bottleneck(nn.Module):
     """GN-ReLU-1x1 -> GN-ReLU-3x3 -> GN-ReLU-1x1 (x2 channels) + skip."""
@@ -26,9 +28,9 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        y = self.conv1(F.relu(self.bn1(x)))
-        y = self.conv2(F.relu(self.bn2(y)))
-        y = self.conv3(F.relu(self.bn3(y)))
+        y = self.conv1(group_norm_relu(x, self.bn1))        # NHWC GroupNorm+ReLU kernel on the GPU path
+        y = self.conv2(group_norm_relu(y, self.bn2))
+        y = self.conv3(group_norm_relu(y, self.bn3))
         return y + (x if self.downsample is None else self.downsample(x))
 
 
@@ -93,12 +95,12 @@ class HourglassNet(nn.Module):
         """x [N,S,S] or [N,1,S,S] -> ([scores [N,num_outputs,S/4,S/4]] per stack, [latent] per stack)."""
         if x.dim() == 3:
             x = x.unsqueeze(1)
-        x = self.layer1(F.relu(self.bn1(self.conv1(x))))
+        x = self.layer1(group_norm_relu(self.conv1(x), self.bn1))
         x = self.layer3(self.layer2(F.max_pool2d(x, 2, stride=2)))
         out, latents = [], []
         for i in range(self.num_stacks):
             y, latent = self.hg[i](x)
-            y = self.fc[i](self.res[i](y))
+            y = group_norm_relu(self.fc[i][0](self.res[i](y)), self.fc[i][1])   # fc = Conv-GN-ReLU (keys unchanged)
             score = self.score[i](y)
             out.append(score)
             latents.append(latent)

@@ -341,3 +341,54 @@ def mesh_depth_fwd(vertices, faces, out_size, src_size=640, clamp_max=100.0):
         _lib.check(_lib.lib().shr_mesh_depth_fwd(_ptr(vertices), _ptr(faces), B, NV, faces.shape[0], src_size, out_size,
                                                  clamp_max, _ptr(depth), _stream()), "shr_mesh_depth_fwd")
     return depth
+
+
+def group_norm_relu_supported(x, num_groups):
+    """True when the NHWC GroupNorm+ReLU kernels take this activation (CUDA fp32, channels-last)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] > 0
+            and x.is_contiguous(memory_format=torch.channels_last)
+            and bool(_lib.lib().shr_group_norm_relu_supported(int(x.shape[1]), int(num_groups))))
+
+
+class GroupNormReLU(torch.autograd.Function):
+    """relu(group_norm(x, G, weight, bias, eps)) on channels-last activations
+    (network/hourglass.py:28-31), one kernel per direction."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, num_groups, eps):
+        N, C, H, W = x.shape
+        weight, bias = weight.contiguous(), bias.contiguous()
+        with torch.cuda.device(x.device):
+            y = torch.empty_like(x, memory_format=torch.channels_last)
+            mean = torch.empty((N, num_groups), dtype=torch.float32, device=x.device)
+            rstd = torch.empty((N, num_groups), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().shr_group_norm_relu_fwd(_ptr(x), _ptr(weight), _ptr(bias), N, C, H * W, num_groups,
+                                                          float(eps), _ptr(y), _ptr(mean), _ptr(rstd), _stream()),
+                       "shr_group_norm_relu_fwd")
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        ctx.num_groups = num_groups
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, mean, rstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            dg = torch.empty((N, C), dtype=torch.float32, device=x.device)
+            db = torch.empty((N, C), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().shr_group_norm_relu_bwd(_ptr(x), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(mean),
+                                                          _ptr(rstd), N, C, H * W, ctx.num_groups, _ptr(dx), _ptr(dg),
+                                                          _ptr(db), _stream()), "shr_group_norm_relu_bwd")
+        return dx, dg.sum(0), db.sum(0), None, None
+
+
+FUSED_GROUP_NORM_RELU = True    # False: always torch's group_norm + relu (A/B measurements)
+
+
+def group_norm_relu(x, gn):
+    """F.relu(gn(x)) for an nn.GroupNorm `gn`: the NHWC kernels when they apply, torch otherwise."""
+    if FUSED_GROUP_NORM_RELU and gn.affine and group_norm_relu_supported(x, gn.num_groups):
+        return GroupNormReLU.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps)
+    return torch.nn.functional.relu(gn(x))

@@ -1,0 +1,51 @@
+"""NHWC GroupNorm+ReLU kernels (network/hourglass.py:28-31 pairs) vs torch's group_norm + relu."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,C,H,W,G", [(5, 64, 32, 32, 4), (5, 64, 32, 32, 16), (7, 128, 16, 16, 16), (3, 128, 4, 4, 16),
+                                       (4, 256, 8, 8, 16), (2, 256, 16, 16, 8), (3, 32, 5, 7, 8)])
+def test_group_norm_relu_matches_torch(N, C, H, W, G):
+    from spherehand_amd import ops
+    g = torch.Generator().manual_seed(N * C + G)
+    x = (torch.randn(N, C, H, W, generator=g) * 3 + 1).cuda().to(memory_format=torch.channels_last).requires_grad_(True)
+    gn = torch.nn.GroupNorm(G, C).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C, generator=g)); gn.bias.copy_(torch.randn(C, generator=g) * 0.5)
+    up = torch.randn(N, C, H, W, generator=g).cuda().to(memory_format=torch.channels_last)
+    assert ops.group_norm_relu_supported(x, G)
+    y = ops.group_norm_relu(x, gn)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    (y * up).sum().backward()
+    got = (y.detach(), x.grad.clone(), gn.weight.grad.clone(), gn.bias.grad.clone())
+    x.grad = None; gn.weight.grad = None; gn.bias.grad = None
+    xd = x.detach().double().requires_grad_(True)
+    gd = torch.nn.GroupNorm(G, C).cuda().double()
+    gd.load_state_dict({k: v.double() for k, v in gn.state_dict().items()})
+    yr = torch.relu(gd(xd))
+    (yr * up.double()).sum().backward()
+    ref = (yr.detach(), xd.grad, gd.weight.grad, gd.bias.grad)
+    for a, b, tol in zip(got, ref, (2e-6, 2e-5, 2e-5, 2e-5)):
+        assert (a.double() - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+
+
+def test_group_norm_relu_falls_back_outside_its_shapes():
+    from spherehand_amd import ops
+    x = torch.randn(2, 48, 8, 8).cuda()                                    # NCHW, C % 32 != 0
+    gn = torch.nn.GroupNorm(4, 48).cuda()
+    assert not ops.group_norm_relu_supported(x, 4)
+    assert torch.equal(ops.group_norm_relu(x, gn), torch.relu(gn(x)))
+
+
+def test_hourglass_gpu_matches_cpu_reference_path():
+    """The network with the kernels (GPU, channels-last) against itself on torch ops only (CPU)."""
+    from spherehand_amd.hourglass import create_hourglass_network
+    torch.manual_seed(0)
+    net = create_hourglass_network(82, 1)
+    x = torch.randn(3, 1, 64, 64)
+    ref, _ = net(x)
+    out, _ = net.cuda().to(memory_format=torch.channels_last)(x.cuda().to(memory_format=torch.channels_last))
+    assert (out[0].cpu() - ref[0]).abs().max().item() <= 2e-4 * ref[0].abs().max().item()

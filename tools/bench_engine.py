@@ -19,7 +19,7 @@ eng.network.train()
 real = [torch.stack([ds[i][k] for i in range(25)]) for k in range(4)]
 pose = sample_poses(48, seed=1)
 def T(fn, reps=20):
-    for _ in range(3): fn()
+    for _ in range(10): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
@@ -36,3 +36,33 @@ def losses():
     xyz.grad = None
     l, _ = eng.criterion.mv_projection_loss(cam, inv, xyz, orig, True); l.backward()
 print("MutualProjectionLoss fwd+bwd (225 crops):       %.2f ms" % T(losses))
+# cumulative sections of the step (each timed with a device sync at the end)
+dev = eng.env.device
+def upto(stage):
+    def f():
+        synt_dms, uv_hms, d_hms, xyz_t = eng.hand_synthesizer(pose.to(dev))
+        if stage == 0: return
+        scaled, orig, gt, cam, inv = eng._prepare_real(real)
+        if stage == 1: return
+        eng.optimizer.zero_grad(set_to_none=True)
+        result = eng.ddp_network(synt_dms=synt_dms, real_dms=scaled)
+        if stage == 2: return
+        terms, _ = eng.criterion(result, synt_target={'uv_hms': uv_hms, 'd_hms': d_hms, 'xyz_pts': xyz_t},
+                                 real_target={'real_dms': orig, 'camera_poses': cam, 'inv_camera_poses': inv, 'is_mv': True})
+        if stage == 3: return
+        from spherehand_amd.engine import combine_loss
+        combine_loss(terms).backward()
+        if stage == 4: return
+        eng.optimizer.step()
+    return f
+names = ["synthesizer", "+ prepare real batch", "+ network forward (augment, hourglass, xyz)", "+ criterion forward",
+         "+ backward", "+ Adam step"]
+prev = 0.0
+for i, nm in enumerate(names):
+    t = T(upto(i))
+    print("%-46s %6.2f ms (+%.2f)" % (nm, t, t - prev)); prev = t
+from spherehand_amd import ops
+for fused in (True, False, True):
+    ops.FUSED_GROUP_NORM_RELU = fused
+    print("full step, NHWC GroupNorm+ReLU kernels %-5s     %.2f ms ; hourglass fwd+bwd %.2f ms"
+          % (fused, T(lambda: eng.step(real, pose, True, True)), T(cnn)))
