@@ -132,8 +132,8 @@ int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W,
  * backward: the `F.relu(self.bnK(x))` pairs of network/hourglass.py:28-31 without the NCHW
  * round trips of torch's GroupNorm.  G groups of C/G consecutive channels, biased variance,
  * eps inside the root (torch.nn.GroupNorm).  mean / rstd are [N][G] (saved for the backward).
- * The backward returns dx and PER-SAMPLE partials dgamma_partial / dbeta_partial [N][C] (the
- * caller sums them over N).  shr_group_norm_relu_supported: C % 32 == 0 and C/G in
+ * The backward returns dx, PER-SAMPLE partials dgamma_partial / dbeta_partial [N][C] and, when
+ * dgamma / dbeta [C] are not NULL, their sums over the samples (in order: deterministic).  shr_group_norm_relu_supported: C % 32 == 0 and C/G in
  * {4, 8, 16, 32}; buffers 16-byte aligned. */
 int shr_group_norm_relu_supported(int C, int G);
 int shr_group_norm_relu_fwd(const float *x, const float *gamma, const float *beta,
@@ -142,7 +142,8 @@ int shr_group_norm_relu_fwd(const float *x, const float *gamma, const float *bet
 int shr_group_norm_relu_bwd(const float *x, const float *dy, const float *gamma,
                             const float *beta, const float *mean, const float *rstd,
                             int N, int C, int HW, int G, float *dx,
-                            float *dgamma_partial, float *dbeta_partial, void *stream);
+                            float *dgamma_partial, float *dbeta_partial,
+                            float *dgamma, float *dbeta, void *stream);
 
 
 /* View-to-view projection of the sphere centres ---------------------------------

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (device memory, streams: the plumbing this library s
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libspherehand_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -34,7 +34,7 @@ SIGNATURES = {
     "shr_sphere_raster_mse_regions": ([_i, _i], _i),
     "shr_group_norm_relu_supported": ([_i, _i], _i),
     "shr_group_norm_relu_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp], _i),
-    "shr_group_norm_relu_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
+    "shr_group_norm_relu_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "shr_sphere_raster_mse": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "shr_mutual_project_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "shr_mutual_project_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),

@@ -155,6 +155,32 @@ group_norm_relu_bwd_kernel(const float *__restrict__ x, const float *__restrict_
   }
 }
 
+// dgamma[c] = sum_n dgamma_part[n][c] (same for dbeta).  32 channels x 8 sample-lanes per
+// workgroup: lane s sums the samples n = s (mod 8), the eight partial sums are added in order:
+// deterministic.
+__global__ void __launch_bounds__(256)
+group_norm_param_grad_kernel(const float *__restrict__ dg_part, const float *__restrict__ db_part, int N, int C,
+                             float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  __shared__ float s_a[8][32], s_b[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float a = 0.f, b = 0.f;
+  if (c < C) {
+#pragma unroll 4
+    for (int n = sl; n < N; n += 8) { a += dg_part[(size_t)n * C + c]; b += db_part[(size_t)n * C + c]; }
+  }
+  s_a[sl][cl] = a;
+  s_b[sl][cl] = b;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    float ta = 0.f, tb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { ta += s_a[k][cl]; tb += s_b[k][cl]; }
+    dgamma[c] = ta;
+    dbeta[c] = tb;
+  }
+}
+
 bool gn_supported(int C, int G) {
   if (C <= 0 || G <= 0 || C % G || C % kGnBlockC) return false;
   const int cpg = C / G;
@@ -179,7 +205,8 @@ extern "C" int shr_group_norm_relu_fwd(const float *x, const float *gamma, const
 
 extern "C" int shr_group_norm_relu_bwd(const float *x, const float *dy, const float *gamma, const float *beta,
                                        const float *mean, const float *rstd, int N, int C, int HW, int G, float *dx,
-                                       float *dgamma_partial, float *dbeta_partial, void *stream) {
+                                       float *dgamma_partial, float *dbeta_partial, float *dgamma, float *dbeta,
+                                       void *stream) {
   using namespace shr;
   if (N == 0) return SHR_OK;
   if (!x || !dy || !gamma || !beta || !mean || !rstd || !dx || !dgamma_partial || !dbeta_partial || N < 0 || HW <= 0)
@@ -191,5 +218,8 @@ extern "C" int shr_group_norm_relu_bwd(const float *x, const float *dy, const fl
   if (N > 65535) return SHR_ETOOLARGE;
   hipLaunchKernelGGL(group_norm_relu_bwd_kernel, dim3((unsigned)(C / kGnBlockC), (unsigned)N), dim3(kGnThreads), 0,
                      (hipStream_t)stream, x, dy, gamma, beta, mean, rstd, C, HW, G, dx, dgamma_partial, dbeta_partial);
+  if (dgamma && dbeta)
+    hipLaunchKernelGGL(group_norm_param_grad_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
+                       dgamma_partial, dbeta_partial, N, C, dgamma, dbeta);
   return (int)hipGetLastError();
 }

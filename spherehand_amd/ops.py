@@ -376,12 +376,13 @@ class GroupNormReLU(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         with torch.cuda.device(x.device):
             dx = torch.empty_like(x, memory_format=torch.channels_last)
-            dg = torch.empty((N, C), dtype=torch.float32, device=x.device)
-            db = torch.empty((N, C), dtype=torch.float32, device=x.device)
+            part = torch.empty((2, N, C), dtype=torch.float32, device=x.device)     # per-sample partials (workspace)
+            dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
             _lib.check(_lib.lib().shr_group_norm_relu_bwd(_ptr(x), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(mean),
-                                                          _ptr(rstd), N, C, H * W, ctx.num_groups, _ptr(dx), _ptr(dg),
-                                                          _ptr(db), _stream()), "shr_group_norm_relu_bwd")
-        return dx, dg.sum(0), db.sum(0), None, None
+                                                          _ptr(rstd), N, C, H * W, ctx.num_groups, _ptr(dx),
+                                                          _ptr(part[0]), _ptr(part[1]), _ptr(dgb[0]), _ptr(dgb[1]),
+                                                          _stream()), "shr_group_norm_relu_bwd")
+        return dx, dgb[0], dgb[1], None, None
 
 
 FUSED_GROUP_NORM_RELU = True    # False: always torch's group_norm + relu (A/B measurements)
