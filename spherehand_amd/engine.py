@@ -154,7 +154,10 @@ class Engine:
         self.real_batch = getattr(opts, 'real_batch', 25)
         self.synt_batch = getattr(opts, 'synt_batch', 48)
         self.steps_per_epoch = getattr(opts, 'steps_per_epoch', None)
-        self.optimizer = torch.optim.Adam(self.network.parameters(), lr=opts.lr, weight_decay=1e-5)
+        # network/engine.py:100: Adam(lr, weight_decay=1e-5); on the GPU the single-kernel (fused) implementation
+        on_gpu = self.env.device.type == 'cuda'
+        self.optimizer = torch.optim.Adam(self.network.parameters(), lr=opts.lr, weight_decay=1e-5,
+                                          **({'fused': True} if on_gpu else {}))
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=max(1, self.epoch // 3), gamma=0.1)
         self.starting_epoch = 0
 

@@ -24,6 +24,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     for _ in range(5): eng.step(real, pose, True, True)
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=25, max_name_column_width=60))
 t0 = time.perf_counter()
 for _ in range(20): eng.step(real, pose, True, True)
 torch.cuda.synchronize(); print("step ms", (time.perf_counter() - t0) / 20 * 1e3)
