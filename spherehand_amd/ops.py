@@ -19,6 +19,25 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(device):
+    """Device guard for the launches below: a no-op when `device` is already current (one process
+    per GPU: always), torch.cuda.device(...) otherwise."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(device)
+
+
 def _check_input(t, name, dtype=torch.float32):
     if not isinstance(t, torch.Tensor):
         raise RuntimeError("%s must be a torch.Tensor" % name)
@@ -36,7 +55,7 @@ def sphere_raster_fwd(spheres, H, W, want_argmin=False):
     if spheres.dim() != 3 or spheres.shape[2] != 4:
         raise RuntimeError("spheres must be [N,J,4]")
     N, J, _ = spheres.shape
-    with torch.cuda.device(spheres.device):
+    with _on(spheres.device):
         depth = torch.empty((N, H, W), dtype=torch.float32, device=spheres.device)
         arg = torch.empty((N, H, W), dtype=torch.uint8, device=spheres.device) if want_argmin else None
         _lib.check(_lib.lib().shr_sphere_raster_fwd(_ptr(spheres), N, J, H, W, _ptr(depth), _ptr(arg),
@@ -57,7 +76,7 @@ def sphere_raster_bwd(spheres, grad_depth, argmin=None):
         _check_input(argmin, "argmin", torch.uint8)
         if argmin.shape != grad_depth.shape:
             raise RuntimeError("argmin must be [N,H,W]")
-    with torch.cuda.device(spheres.device):
+    with _on(spheres.device):
         out = torch.empty((N, J, 4), dtype=torch.float32, device=spheres.device)
         _lib.check(_lib.lib().shr_sphere_raster_bwd(_ptr(spheres), _ptr(grad_depth), _ptr(argmin), N, J, H, W,
                                                     _ptr(out), _stream()), "shr_sphere_raster_bwd")
@@ -124,7 +143,7 @@ def sphere_raster_mse(spheres, target, target_index=None, want_depth=True):
     R = _lib.lib().shr_sphere_raster_mse_regions(int(H), int(W))
     if R <= 0:
         raise RuntimeError("image rows too wide for the fused kernel (compose sphere_raster_fwd / _bwd)")
-    with torch.cuda.device(spheres.device):
+    with _on(spheres.device):
         depth = torch.empty((N, H, W), dtype=torch.float32, device=spheres.device) if want_depth else None
         sse = torch.empty((N, R), dtype=torch.float32, device=spheres.device)
         grad = torch.empty((N, R, J, 4), dtype=torch.float32, device=spheres.device)
@@ -176,7 +195,7 @@ def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
     J = centres.shape[1]
     if radii.numel() != J:
         raise RuntimeError("radii must have J entries")
-    with torch.cuda.device(depth.device):
+    with _on(depth.device):
         loss_sum = torch.empty(N, dtype=torch.float32, device=depth.device)
         grad = torch.empty((N, J, 3), dtype=torch.float32, device=depth.device) if want_grad else None
         if depth_index is None:
@@ -228,7 +247,7 @@ class MutualProject(torch.autograd.Function):
         B, V, J = joints.shape[0], joints.shape[1], joints.shape[2]
         if cam.shape != (B, V, 4, 4) or inv_cam.shape != (B, V, 4, 4) or joints.shape[3] != 3:
             raise RuntimeError("expected cam/inv_cam [B,V,4,4] and joints [B,V,J,3]")
-        with torch.cuda.device(joints.device):
+        with _on(joints.device):
             out = torch.empty((B, V, V, J, 4), dtype=torch.float32, device=joints.device)
             _lib.check(_lib.lib().shr_mutual_project_fwd(_ptr(cam), _ptr(inv_cam), _ptr(joints), _ptr(radii), B, V, J,
                                                          _ptr(out), _stream()), "shr_mutual_project_fwd")
@@ -240,7 +259,7 @@ class MutualProject(torch.autograd.Function):
         cam, inv_cam = ctx.saved_tensors
         g = grad_spheres.contiguous()
         B, V, _, J, _ = g.shape
-        with torch.cuda.device(g.device):
+        with _on(g.device):
             out = torch.empty((B, V, J, 3), dtype=torch.float32, device=g.device)
             _lib.check(_lib.lib().shr_mutual_project_bwd(_ptr(cam), _ptr(inv_cam), _ptr(g), B, V, J, _ptr(out),
                                                          _stream()), "shr_mutual_project_bwd")
@@ -256,7 +275,7 @@ def tri_raster_fwd(width, height, face_vertices):
     B, F = face_vertices.shape[0], face_vertices.shape[1]
     if face_vertices.numel() != B * F * 9:
         raise RuntimeError("vertices must hold 9 floats per face ([B,F,3,3])")
-    with torch.cuda.device(face_vertices.device):
+    with _on(face_vertices.device):
         depth = torch.empty((B, height, width), dtype=torch.float32, device=face_vertices.device)
         _lib.check(_lib.lib().shr_tri_raster_fwd(_ptr(face_vertices), B, F, width, height, _ptr(depth), _stream()),
                    "shr_tri_raster_fwd")
@@ -270,7 +289,7 @@ def tri_raster_indexed_fwd(width, height, vertices, faces):
     if vertices.dim() != 3 or vertices.shape[2] != 4 or faces.dim() != 2 or faces.shape[1] != 3:
         raise RuntimeError("vertices must be [B,NV,4] and faces [F,3]")
     B, NV = vertices.shape[0], vertices.shape[1]
-    with torch.cuda.device(vertices.device):
+    with _on(vertices.device):
         depth = torch.empty((B, height, width), dtype=torch.float32, device=vertices.device)
         _lib.check(_lib.lib().shr_tri_raster_indexed_fwd(_ptr(vertices), _ptr(faces), B, NV, faces.shape[0], width,
                                                          height, _ptr(depth), _stream()),
@@ -289,7 +308,7 @@ def lbs_project(T, skin_vertex_start, skin_bone, skin_wv, right_hand=True, camer
     B, NB = T.shape[0], T.shape[1]
     NV = skin_vertex_start.numel() - 1
     cx, cy, fx, fy = camera if camera is not None else (0.0, 0.0, 1.0, 1.0)
-    with torch.cuda.device(T.device):
+    with _on(T.device):
         out = torch.empty((B, NV, 4), dtype=torch.float32, device=T.device)
         _lib.check(_lib.lib().shr_lbs_project(_ptr(T), B, NB, NV, _ptr(skin_vertex_start), _ptr(skin_bone),
                                               _ptr(skin_wv), int(bool(right_hand)), int(camera is not None),
@@ -309,7 +328,7 @@ class ForwardKinematics(torch.autograd.Function):
         if params.dim() != 2 or params.shape[1] != 26:
             raise RuntimeError("parameters must be [B,26]")
         B = params.shape[0]
-        with torch.cuda.device(params.device):
+        with _on(params.device):
             T = torch.empty((B, 17, 4, 4), dtype=torch.float32, device=params.device)
             _lib.check(_lib.lib().shr_fk_fwd(_ptr(params), B, _ptr(offset), _ptr(offset_inv), _ptr(T), _stream()),
                        "shr_fk_fwd")
@@ -321,7 +340,7 @@ class ForwardKinematics(torch.autograd.Function):
         params, offset, offset_inv = ctx.saved_tensors
         g = grad_T.contiguous().float()
         B = params.shape[0]
-        with torch.cuda.device(params.device):
+        with _on(params.device):
             out = torch.empty((B, 26), dtype=torch.float32, device=params.device)
             _lib.check(_lib.lib().shr_fk_bwd(_ptr(params), B, _ptr(offset), _ptr(offset_inv), _ptr(g), _ptr(out),
                                              _stream()), "shr_fk_bwd")
@@ -336,7 +355,7 @@ def mesh_depth_fwd(vertices, faces, out_size, src_size=640, clamp_max=100.0):
     if vertices.dim() != 3 or vertices.shape[2] != 4 or faces.dim() != 2 or faces.shape[1] != 3:
         raise RuntimeError("vertices must be [B,NV,4] and faces [F,3]")
     B, NV = vertices.shape[0], vertices.shape[1]
-    with torch.cuda.device(vertices.device):
+    with _on(vertices.device):
         depth = torch.empty((B, out_size, out_size), dtype=torch.float32, device=vertices.device)
         _lib.check(_lib.lib().shr_mesh_depth_fwd(_ptr(vertices), _ptr(faces), B, NV, faces.shape[0], src_size, out_size,
                                                  clamp_max, _ptr(depth), _stream()), "shr_mesh_depth_fwd")
@@ -358,7 +377,7 @@ class GroupNormReLU(torch.autograd.Function):
     def forward(ctx, x, weight, bias, num_groups, eps):
         N, C, H, W = x.shape
         weight, bias = weight.contiguous(), bias.contiguous()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             y = torch.empty_like(x, memory_format=torch.channels_last)
             mean = torch.empty((N, num_groups), dtype=torch.float32, device=x.device)
             rstd = torch.empty((N, num_groups), dtype=torch.float32, device=x.device)
@@ -374,7 +393,7 @@ class GroupNormReLU(torch.autograd.Function):
         x, weight, bias, mean, rstd = ctx.saved_tensors
         N, C, H, W = x.shape
         dy = dy.contiguous(memory_format=torch.channels_last)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             dx = torch.empty_like(x, memory_format=torch.channels_last)
             part = torch.empty((2, N, C), dtype=torch.float32, device=x.device)     # per-sample partials (workspace)
             dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
