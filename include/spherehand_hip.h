@@ -135,6 +135,21 @@ int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W,
  * The backward returns dx, PER-SAMPLE partials dgamma_partial / dbeta_partial [N][C] and, when
  * dgamma / dbeta [C] are not NULL, their sums over the samples (in order: deterministic).  shr_group_norm_relu_supported: C % 32 == 0 and C/G in
  * {4, 8, 16, 32}; buffers 16-byte aligned. */
+/* Pointwise tail of the synthetic branch (network/util_modules.py:104-122), forward only.
+ * shr_heatmap_paint: HeatmapRender.forward (mesh/render.py:226-248) for BJ = B*J key-points
+ *   uvd[BJ][4] = (u, v, depth, w): uv_hm = uv_scale * exp(-0.5*sigma*((u-uj)^2+(v-vj)^2)) on the S x S
+ *   grid, d_hm = d_scale * (depth where the Gaussian > 0.05, else 0), and xyz[BJ][4] = K^-1 uvd
+ *   (mesh/pointTransformation.py:102-124; a00,a03 / a11,a13 = the non-trivial entries of rows 0 / 1
+ *   of K^-1).
+ * shr_depth_noise: DepthNoise.forward (network/util_modules.py:46-84): per pixel a rounded source
+ *   shift and depth noise on foreground pixels from normal3[3][B][H][W] standard-normal draws
+ *   (out must not alias depth). */
+int shr_heatmap_paint(const float *uvd, int BJ, int S, float sigma, float uv_scale, float d_scale,
+                      float a00, float a03, float a11, float a13,
+                      float *uv_hm, float *d_hm, float *xyz, void *stream);
+int shr_depth_noise(const float *depth, const float *normal3, int B, int H, int W,
+                    float sigma_xy, float sigma_z, float *out, void *stream);
+
 int shr_group_norm_relu_supported(int C, int G);
 int shr_group_norm_relu_fwd(const float *x, const float *gamma, const float *beta,
                             int N, int C, int HW, int G, float eps,

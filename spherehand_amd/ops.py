@@ -412,3 +412,33 @@ def group_norm_relu(x, gn):
     if FUSED_GROUP_NORM_RELU and gn.affine and group_norm_relu_supported(x, gn.num_groups):
         return GroupNormReLU.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps)
     return torch.nn.functional.relu(gn(x))
+
+
+def heatmap_paint(uvd, S, sigma, inv_k, uv_scale=1.0, d_scale=1.0):
+    """uvd [B,J,4] heat-map-space key-points -> (uv_hm [B,J,S,S] * uv_scale, d_hm [B,J,S,S] * d_scale,
+    xyz [B,J,4] = inv_k @ uvd): HeatmapRender + InverseOthographicalProjection in one launch."""
+    _check_input(uvd, "uvd_points")
+    if uvd.dim() != 3 or uvd.shape[2] != 4:
+        raise RuntimeError("uvd_points must be [B,J,4]")
+    B, J = uvd.shape[0], uvd.shape[1]
+    a00, a03, a11, a13 = (float(inv_k[0][0]), float(inv_k[0][3]), float(inv_k[1][1]), float(inv_k[1][3]))
+    with _on(uvd.device):
+        uv = torch.empty((B, J, S, S), dtype=torch.float32, device=uvd.device)
+        d = torch.empty((B, J, S, S), dtype=torch.float32, device=uvd.device)
+        xyz = torch.empty((B, J, 4), dtype=torch.float32, device=uvd.device)
+        _lib.check(_lib.lib().shr_heatmap_paint(_ptr(uvd), B * J, int(S), float(sigma), float(uv_scale), float(d_scale),
+                                                a00, a03, a11, a13, _ptr(uv), _ptr(d), _ptr(xyz), _stream()),
+                   "shr_heatmap_paint")
+    return uv, d, xyz
+
+
+def depth_noise(depth, sigma_xy, sigma_z, generator=None):
+    """DepthNoise on [B,H,W] scaled depth: one torch.randn([3,B,H,W]) + one launch."""
+    _check_input(depth, "depth")
+    B, H, W = depth.shape
+    with _on(depth.device):
+        normal3 = torch.randn((3, B, H, W), dtype=torch.float32, device=depth.device, generator=generator)
+        out = torch.empty_like(depth)
+        _lib.check(_lib.lib().shr_depth_noise(_ptr(depth), _ptr(normal3), B, H, W, float(sigma_xy), float(sigma_z),
+                                              _ptr(out), _stream()), "shr_depth_noise")
+    return out

@@ -207,11 +207,25 @@ class Hand3DHeatmapRender(nn.Module):
         self.inv_camera = InverseOthographicalProjection(half, half, f, f)
         self.lbs = keypoint_skinning(bones)
         self.num_vertices = self.lbs.num_vertices
+        self._skin_bone_i32 = None
 
-    def forward(self, transformation_mats, rand_f=None):
-        uvd_points = self.camera(self.lbs(transformation_mats), rand_f)
+    def forward(self, transformation_mats, rand_f=None, uv_scale=1.0, d_scale=1.0):
+        """(uv_scale / d_scale: HandSynthesizer's heat-map scalings, applied in the same launch on the GPU path)"""
+        T = transformation_mats
+        if T.is_cuda and not torch.is_grad_enabled() and T.dtype == torch.float32:
+            # forward-only GPU path: skinning + camera (one launch), then Gaussians + depth painting +
+            # back-projection (one launch)
+            lbs = self.lbs
+            if self._skin_bone_i32 is None or self._skin_bone_i32.device != T.device:
+                self._skin_bone_i32 = lbs.skin_bone.to(device=T.device, dtype=torch.int32).contiguous()
+                self._inv_k = self.inv_camera.inv_k_mat[0].cpu().tolist()
+            cam = self.camera
+            uvd = ops.lbs_project(T.contiguous(), lbs.skin_vertex_start, self._skin_bone_i32, lbs.skin_wv, lbs.right_hand,
+                                  (cam.cx, cam.cy, cam.fx, cam.fy), None if rand_f is None else rand_f.contiguous().float())
+            return ops.heatmap_paint(uvd, self.width, self.hm_renderer.sigma, self._inv_k, uv_scale, d_scale)
+        uvd_points = self.camera(self.lbs(T), rand_f)
         hms, dms = self.hm_renderer(uvd_points)
-        return hms, dms, self.inv_camera(uvd_points)
+        return hms * uv_scale, dms * d_scale, self.inv_camera(uvd_points)
 
 
 def _collision_pairs():

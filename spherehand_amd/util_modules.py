@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .kinematicsTransformation import HandTransformationMat
 from .pointTransformation import RandScale
 from .render import DepthRender, Hand3DHeatmapRender
@@ -104,6 +105,8 @@ class DepthNoise(nn.Module):
 
     def forward(self, dm):
         n, h, w = dm.shape
+        if dm.is_cuda and dm.dtype == torch.float32 and not torch.is_grad_enabled():
+            return ops.depth_noise(dm.contiguous(), self.sigma_x, self.sigma_z)       # one randn + one launch
         sx = torch.clamp((torch.randn_like(dm) * self.sigma_x + 0.5).long() + self.u_grid, 0, w - 1)
         sy = torch.clamp((torch.randn_like(dm) * self.sigma_y + 0.5).long() + self.v_grid, 0, h - 1)
         noisy = torch.gather(dm.reshape(n, h * w), 1, (sy * w + sx).reshape(n, h * w)).view(n, h, w)
@@ -202,11 +205,12 @@ class HandSynthesizer(nn.Module):
     @torch.no_grad()
     def forward(self, parameters):
         transform_mats = self.rand_scale(self.hand_skeleton_transform(parameters))
-        rand_f_ratio = (torch.rand(transform_mats.shape[0]) * 0.2 + 0.9).to(transform_mats.device)
+        # focal jitter U(0.9, 1.1) (util_modules.py:110), drawn on the tensors' device (no host round trip)
+        rand_f_ratio = torch.rand(transform_mats.shape[0], device=transform_mats.device) * 0.2 + 0.9
         depth = self.dm_render(transform_mats, rand_f_ratio) * self.depth_scale
         if self.add_noise:
             depth = self.depth_noiser(depth)
         if not self.out_heatmap:
             return depth
-        uv_hms, depth_hms, xyz_pts = self.hm_render(transform_mats, rand_f_ratio)
-        return depth, uv_hms * self.uv_hm_scale, depth_hms * self.depth_scale, xyz_pts
+        uv_hms, depth_hms, xyz_pts = self.hm_render(transform_mats, rand_f_ratio, self.uv_hm_scale, self.depth_scale)
+        return depth, uv_hms, depth_hms, xyz_pts

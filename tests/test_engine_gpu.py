@@ -117,3 +117,39 @@ def test_render_loss_fits_a_pose(tmp_path):
         first = loss.item() if first is None else first
     assert loss.item() < 0.5 * first
     assert (joints - truth).norm(dim=-1).mean().item() < 4.0 * 1.7 * 0.8     # closer than the start (E|N(0,4^2 I)| ~ 6.4)
+
+
+def test_synth_post_kernels_match_the_torch_modules():
+    """heat-map painting + back-projection and the depth-noise kernel against the torch modules they replace."""
+    import numpy as np
+    from spherehand_amd import hand_model, ops
+    from spherehand_amd.joint_angle import sample_poses
+    from spherehand_amd.kinematicsTransformation import HandTransformationMat
+    from spherehand_amd.render import Hand3DHeatmapRender
+    from spherehand_amd.util_modules import DepthNoise
+    mesh = hand_model.load_mesh()
+    fk = HandTransformationMat([b["offset_matrix"].astype(np.float32) for b in mesh["bones"]]).cuda()
+    T = fk(sample_poses(12, seed=3).cuda()).detach()
+    rf = torch.rand(12, device="cuda") * 0.2 + 0.9
+    hm = Hand3DHeatmapRender(mesh["bones"], 16).cuda()
+    for rand_f in (None, rf):
+        with torch.no_grad():
+            a = hm(T, rand_f, 1.0, 0.01)                      # kernels
+        with torch.enable_grad():
+            b = hm(T, rand_f, 1.0, 0.01)                      # torch ops
+        for x, y, tol in zip(a, b, (2e-6, 1e-7, 2e-4)):
+            assert x.shape == y.shape and (x - y).abs().max().item() <= tol
+    # depth noise: identical to the torch formula fed the same normal draws
+    dm = (torch.rand(5, 64, 64, device="cuda") * 1.4).contiguous()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    out = ops.depth_noise(dm, 0.5, 0.05, generator=g)
+    g.manual_seed(7)
+    n3 = torch.randn((3, 5, 64, 64), device="cuda", generator=g)
+    u = torch.arange(64, device="cuda").view(1, 1, 64); v = torch.arange(64, device="cuda").view(1, 64, 1)
+    sx = torch.clamp((n3[0] * 0.5 + 0.5).long() + u, 0, 63); sy = torch.clamp((n3[1] * 0.5 + 0.5).long() + v, 0, 63)
+    noisy = torch.gather(dm.reshape(5, -1), 1, (sy * 64 + sx).reshape(5, -1)).view(5, 64, 64)
+    ref = torch.where(noisy < 1.0, noisy + n3[2] * 0.05, noisy)
+    assert torch.equal(out, ref)
+    with torch.no_grad():
+        z = DepthNoise(64, 64).cuda()(dm)
+    assert z.shape == dm.shape and ((z - dm).abs() > 0).float().mean().item() > 0.3
