@@ -673,15 +673,16 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
           po[b] = ok[b] ? static_cast<const void *>(oin4 + c) : static_cast<const void *>(rec);
         }
         asm volatile(
-            "global_load_dwordx4 %0, %8, off\n\tglobal_load_dword %4, %12, off\n\t"
-            "global_load_dwordx4 %1, %9, off\n\tglobal_load_dword %5, %13, off\n\t"
-            "global_load_dwordx4 %2, %10, off\n\tglobal_load_dword %6, %14, off\n\t"
-            "global_load_dwordx4 %3, %11, off\n\tglobal_load_dword %7, %15, off\n\t"
+            "global_load_dwordx4 %0, %12, off\n\tglobal_load_dword %4, %16, off\n\t"
+            "global_load_dwordx4 %1, %13, off\n\tglobal_load_dword %5, %17, off\n\t"
+            "global_load_dwordx4 %2, %14, off\n\tglobal_load_dword %6, %18, off\n\t"
+            "global_load_dwordx4 %3, %15, off\n\tglobal_load_dword %7, %19, off\n\t"
             "s_waitcnt vmcnt(0)"
             : "=&v"(g2[0]), "=&v"(g2[1]), "=&v"(g2[2]), "=&v"(g2[3]), "=&v"(o2[0]), "=&v"(o2[1]), "=&v"(o2[2]),
-              "=&v"(o2[3])
+              "=&v"(o2[3]), "+v"(g1[0]), "+v"(g1[1]), "+v"(o1[0]), "+v"(o1[1])   // the speculative batch lands here too
             : "v"(pg[0]), "v"(pg[1]), "v"(pg[2]), "v"(pg[3]), "v"(po[0]), "v"(po[1]), "v"(po[2]), "v"(po[3])
             : "memory");
+        static_assert(kSpecUnits == 2, "the statement above ties two speculative units");
         if (!spec_stored) {
 #pragma unroll
           for (int b = 0; b < kSpecUnits; b++) {
@@ -695,7 +696,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
           if (ok[b]) put_unit(wave_s + ((k + b) << 4), g2[b], o2[b]);
       }
       if (!spec_stored) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(g1[0]), "+v"(g1[1]), "+v"(o1[0]), "+v"(o1[1]) : : "memory");
 #pragma unroll
         for (int b = 0; b < kSpecUnits; b++) {
           const int u = wave_s + ((k1 + b) << 4);
