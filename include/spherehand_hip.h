@@ -135,6 +135,20 @@ int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W,
  * The backward returns dx, PER-SAMPLE partials dgamma_partial / dbeta_partial [N][C] and, when
  * dgamma / dbeta [C] are not NULL, their sums over the samples (in order: deterministic).  shr_group_norm_relu_supported: C % 32 == 0 and C/G in
  * {4, 8, 16, 32}; buffers 16-byte aligned. */
+/* Soft-argmax read-out of the network's heat-maps (network/util_modules.py:164-201), forward and
+ * backward: hm[N][2J][h][w] fp32 with element (n, c, y, x) at n*stride_n + c*stride_c + (y*w + x)*stride_px
+ * (NCHW: stride_c = h*w, stride_px = 1; channels-last: stride_c = 1, stride_px = 2J).  Channels 0..J-1 are
+ * the uv heat-maps, J..2J-1 the depth heat-maps.  xyz[N][J][3] = ((u - cx)/fx, (v - cy)/fy, d * depth_scale_inv)
+ * with u, v the softmax(20 * uv) expectation of the pixel grid and d the relu-normalised depth.  The backward
+ * writes grad_hm in the input's layout (same strides).  _supported: the 2J maps of a sample fit LDS. */
+int shr_soft_argmax_supported(int J, int h, int w);
+int shr_soft_argmax_fwd(const float *hm, long long stride_n, long long stride_c, long long stride_px,
+                        int N, int J, int h, int w, float cx, float cy, float fx, float fy,
+                        float depth_scale_inv, float *xyz, void *stream);
+int shr_soft_argmax_bwd(const float *hm, long long stride_n, long long stride_c, long long stride_px,
+                        int N, int J, int h, int w, float cx, float cy, float fx, float fy,
+                        float depth_scale_inv, const float *grad_xyz, float *grad_hm, void *stream);
+
 /* Pointwise tail of the synthetic branch (network/util_modules.py:104-122), forward only.
  * shr_heatmap_paint: HeatmapRender.forward (mesh/render.py:226-248) for BJ = B*J key-points
  *   uvd[BJ][4] = (u, v, depth, w): uv_hm = uv_scale * exp(-0.5*sigma*((u-uj)^2+(v-vj)^2)) on the S x S

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (device memory, streams: the plumbing this library s
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libspherehand_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -32,6 +32,11 @@ SIGNATURES = {
     "shr_data_to_model": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "shr_data_to_model_indexed": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "shr_sphere_raster_mse_regions": ([_i, _i], _i),
+    "shr_soft_argmax_supported": ([_i, _i, _i], _i),
+    "shr_soft_argmax_fwd": ([_vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _i, _i, _i, _i, _f, _f, _f, _f, _f,
+                             _vp, _vp], _i),
+    "shr_soft_argmax_bwd": ([_vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _i, _i, _i, _i, _f, _f, _f, _f, _f,
+                             _vp, _vp, _vp], _i),
     "shr_heatmap_paint": ([_vp, _i, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp], _i),
     "shr_depth_noise": ([_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp], _i),
     "shr_group_norm_relu_supported": ([_i, _i], _i),

@@ -52,9 +52,9 @@ class HeatmapEstimationNetwork(nn.Module):
     def _split(self, outputs):
         return [o[:, :self.num_joints] for o in outputs], [o[:, self.num_joints:] for o in outputs]
 
-    def _real_result(self, uv_hms, d_hms, u_scale, v_scale, B, V):
+    def _real_result(self, outputs, uv_hms, d_hms, u_scale, v_scale, B, V):
         inv = torch.stack([1.0 / u_scale, 1.0 / v_scale, torch.ones_like(u_scale)], dim=-1).unsqueeze(1)
-        xyz = [self.xyz_recover(uv, d, True) * inv for uv, d in zip(uv_hms, d_hms)]
+        xyz = [self.xyz_recover.from_output(o) * inv for o in outputs]
         shape5 = lambda h: h.reshape(B, V, self.num_joints, h.shape[-2], h.shape[-1])   # noqa: E731
         return {'real_uv_hms': [shape5(h) for h in uv_hms], 'real_d_hms': [shape5(h) for h in d_hms],
                 'real_xyz': [p.reshape(B, V, self.num_joints, 3) for p in xyz]}
@@ -69,12 +69,14 @@ class HeatmapEstimationNetwork(nn.Module):
             inputs.append(flat)
         outputs, latents = self.hg(torch.cat(inputs, dim=0) if len(inputs) > 1 else inputs[0])
         if synt_dms is not None:
-            uv, d = self._split([o[:n_synt] for o in outputs])
+            synt_out = [o[:n_synt] for o in outputs]
+            uv, d = self._split(synt_out)
             result.update({'synt_uv_hms': uv, 'synt_d_hms': d,
-                           'synt_xyz': [self.xyz_recover(a, b) for a, b in zip(uv, d)]})
+                           'synt_xyz': [self.xyz_recover.from_output(o) for o in synt_out]})
         if real_dms is not None:
-            uv, d = self._split([o[n_synt:] for o in outputs])
-            result.update(self._real_result(uv, d, u_scale, v_scale, B, V))
+            real_out = [o[n_synt:] for o in outputs]
+            uv, d = self._split(real_out)
+            result.update(self._real_result(real_out, uv, d, u_scale, v_scale, B, V))
             if synt_dms is not None:
                 if self.resize_dm is not None:
                     result['real_resized_dms'] = flat

@@ -442,3 +442,44 @@ def depth_noise(depth, sigma_xy, sigma_z, generator=None):
         _lib.check(_lib.lib().shr_depth_noise(_ptr(depth), _ptr(normal3), B, H, W, float(sigma_xy), float(sigma_z),
                                               _ptr(out), _stream()), "shr_depth_noise")
     return out
+
+
+def soft_argmax_supported(hm, J):
+    """True when the soft-argmax kernels take this raw network output (CUDA fp32 [N,2J,h,w], pixels
+    linear in memory: NCHW or channels-last, also as a batch slice)."""
+    if not (hm.is_cuda and hm.dtype == torch.float32 and hm.dim() == 4 and hm.shape[1] == 2 * J and hm.shape[0] > 0):
+        return False
+    h, w = hm.shape[2], hm.shape[3]
+    if hm.stride(2) != w * hm.stride(3) or hm.stride(3) < 1 or hm.stride(1) < 1:
+        return False
+    return bool(_lib.lib().shr_soft_argmax_supported(int(J), int(h), int(w)))
+
+
+class SoftArgmaxXYZ(torch.autograd.Function):
+    """hm [N,2J,h,w] (uv heat-maps | depth heat-maps) -> xyz [N,J,3]: RecoverXYZCoordinateFromHeatmap
+    (network/util_modules.py:164-201) in one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, hm, J, cx, cy, fx, fy, depth_scale_inv):
+        N, _, h, w = hm.shape
+        with _on(hm.device):
+            xyz = torch.empty((N, J, 3), dtype=torch.float32, device=hm.device)
+            _lib.check(_lib.lib().shr_soft_argmax_fwd(_ptr(hm), hm.stride(0), hm.stride(1), hm.stride(3), N, J, h, w,
+                                                      float(cx), float(cy), float(fx), float(fy), float(depth_scale_inv),
+                                                      _ptr(xyz), _stream()), "shr_soft_argmax_fwd")
+        ctx.save_for_backward(hm)
+        ctx.args = (J, cx, cy, fx, fy, depth_scale_inv)
+        return xyz
+
+    @staticmethod
+    def backward(ctx, grad_xyz):
+        (hm,) = ctx.saved_tensors
+        J, cx, cy, fx, fy, ds = ctx.args
+        N, _, h, w = hm.shape
+        grad_xyz = grad_xyz.contiguous()
+        with _on(hm.device):
+            grad_hm = torch.empty_strided(hm.shape, hm.stride(), dtype=torch.float32, device=hm.device)
+            _lib.check(_lib.lib().shr_soft_argmax_bwd(_ptr(hm), hm.stride(0), hm.stride(1), hm.stride(3), N, J, h, w,
+                                                      float(cx), float(cy), float(fx), float(fy), float(ds),
+                                                      _ptr(grad_xyz), _ptr(grad_hm), _stream()), "shr_soft_argmax_bwd")
+        return grad_hm, None, None, None, None, None, None

@@ -43,6 +43,14 @@ class RecoverXYZCoordinateFromHeatmap(nn.Module):
         self.register_buffer('u_grid', torch.arange(width, dtype=torch.float32).view(1, 1, 1, width))
         self.register_buffer('v_grid', torch.arange(height, dtype=torch.float32).view(1, 1, height, 1))
 
+    def from_output(self, hm):
+        """xyz from the network's raw output hm [N,2J,h,w] (uv maps | depth maps): one kernel per direction on
+        the GPU, the torch formulation (forward()) otherwise."""
+        J = hm.shape[1] // 2
+        if ops.soft_argmax_supported(hm, J):
+            return ops.SoftArgmaxXYZ.apply(hm, J, self.cx, self.cy, self.fx, self.fy, self.depth_scale)
+        return self.forward(hm[:, :J], hm[:, J:])
+
     def forward(self, uv_hms, d_hms, is_shuffing=False):
         p = _spatial_softmax(uv_hms, 20.0)
         u = (p * self.u_grid).sum(dim=(-2, -1))

@@ -49,3 +49,30 @@ def test_hourglass_gpu_matches_cpu_reference_path():
     ref, _ = net(x)
     out, _ = net.cuda().to(memory_format=torch.channels_last)(x.cuda().to(memory_format=torch.channels_last))
     assert (out[0].cpu() - ref[0]).abs().max().item() <= 2e-4 * ref[0].abs().max().item()
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc", "nhwc_slice"])
+def test_soft_argmax_kernels_match_the_torch_formulation(layout):
+    """RecoverXYZCoordinateFromHeatmap: one launch per direction vs the torch ops (fp64 reference)."""
+    from spherehand_amd import ops
+    from spherehand_amd.util_modules import RecoverXYZCoordinateFromHeatmap
+    g = torch.Generator().manual_seed(5)
+    N, J, S = 9, 41, 16
+    base = torch.randn(N + 3, 2 * J, S, S, generator=g) * 0.6
+    base[:, :J] += torch.exp(-((torch.arange(S).view(1, 1, S, 1) - 7.3) ** 2 + (torch.arange(S).view(1, 1, 1, S) - 4.6) ** 2) / 3)
+    base = base.cuda()
+    if layout != "nchw":
+        base = base.to(memory_format=torch.channels_last)
+    hm = (base[2:2 + N] if layout == "nhwc_slice" else base[:N]).detach().requires_grad_(True)
+    rec = RecoverXYZCoordinateFromHeatmap(S, S, 0.01).cuda()
+    assert ops.soft_argmax_supported(hm, J)
+    up = torch.randn(N, J, 3, generator=g).cuda()
+    xyz = rec.from_output(hm)
+    (xyz * up).sum().backward()
+    got_x, got_g = xyz.detach(), hm.grad.clone()
+    hd = hm.detach().double().requires_grad_(True)
+    rd = RecoverXYZCoordinateFromHeatmap(S, S, 0.01).cuda().double()
+    ref = rd.forward(hd[:, :J], hd[:, J:])
+    (ref * up.double()).sum().backward()
+    assert (got_x.double() - ref.detach()).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert (got_g.double() - hd.grad).abs().max().item() <= 2e-5 * max(1.0, hd.grad.abs().max().item())
