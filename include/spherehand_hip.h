@@ -135,6 +135,18 @@ int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W,
  * The backward returns dx, PER-SAMPLE partials dgamma_partial / dbeta_partial [N][C] and, when
  * dgamma / dbeta [C] are not NULL, their sums over the samples (in order: deterministic).  shr_group_norm_relu_supported: C % 32 == 0 and C/G in
  * {4, 8, 16, 32}; buffers 16-byte aligned. */
+/* CollisionLoss and BoneLengthLoss (mesh/render.py:145-206) on M samples of J sphere centres (sample m at
+ * joints + m*sample_stride floats, [J][3]) with their gradients, one launch.  Collision pairs: spheres
+ * 0..num_palm-1 (palm) against every finger sphere, and finger spheres of different fingers (finger f =
+ * spheres num_palm + f*per_finger ...); hinge relu(min_dist_sq - |c_a - c_b|^2).  Bone pairs (bone_a[k],
+ * bone_b[k]), k < K: relu(bone_min_sq[k] - d^2) and relu(d^2 - bone_max_sq[k]).  Outputs per sample: the three
+ * sums [M] and the three UNIT gradients [M][J][3]; the caller applies the reference's sum / means and weights. */
+int shr_pair_losses(const float *joints, long long sample_stride, int M, int J, int num_palm, int per_finger,
+                    float min_dist_sq, const int32_t *bone_a, const int32_t *bone_b,
+                    const float *bone_min_sq, const float *bone_max_sq, int K,
+                    float *coll_sum, float *bone_lo_sum, float *bone_hi_sum,
+                    float *grad_coll, float *grad_bone_lo, float *grad_bone_hi, void *stream);
+
 /* Soft-argmax read-out of the network's heat-maps (network/util_modules.py:164-201), forward and
  * backward: hm[N][2J][h][w] fp32 with element (n, c, y, x) at n*stride_n + c*stride_c + (y*w + x)*stride_px
  * (NCHW: stride_c = h*w, stride_px = 1; channels-last: stride_c = 1, stride_px = 2J).  Channels 0..J-1 are

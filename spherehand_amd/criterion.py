@@ -8,6 +8,7 @@ network/create_network_and_criterion.py surface:
 import torch
 import torch.nn as nn
 
+from . import ops
 from .hourglass import create_hourglass_network
 from .multiview_utility import MultiviewConsistencyLoss, MutualProjectionLoss
 from .render import BoneLengthLoss, CollisionLoss
@@ -104,6 +105,12 @@ class MultiTaskLoss(nn.Module):
         self.prior_loss = prior_loss if isinstance(prior_loss, nn.Module) else None
         self.collision_criterion = CollisionLoss() if collision_loss else None
         self.bone_length_criterion = BoneLengthLoss() if bone_length_loss else None
+        if self.bone_length_criterion is not None:     # int32 / flat copies of its tables for the fused kernel
+            bl = self.bone_length_criterion
+            self.register_buffer('_bone_a', bl.joint_1.to(torch.int32), persistent=False)
+            self.register_buffer('_bone_b', bl.joint_2.to(torch.int32), persistent=False)
+            self.register_buffer('_bone_min', bl.min_length.reshape(-1).clone(), persistent=False)
+            self.register_buffer('_bone_max', bl.max_length.reshape(-1).clone(), persistent=False)
         self.domain_loss = nn.MSELoss()
         self.heatmap_size = heatmap_size
         self.weights = {'synt_hm': 1e3, 'synt_pt': 1e-1, 'mv_consistency': 1e-3, 'mv_projection': 1,
@@ -137,10 +144,19 @@ class MultiTaskLoss(nn.Module):
             terms['pose_prior'] = sum(w['prior'] * self.prior_loss.prior_loss(xyz / 100.0) for xyz in real_xyz)
         if self.temporal_smooth_loss is not None:
             terms['temporal_smooth'] = sum(w['temporal_smooth'] * self.temporal_smooth_loss(xyz) for xyz in real_xyz)
-        if self.collision_criterion is not None:
-            terms['collision'] = sum(w['collision'] * self.collision_criterion(xyz) for xyz in real_xyz)
-        if self.bone_length_criterion is not None:
-            terms['bone_length'] = sum(w['bone_length'] * self.bone_length_criterion(xyz) for xyz in real_xyz)
+        cc, bc = self.collision_criterion, self.bone_length_criterion
+        if cc is not None and bc is not None and real_xyz and real_xyz[0].is_cuda and real_xyz[0].dtype == torch.float32:
+            # both hinge losses and their gradients in one launch (same indexing as the modules: the first 41
+            # points of joints.view(B, -1, 3))
+            pairs = [ops.PairLosses.apply(xyz.reshape(xyz.shape[0], -1, 3), 41, 11, 6, float(cc.min_sq_dist),
+                                          self._bone_a, self._bone_b, self._bone_min, self._bone_max) for xyz in real_xyz]
+            terms['collision'] = sum(w['collision'] * p[0] for p in pairs)
+            terms['bone_length'] = sum(w['bone_length'] * p[1] for p in pairs)
+        else:
+            if cc is not None:
+                terms['collision'] = sum(w['collision'] * cc(xyz) for xyz in real_xyz)
+            if bc is not None:
+                terms['bone_length'] = sum(w['bone_length'] * bc(xyz) for xyz in real_xyz)
         if 'batch_synt_fea' in result and 'batch_real_fea' in result:
             terms['domain_loss'] = sum(
                 w['domain'] * self.domain_loss(s.mean(dim=(0, 2, 3)), r.mean(dim=(0, 2, 3)))

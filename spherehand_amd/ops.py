@@ -483,3 +483,39 @@ class SoftArgmaxXYZ(torch.autograd.Function):
                                                       float(cx), float(cy), float(fx), float(fy), float(ds),
                                                       _ptr(grad_xyz), _ptr(grad_hm), _stream()), "shr_soft_argmax_bwd")
         return grad_hm, None, None, None, None, None, None
+
+
+class PairLosses(torch.autograd.Function):
+    """(joints [B,P,3] with P >= J: the first J points of a sample are its sphere centres, as the reference's
+    `joints.view(B, -1, 3)` indexing implies) -> (collision loss, bone-length loss) of mesh/render.py:145-206
+    with the reference's reductions (sum; mean of the two hinges over [B,K]).  One launch; the backward only
+    scales the unit gradients the kernel already produced."""
+
+    @staticmethod
+    def forward(ctx, joints, J, num_palm, per_finger, min_dist_sq, bone_a, bone_b, bone_min_sq, bone_max_sq):
+        joints = joints.contiguous()
+        B, P = joints.shape[0], joints.shape[1]
+        K = bone_a.numel()
+        with _on(joints.device):
+            sums = torch.empty((3, B), dtype=torch.float32, device=joints.device)
+            grads = torch.empty((3, B, J, 3), dtype=torch.float32, device=joints.device)
+            _lib.check(_lib.lib().shr_pair_losses(_ptr(joints), P * 3, B, J, int(num_palm), int(per_finger),
+                                                  float(min_dist_sq), _ptr(bone_a), _ptr(bone_b), _ptr(bone_min_sq),
+                                                  _ptr(bone_max_sq), K, _ptr(sums[0]), _ptr(sums[1]), _ptr(sums[2]),
+                                                  _ptr(grads[0]), _ptr(grads[1]), _ptr(grads[2]), _stream()),
+                       "shr_pair_losses")
+        ctx.save_for_backward(grads)
+        ctx.meta = (B, P, J, K)
+        tot = sums.sum(dim=1)
+        return tot[0], (tot[1] + tot[2]) / float(B * K)
+
+    @staticmethod
+    def backward(ctx, g_coll, g_bone):
+        (grads,) = ctx.saved_tensors
+        B, P, J, K = ctx.meta
+        g = grads[0] * g_coll + (grads[1] + grads[2]) * (g_bone / float(B * K))
+        if P > J:
+            full = torch.zeros((B, P, 3), dtype=torch.float32, device=g.device)
+            full[:, :J] = g
+            g = full
+        return g, None, None, None, None, None, None, None, None

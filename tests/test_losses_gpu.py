@@ -114,3 +114,27 @@ def test_data_to_model_fits_and_nan_vs_oracle(oracle, fit):
     if fit in ("good", "bad"):
         gref = oracle.data_to_model_bwd(depth, centres, radii) * (n * S * S)         # oracle returns d mean / d centres
         assert np.abs(grad - gref).max() <= 2e-5 * np.abs(gref).max() + 1e-4
+
+
+def test_pair_losses_kernel_matches_the_modules():
+    """CollisionLoss + BoneLengthLoss (values and gradients) in one launch vs the torch modules, on the
+    [B,V,J,3] input the criterion passes (only a sample's first 41 points count, as in the reference)."""
+    from spherehand_amd import ops
+    from spherehand_amd.render import BoneLengthLoss, CollisionLoss
+    g = golden("g7_network.npz")
+    rs = np.random.RandomState(0)
+    base = np.tile(np.asarray(g["geo_joints"], np.float32).reshape(-1, 41, 3), (1, 1, 1))            # 6 poses
+    xyz = np.stack([base + rs.normal(0, s, base.shape).astype(np.float32) for s in (3.0, 8.0, 0.5)], 1)   # [6,3,41,3]
+    xyz[::2] *= 0.25                                          # shrunken hands: spheres closer than 6 mm, bones too short
+    cc, bc = CollisionLoss().cuda(), BoneLengthLoss().cuda()
+    a = dev(xyz).requires_grad_(True)
+    (cc(a) * 1.7 + bc(a) * 0.3).backward()
+    ref = (cc(a).item(), bc(a).item(), a.grad.clone())
+    b = dev(xyz).requires_grad_(True)
+    col, bone = ops.PairLosses.apply(b.reshape(6, -1, 3), 41, 11, 6, float(cc.min_sq_dist), bc.joint_1.to(torch.int32),
+                                     bc.joint_2.to(torch.int32), bc.min_length.reshape(-1).clone(), bc.max_length.reshape(-1).clone())
+    (col * 1.7 + bone * 0.3).backward()
+    assert abs(col.item() - ref[0]) <= 1e-5 * max(1.0, abs(ref[0])) and abs(bone.item() - ref[1]) <= 1e-5 * max(1.0, abs(ref[1]))
+    assert ref[0] > 0 and ref[1] > 0
+    assert (b.grad - ref[2]).abs().max().item() <= 1e-5 * max(1.0, ref[2].abs().max().item())
+    assert b.grad[:, 1:].abs().max().item() == 0          # the other views are not looked at
