@@ -191,6 +191,10 @@ def main():
             return best
         fwd_us = kernel_us(fwd)
         bwd_us = kernel_us(bwd)
+        # context for the roofline: what ONE plain fill launch of the depth output (16.8 of the
+        # forward's 21.1 MB, no arithmetic, same stream) takes at this batch size -- the practical
+        # ceiling of any kernel that has to write a 256-crop batch per launch
+        fill_us = kernel_us(lambda _s: depth.fill_(100.0))
 
     if rank == 0:
         # algorithmic bytes ("u8 argmin saved" variant: 165 808 B/crop fwd+bwd @128):
@@ -223,7 +227,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes,
-                         "launch_us": {"fwd": round(fwd_us, 3), "bwd": round(bwd_us, 3)}},
+                         "launch_us": {"fwd": round(fwd_us, 3), "bwd": round(bwd_us, 3)},
+                         "plain_fill_of_the_depth_output_us": round(fill_us, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spheres.cpu().numpy(), grad.cpu().numpy())
