@@ -582,9 +582,14 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   const int wave_s = rfl(wave);
   // Every wave requests the crop's records (lane j = sphere j) with an explicit instruction so
   // that the staging requests below can be queued behind it and awaited separately.
+  // The four OLDEST waves (one per SIMD: the arbitration serves them first, their requests head
+  // the memory queue) read the records: wave 0 builds the work list, waves 1-3 derive the touched
+  // rows and request what step 2 of the staging needs, for the whole workgroup.  A young wave's
+  // copy of the records arrived up to 3 k cycles later and held the barrier.
   const float4 *rec = spheres + (size_t)n * J;
-  v4f sphv;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sphv) : "v"(rec + min(lane, J - 1)));
+  const bool lead = wave_s < 4, p2_wave = wave_s >= 1 && wave_s < 4;
+  v4f sphv = {0.f, 0.f, 0.f, 0.f};
+  if (lead) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sphv) : "v"(rec + min(lane, J - 1)));
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
   bool have_sph = false;
   s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // 1024 = 16 waves x 64 spheres
@@ -597,15 +602,16 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     // Reading is the bandwidth-bound part (82 KB per 128x128 crop arrive in ~8 k cycles when
     // all CUs read), and only the rows some sphere's box touches are ever looked at (half of
     // a hand crop).  Those rows are known once the records have arrived, so the staging is
-    // split: the central half of the region is requested at once, speculatively, together
-    // with the records; what the touched rows need beyond it is requested when the records
-    // are in.  Units = 64 consecutive 16-byte chunks, unit u belongs to wave u mod 16.
+    // split: the central half of the region is requested at once, speculatively, by all waves
+    // (units = 64 consecutive 16-byte chunks, unit u belongs to wave u mod 16); what the
+    // touched rows need beyond it is requested by waves 1-3 as soon as THEIR records are in.
     const int w4 = W >> 2;
     const int nchunk = rh * w4;
     const int nunits = (nchunk + 63) >> 6;
     const float4 *gin4 = reinterpret_cast<const float4 *>(gin + (size_t)r0 * W);
     const uchar4 *oin4 = reinterpret_cast<const uchar4 *>(oin + (size_t)r0 * W);
-    const int uc0 = nunits >> 2, uc1 = nunits - uc0;          // central units
+    const int uc0 = nunits >> 2;                                          // step 1 covers the central units [uc0, uc1)
+    const int uc1 = min(nunits - uc0, uc0 + kZWaves * kSpecUnits);
     const int k1 = (max(uc0 - wave_s, 0) + kZWaves - 1) >> 4;  // this wave's first central unit is wave + 16 k1
     v4f g1[kSpecUnits];
     uint32_t o1[kSpecUnits];
@@ -634,7 +640,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     // owner padding = "nobody": the walk may overhang the image edge / region end
     for (int i = tid; i < rh * kRowPad; i += 1024) obuf[(i / kRowPad) * LW + W + (i % kRowPad)] = SHR_ARGMIN_NONE;
     for (int i = tid; i < kPadRows * LW; i += 1024) obuf[rh * LW + i] = SHR_ARGMIN_NONE;
-    if (!have_sph) {
+    if (lead && !have_sph) {
       if (VEC4) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(sphv) : "n"(2 * kSpecUnits) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" : "+v"(sphv) : : "memory");
       if (lane < J) sph = make_float4(sphv.x, sphv.y, sphv.z, sphv.w);
@@ -647,15 +653,18 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
       if (lane == 0) s_flag[1] = total;
     }
     if (VEC4) {
-      int cv0, cv1;
-      touched_rows(sph, lane < J, ay, ky, r0, r1, cv0, cv1);
-      // a patch row may overhang its sphere's box by kPadRows rows: those owners are read too
       int ua = nunits, ub = nunits;
-      if (cv1 >= cv0) { ua = ((cv0 - r0) * w4) >> 6; ub = min(nunits, ((min(cv1 + kPadRows, r1 - 1) - r0 + 1) * w4 + 63) >> 6); }
-      ua = rfl(ua);
-      ub = rfl(ub);
+      if (p2_wave) {
+        int cv0, cv1;
+        touched_rows(sph, lane < J, ay, ky, r0, r1, cv0, cv1);
+        if (cv1 >= cv0) { ua = ((cv0 - r0) * w4) >> 6; ub = min(nunits, ((cv1 - r0 + 1) * w4 + 63) >> 6); }
+        ua = rfl(ua);
+        ub = rfl(ub);
+      }
+      // step 2: the touched units outside step 1's, [ua, min(ub, uc0)) and [max(ua, uc1), ub), dealt to waves 1-3
+      const int n_lo = max(0, min(ub, uc0) - ua), hi0 = max(ua, uc1), n_out = n_lo + max(0, ub - hi0);
       bool spec_stored = false;
-      for (int k = (max(ua - wave_s, 0) + kZWaves - 1) >> 4; wave_s + (k << 4) < ub; k += kStageBatch) {
+      for (int t0 = wave_s - 1; p2_wave && t0 < n_out; t0 += 3 * kStageBatch) {
         // The requests and their wait are ONE asm statement: the compiler treats an asm
         // result as available at once and may copy it before a separate wait.  A slot
         // without a unit re-reads the records (no control flow around the statement).
@@ -664,11 +673,13 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
         uint32_t o2[kStageBatch];
         bool ok[kStageBatch];
         const void *pg[kStageBatch], *po[kStageBatch];
+        int us[kStageBatch];
 #pragma unroll
         for (int b = 0; b < kStageBatch; b++) {
-          const int kk = k + b, u = wave_s + (kk << 4);
-          ok[b] = u < ub && !(kk >= k1 && kk < k1 + kSpecUnits && u < uc1);   // wave-uniform
-          const int c = min((u << 6) + lane, nchunk - 1);
+          const int t = t0 + 3 * b;
+          ok[b] = t < n_out;                                                  // wave-uniform
+          const int u = us[b] = t < n_lo ? ua + t : hi0 + (t - n_lo);
+          const int c = min(max((u << 6) + lane, 0), nchunk - 1);
           pg[b] = ok[b] ? static_cast<const void *>(gin4 + c) : static_cast<const void *>(rec);
           po[b] = ok[b] ? static_cast<const void *>(oin4 + c) : static_cast<const void *>(rec);
         }
@@ -693,7 +704,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
         }
 #pragma unroll
         for (int b = 0; b < kStageBatch; b++)
-          if (ok[b]) put_unit(wave_s + ((k + b) << 4), g2[b], o2[b]);
+          if (ok[b]) put_unit(us[b], g2[b], o2[b]);
       }
       if (!spec_stored) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(g1[0]), "+v"(g1[1]), "+v"(o1[0]), "+v"(o1[1]) : : "memory");

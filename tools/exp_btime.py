@@ -15,8 +15,10 @@ depth, owner = ops.sphere_raster_fwd(spheres, S, S, want_argmin=True)
 gs = torch.empty(N, J, 4, device=dev)
 tbuf = torch.zeros(N * 16 * 8, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
+MODE = os.environ.get("MODE", "fwd_bwd")
 for _ in range(50):
-    ops.sphere_raster_fwd(spheres, S, S, want_argmin=True)   # as in the bench: forward, then backward
+    if MODE == "fwd_bwd":
+        ops.sphere_raster_fwd(spheres, S, S, want_argmin=True)   # as in the bench: forward, then backward
     lib.exp_zbwd_t_launch(spheres.data_ptr(), grad.data_ptr(), owner.data_ptr(), N, J, S, S, gs.data_ptr(), 128, SHARES, tbuf.data_ptr(), st)
 torch.cuda.synchronize()
 ref = ops.sphere_raster_bwd(spheres, grad, owner)
