@@ -375,11 +375,16 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
   const Axis ax = make_axis(W), ay = make_axis(H);
   const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
 
-  // every wave keeps the crop's records in registers, lane j = sphere j (one 656-byte line
-  // set, served to the later waves by the L2)
+  // the waves that need the crop's records before the first barrier (wave 0: work list; the
+  // background waves: touched rows) read them from memory, lane j = sphere j; the others take
+  // wave 0's LDS copy after the barrier (their requests would only lengthen the memory queue)
+  const int wave_s = rfl(wave);
+  const bool list_wave = wave_s == 0;
+  const int nbgw = min(kBgWaves, nwaves - 1);
+  const bool bg_wave = nwaves == 1 || (wave_s >= 1 && wave_s <= nbgw);
   const bool valid = lane < J;
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid) sph = spheres[(size_t)n * J + lane];
+  if (valid && (list_wave || bg_wave)) sph = spheres[(size_t)n * J + lane];
 
   {  // background everywhere (pad rows/columns included); overlaps the read above
     const Key bg = OWNER ? (Key)(((unsigned long long)depth_key(kBackground) << 32) | SHR_ARGMIN_NONE)
@@ -397,15 +402,11 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
     for (int i = nvec * per16 + tid; i < ncell; i += nthr) zbuf[i] = bg;
   }
 
-  const int wave_s = rfl(wave);
-  const bool list_wave = wave_s == 0;
   int cv0 = r0, cv1 = r1 - 1;
   // Waves 1..kBgWaves store the background rows while wave 0 builds the list: they are the
   // first to finish the z-buffer initialisation (the SIMD arbitration favours old waves) and
   // a wave issues a wave-wide store every ~55 cycles, so ~6 stores apiece fit in wave 0's
   // shadow.  The other waves learn the touched rows after the barrier.
-  const int nbgw = min(kBgWaves, nwaves - 1);
-  const bool bg_wave = nwaves == 1 || (wave_s >= 1 && wave_s <= nbgw);
 
   if (list_wave) {
     s_sph[lane] = sph;
@@ -472,6 +473,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
   };
   if (VEC4 && bg_wave) store_background(nwaves == 1 ? 0 : wave_s - 1, nwaves == 1 ? 1 : nbgw);
   __syncthreads();
+  if (!(list_wave || bg_wave)) sph = s_sph[lane];
 
   if (s_flag[0]) {  // workgroup-uniform: this crop needs the general path
     const int tiles_x = (W + kTileW - 1) / kTileW;
