@@ -821,9 +821,11 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
   const float *tgt = target + (size_t)(target_index ? target_index[n] : n) * H * W + (size_t)r0 * W;
   float *out = depth ? depth + (size_t)n * H * W + (size_t)r0 * W : nullptr;
 
+  const int wave_s = rfl(wave);
+  const bool bg_wave = wave_s >= 1 && wave_s <= kBgWaves;
   const bool valid = lane < J;
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid) sph = spheres[(size_t)n * J + lane];
+  if (valid && (wave_s == 0 || bg_wave)) sph = spheres[(size_t)n * J + lane];   // the others: wave 0's LDS copy, later
   s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // 1024 = 16 waves x 64 spheres
   {  // background everywhere
     const Key bg = ((Key)depth_key(kBackground) << 32) | SHR_ARGMIN_NONE;
@@ -833,14 +835,12 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
     if (tid == 0 && ((rh * LW) & 1)) zbuf[rh * LW - 1] = bg;
   }
 
-  const int wave_s = rfl(wave);
   const int w4 = W >> 2;
   const int nchunk = rh * w4;
   const int nunits = (nchunk + 63) >> 6;
   const float4 *tgt4 = reinterpret_cast<const float4 *>(tgt);
   float4 *out4 = reinterpret_cast<float4 *>(out);
   int ua = 0, ub = nunits;
-  const bool bg_wave = wave_s >= 1 && wave_s <= kBgWaves;
   if (bg_wave) {   // rows no sphere touches: depth = background, stored while wave 0 builds the list
     int cv0, cv1;
     touched_rows(sph, valid, ay, ky, r0, r1, cv0, cv1);
@@ -871,6 +871,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
     }
   }
   __syncthreads();
+  if (!(wave_s == 0 || bg_wave)) sph = s_sph[lane];
   const bool general = s_flag[0] != 0;
   ua = rfl(s_flag[2]);
   ub = rfl(s_flag[3]);
