@@ -303,22 +303,51 @@ __device__ __forceinline__ float axis_coord_t(const Axis &a, int u) {
   return POW2 ? t * a.mul : (t * 300.0f) / a.size;
 }
 
-// Streaming stores (no reuse on this GPU: the depth map is read next by another kernel,
-// possibly on another XCD): written through instead of left dirty in the L2 for the
-// end-of-kernel write-back.
-typedef float v4f_t __attribute__((ext_vector_type(4)));
+// Output stores are written THROUGH at agent scope (`sc1`): the depth map is read next by
+// another kernel, possibly on another XCD, so every line has to reach memory before the
+// kernel can retire anyway.  Left dirty in the L2 they are flushed by the end-of-kernel
+// write-back (plain stores: forward 8.9 us; `nt`: 8.05 or 8.45 us depending on the process;
+// `sc1`: 7.8 us in every process, tools/exp_storebits.sh).  Mode digits for the experiment
+// builds (-DSHR_STORE_MODE=<depth><owner>, -DSHR_BWD_STORE_MODE=<grad>): 0 plain, 1 nt,
+// 2 sc0 sc1, 3 sc0 sc1 nt, 4 sc1, 5 sc0, 6 sc1 nt.
+#ifndef SHR_STORE_MODE
+#define SHR_STORE_MODE 44
+#endif
+#ifndef SHR_BWD_STORE_MODE
+#define SHR_BWD_STORE_MODE 4
+#endif
 typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+// (the s_nop covers the "store of more than 64 bits, then its data registers rewritten"
+// hazard the compiler cannot see inside an asm statement)
+template <int M> __device__ __forceinline__ void asm_store16(void *p, v4u_t t) {
+  if (M == 0) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+  if (M == 1) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+  if (M == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+  if (M == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+  if (M == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+  if (M == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+  if (M == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+template <int M> __device__ __forceinline__ void asm_store4(void *p, uint32_t t) {
+  if (M == 0) asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(t) : "memory");
+  if (M == 1) asm volatile("global_store_dword %0, %1, off nt" ::"v"(p), "v"(t) : "memory");
+  if (M == 2) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
+  if (M == 3) asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(t) : "memory");
+  if (M == 4) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+  if (M == 5) asm volatile("global_store_dword %0, %1, off sc0" ::"v"(p), "v"(t) : "memory");
+  if (M == 6) asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(t) : "memory");
+}
 __device__ __forceinline__ void stream_store(float4 *p, const float4 v) {
-  v4f_t t = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(t, reinterpret_cast<v4f_t *>(p));
+  v4u_t t = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  asm_store16<SHR_STORE_MODE / 10>(p, t);
 }
 __device__ __forceinline__ void stream_store(uint4 *p, const uint4 v) {
   v4u_t t = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(t, reinterpret_cast<v4u_t *>(p));
+  asm_store16<SHR_STORE_MODE % 10>(p, t);
 }
 __device__ __forceinline__ void stream_store(uchar4 *p, const uchar4 v) {
   const uint32_t t = (uint32_t)v.x | ((uint32_t)v.y << 8) | ((uint32_t)v.z << 16) | ((uint32_t)v.w << 24);
-  __builtin_nontemporal_store(t, reinterpret_cast<uint32_t *>(p));
+  asm_store4<SHR_STORE_MODE % 10>(p, t);
 }
 
 template <bool OWNER> struct KeyOf { using type = uint32_t; };
@@ -773,7 +802,8 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
       t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
     }
     t.w = t.w * s_sph[tid].w;
-    grad_spheres[(size_t)n * J + tid] = t;
+    const v4u_t tt = {__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w)};
+    asm_store16<SHR_BWD_STORE_MODE>(grad_spheres + (size_t)n * J + tid, tt);
   }
 }
 
