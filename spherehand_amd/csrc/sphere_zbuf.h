@@ -236,21 +236,38 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
       // lane -> (lx, ly) inside a chunk: ly = lane / pw through fp32 ((lane + 1/2) / pw is
       // at least 1/128 away from an integer, v_rcp_f32 is good to 1 ulp)
       const int ly = (int)(lane_mid * __builtin_amdgcn_rcpf((float)pw));
-      const int lx = lane - ly * pw;
+      const int lx = lane - __mul24(ly, pw);   // (24-bit multiplies: v_mul_lo_u32 is quarter rate)
       const bool packed = ly < ph;
       if (ncx == 1) {
         const int u = u0 + lx;
         const float dx = axis_coord_t<POW2>(ax, u) - s.x;
         const float ca = rr - dx * dx;
         int v = v0 + c * ph + ly;
-        int cell = (v - r0) * LW + u;
+        int cell = __mul24(v - r0, LW) + u;
         const int dcell = ph * LW;
-        for (; c < c_end; c += 2, v += 2 * ph, cell += 2 * dcell) {
-          const float dya = axis_coord_t<POW2>(ay, v) - s.y, dyb = axis_coord_t<POW2>(ay, v + ph) - s.y;
-          float qa = ca - dya * dya, qb = ca - dyb * dyb;
-          qa = (packed && v <= v1) ? qa : -1.f;
-          qb = (packed && v + ph <= v1) ? qb : -1.f;
-          body(j, s, cell, cell + dcell, dx, dya, dyb, qa, qb, c + 1 < c_end);
+        if (POW2) {
+          // power-of-two image: the grid coordinates are multiples of 300 / S below 2^24 --
+          // exact in fp32, so the row coordinate is carried by additions, and "row <= v1"
+          // is a comparison of coordinates (half a pixel of margin)
+          float yg = axis_coord_t<true>(ay, v);
+          const float dyg = (float)ph * ay.mul, ylim = axis_coord_t<true>(ay, v1) + 0.5f * ay.mul;
+          const float cav = packed ? ca : -1.f;
+          for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell) {
+            const float ygb = yg + dyg;
+            const float dya = yg - s.y, dyb = ygb - s.y;
+            float qa = cav - dya * dya, qb = cav - dyb * dyb;
+            qa = yg <= ylim ? qa : -1.f;
+            qb = ygb <= ylim ? qb : -1.f;
+            body(j, s, cell, cell + dcell, dx, dya, dyb, qa, qb, c + 1 < c_end);
+          }
+        } else {
+          for (; c < c_end; c += 2, v += 2 * ph, cell += 2 * dcell) {
+            const float dya = axis_coord_t<POW2>(ay, v) - s.y, dyb = axis_coord_t<POW2>(ay, v + ph) - s.y;
+            float qa = ca - dya * dya, qb = ca - dyb * dyb;
+            qa = (packed && v <= v1) ? qa : -1.f;
+            qb = (packed && v + ph <= v1) ? qb : -1.f;
+            body(j, s, cell, cell + dcell, dx, dya, dyb, qa, qb, c + 1 < c_end);
+          }
         }
       } else {   // a box wider than a wave: pw = 64, ph = 1, chunk = (row c / ncx, segment c % ncx)
         for (; c < c_end; ++c) {

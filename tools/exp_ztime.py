@@ -3,7 +3,7 @@ import torch, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "libexpt.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "tools", os.environ.get("EXPLIB", "libexpt.so")))
 vp, ci = ctypes.c_void_p, ctypes.c_int
 lib.exp_zfwd_t_launch.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, ci, vp, vp]
 SHARES = int(os.environ.get('SHARES', '0x40404040'), 16)
