@@ -71,6 +71,29 @@ __device__ __forceinline__ float wave_sum_lane63(float v) {
   return v;
 }
 
+// Four wave sums at once ("transposed" reduction): two quad exchanges leave ONE register
+// whose lane l holds component l & 3 summed over its quad (9 ops for the 4 components),
+// then the remaining four levels run on that single register -- row_shr:4, row_shr:8,
+// and the gfx950 cross-row swaps (v_permlane16_swap / v_permlane32_swap: odd <-> even
+// rows, upper <-> lower half).  15 VALU ops against 24 for four wave_sum_lane63, fixed
+// association.  Lanes 12..15 of EVERY row return the totals of components 0..3; the
+// other lanes return partial sums.
+__device__ __forceinline__ float wave_sum4_transposed(float a0, float a1, float a2, float a3, int lane) {
+  const bool odd = lane & 1, hi = lane & 2;
+  const float k0 = odd ? a1 : a0, s0 = odd ? a0 : a1;
+  const float k1 = odd ? a3 : a2, s1 = odd ? a2 : a3;
+  const float b0 = k0 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0xB1, 0xF, 0xF, false));
+  const float b1 = k1 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0xB1, 0xF, 0xF, false));
+  const float k2 = hi ? b1 : b0, s2 = hi ? b0 : b1;
+  float c = k2 + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0x4E, 0xF, 0xF, false));
+  c = dpp_add<0x114, 0xF>(c);   // row_shr:4
+  c = dpp_add<0x118, 0xF>(c);   // row_shr:8  -> lanes 12..15 of a row: the row's sums
+  const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(c), __float_as_uint(c), false, false);
+  c = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);   // rows 0+1 | 2+3
+  const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(c), false, false);
+  return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+}
+
 // min / max over the 64 lanes, broadcast to every lane (same DPP butterfly; lanes whose
 // DPP source is invalid or masked combine with their own value)
 template <int CTRL, int ROW_MASK, bool IS_MIN>

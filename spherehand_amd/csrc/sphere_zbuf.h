@@ -800,13 +800,10 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
           if (has_b) take(cell_b, dyb, qb);
         },
         [&](int j) {
-          const float sx = wave_sum_lane63(a0), sy = wave_sum_lane63(a1);
-          const float sz = wave_sum_lane63(a2), sw = wave_sum_lane63(a3);
-          if (lane == 63) {
-            float4 t = s_part[wave * SHR_MAX_SPHERES + j];
-            t.x += sx; t.y += sy; t.z += sz; t.w += sw;
-            s_part[wave * SHR_MAX_SPHERES + j] = t;
-          }
+          // (the slot belongs to this wave: ds_add_f32 in program order, no read-back to wait for;
+          // a crop of several row regions visits a sphere once per region)
+          const float t = wave_sum4_transposed(a0, a1, a2, a3, lane);
+          if (lane >= 60) atomicAdd(reinterpret_cast<float *>(s_part + wave * SHR_MAX_SPHERES + j) + (lane & 3), t);
           a0 = a1 = a2 = a3 = 0.f;
         });
   }
@@ -997,13 +994,10 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
           if (has_b) take(cell_b, dyb, qb);
         },
         [&](int j) {
-          const float sx = wave_sum_lane63(a0), sy = wave_sum_lane63(a1);
-          const float sz = wave_sum_lane63(a2), sw = wave_sum_lane63(a3);
-          if (lane == 63) {
-            float4 t = s_part[wave * SHR_MAX_SPHERES + j];
-            t.x += sx; t.y += sy; t.z += sz; t.w += sw;
-            s_part[wave * SHR_MAX_SPHERES + j] = t;
-          }
+          // (the slot belongs to this wave: ds_add_f32 in program order, no read-back to wait for;
+          // a crop of several row regions visits a sphere once per region)
+          const float t = wave_sum4_transposed(a0, a1, a2, a3, lane);
+          if (lane >= 60) atomicAdd(reinterpret_cast<float *>(s_part + wave * SHR_MAX_SPHERES + j) + (lane & 3), t);
           a0 = a1 = a2 = a3 = 0.f;
         });
   } else {

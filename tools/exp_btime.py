@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 from spherehand_amd import ops
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "libexpb.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "tools", os.environ.get("EXPLIB", "libexpb.so")))
 vp, ci = ctypes.c_void_p, ctypes.c_int
 lib.exp_zbwd_t_launch.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp, ci, ci, vp, vp]
 SHARES = int(os.environ.get('SHARES', '0x40404040'), 16)
