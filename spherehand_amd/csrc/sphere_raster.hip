@@ -16,7 +16,7 @@ struct Tuning {
   int force_general = 0;                // 1: always the tile kernels (tests)
   int fwd_waves = 16;                   // waves per forward workgroup
   int fwd_shares = 0x28384858;          // work-list shares of the four wave age groups, oldest in the low byte (sum 256)
-  int bwd_shares = 0x183c505c;
+  int bwd_shares = 0x2c3a4654;
 } g_tune;
 
 constexpr int kMaxLds = 160 * 1024;

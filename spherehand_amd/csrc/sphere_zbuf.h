@@ -207,11 +207,12 @@ __device__ __forceinline__ float axis_coord_t(const Axis &a, int u);
 // sphere.  Per sphere the lane layout (lx, ly) and the column term c = r*r - dx*dx are
 // set up once; a chunk then costs its row coordinate, dy*dy and one subtraction before
 // `body(j, s, cell_a, cell_b, dx, dy_a, dy_b, q_a, q_b, has_b)` -- two consecutive chunks
-// per call (independent dependency chains), q = (r*r - dx*dx) - dy*dy in the reference's
-// association, cell = (v - r0) * LW + u the pixel's index in the region's LDS arrays.
-// Lanes that have no pixel in a chunk (beyond the last row, the packing remainder, or
-// past the box's right edge in a column segment) get q = -1: no hit.  `end_sphere(j)`
-// closes a run on sphere j.
+// per call (independent dependency chains).  The body gets the pixel's cell = (v - r0) * LW + u
+// in the region's LDS arrays, dx = xg - x, ca = r*r - dx*dx, the row coordinate yg and whether
+// the lane HAS a pixel in the chunk (not beyond the last row, the packing remainder, or the
+// box's right edge in a column segment); it forms q = ca - (yg - y)^2 -- the reference's
+// association -- when it needs it (the backward only for pixels the sphere owns).
+// `end_sphere(j)` closes a run on sphere j.
 template <bool POW2, int kSphereCost, typename Body, typename EndSphere>
 __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int hi, int lane, const Axis &ax,
                                            const Axis &ay, int r0, int LW, Body &&body, EndSphere &&end_sphere) {
@@ -247,37 +248,27 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
         const int dcell = ph * LW;
         if (POW2) {
           // power-of-two image: the grid coordinates are multiples of 300 / S below 2^24 --
-          // exact in fp32, so the row coordinate is carried by additions, and "row <= v1"
-          // is a comparison of coordinates (half a pixel of margin)
+          // exact in fp32, so the row coordinate is carried by additions, and "a lane of the
+          // packing whose row is <= v1" is ONE comparison of coordinates (half a pixel of
+          // margin; the limit of a lane outside the packing is -huge)
           float yg = axis_coord_t<true>(ay, v);
-          const float dyg = (float)ph * ay.mul, ylim = axis_coord_t<true>(ay, v1) + 0.5f * ay.mul;
-          const float cav = packed ? ca : -1.f;
+          const float dyg = (float)ph * ay.mul;
+          const float ylim = packed ? axis_coord_t<true>(ay, v1) + 0.5f * ay.mul : -3.0e38f;
           for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell) {
             const float ygb = yg + dyg;
-            const float dya = yg - s.y, dyb = ygb - s.y;
-            float qa = cav - dya * dya, qb = cav - dyb * dyb;
-            qa = yg <= ylim ? qa : -1.f;
-            qb = ygb <= ylim ? qb : -1.f;
-            body(j, s, cell, cell + dcell, dx, dya, dyb, qa, qb, c + 1 < c_end);
+            body(j, s, cell, cell + dcell, dx, ca, yg, ygb, yg <= ylim, ygb <= ylim, c + 1 < c_end);
           }
         } else {
-          for (; c < c_end; c += 2, v += 2 * ph, cell += 2 * dcell) {
-            const float dya = axis_coord_t<POW2>(ay, v) - s.y, dyb = axis_coord_t<POW2>(ay, v + ph) - s.y;
-            float qa = ca - dya * dya, qb = ca - dyb * dyb;
-            qa = (packed && v <= v1) ? qa : -1.f;
-            qb = (packed && v + ph <= v1) ? qb : -1.f;
-            body(j, s, cell, cell + dcell, dx, dya, dyb, qa, qb, c + 1 < c_end);
-          }
+          for (; c < c_end; c += 2, v += 2 * ph, cell += 2 * dcell)
+            body(j, s, cell, cell + dcell, dx, ca, axis_coord_t<POW2>(ay, v), axis_coord_t<POW2>(ay, v + ph),
+                 packed && v <= v1, packed && v + ph <= v1, c + 1 < c_end);
         }
       } else {   // a box wider than a wave: pw = 64, ph = 1, chunk = (row c / ncx, segment c % ncx)
         for (; c < c_end; ++c) {
           const int g = rfl((int)(((float)c + 0.5f) / (float)ncx));
           const int u = u0 + ((c - g * ncx) << 6) + lane, v = v0 + g;
           const float dx = axis_coord_t<POW2>(ax, u) - s.x;
-          const float dy = axis_coord_t<POW2>(ay, v) - s.y;
-          float q = (rr - dx * dx) - dy * dy;
-          q = u <= u1 ? q : -1.f;
-          body(j, s, (v - r0) * LW + u, 0, dx, dy, 0.f, q, -1.f, false);
+          body(j, s, (v - r0) * LW + u, 0, dx, rr - dx * dx, axis_coord_t<POW2>(ay, v), 0.f, u <= u1, false, false);
         }
       }
       end_sphere(j);
@@ -539,7 +530,10 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
     wl.end = s_ends[lane];
     walk_my_slice<POW2, kSphereCostFwd>(
         wl, J, s_flag[1], wave, nwaves, shares, lane, ax, ay, r0, LW,
-        [&](int j, const float4 s, int cell_a, int cell_b, float, float, float, float qa, float qb, bool has_b) {
+        [&](int j, const float4 s, int cell_a, int cell_b, float, float ca, float yga, float ygb, bool ok_a,
+            bool ok_b, bool has_b) {
+          const float dya = yga - s.y, dyb = ygb - s.y;
+          const float qa = ok_a ? ca - dya * dya : -1.f, qb = ok_b ? ca - dyb * dyb : -1.f;
           auto put = [&](Key *cell, float d) {
             if (OWNER)
               atomicMin(reinterpret_cast<unsigned long long *>(cell),
@@ -780,14 +774,15 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     const WaveList wl = load_wave_list(s_sph, s_items, s_ends, lane);
     walk_my_slice<POW2, kSphereCostBwd>(
         wl, J, s_flag[1], wave, kZWaves, shares, lane, ax, ay, r0, LW,
-        [&](int j, const float4 s, int cell_a, int cell_b, float dx, float dya, float dyb, float qa, float qb,
-            bool has_b) {
-          auto take = [&](int cell, float dy, float q) {
-            // lanes without a pixel (q = -1) may point past the region: clamped, and never counted
-            // (a branch-free form with all four LDS reads in flight measured slower: most chunks
-            // own nothing and skip the arithmetic)
+        [&](int j, const float4 s, int cell_a, int cell_b, float dx, float ca, float yga, float ygb, bool ok_a,
+            bool ok_b, bool has_b) {
+          auto take = [&](int cell, float yg, bool ok) {
+            // lanes without a pixel may point past the region: clamped, and never counted.  Most
+            // chunks own nothing: only the owner byte is looked at, dy and q are formed for owned
+            // pixels (a branch-free form with all four LDS reads in flight measured slower)
             cell = min(cell, cell_max);
-            if (obuf[cell] == (uint8_t)j && q > 0.f) {
+            if (obuf[cell] == (uint8_t)j && ok) {
+              const float dy = yg - s.y, q = ca - dy * dy;
               const float g = gbuf[cell];
               const float w = g * __builtin_amdgcn_rsqf(q);  // g / sqrt(q), ~1e-7 rel.
               a0 = __builtin_fmaf(-w, dx, a0);
@@ -796,8 +791,8 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
               a3 -= w;
             }
           };
-          take(cell_a, dya, qa);
-          if (has_b) take(cell_b, dyb, qb);
+          take(cell_a, yga, ok_a);
+          if (has_b) take(cell_b, ygb, ok_b);
         },
         [&](int j) {
           // (the slot belongs to this wave: ds_add_f32 in program order, no read-back to wait for;
@@ -929,7 +924,10 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
     wl.end = s_ends[lane];
     walk_my_slice<POW2, kSphereCostMse>(
         wl, J, s_flag[1], wave, kZWaves, shares_fwd, lane, ax, ay, r0, LW,
-        [&](int j, const float4 s, int cell_a, int cell_b, float, float, float, float qa, float qb, bool has_b) {
+        [&](int j, const float4 s, int cell_a, int cell_b, float, float ca, float yga, float ygb, bool ok_a,
+            bool ok_b, bool has_b) {
+          const float dya = yga - s.y, dyb = ygb - s.y;
+          const float qa = ok_a ? ca - dya * dya : -1.f, qb = ok_b ? ca - dyb * dyb : -1.f;
           auto put = [&](Key *cell, float d) { atomicMin(cell, ((Key)depth_key(d) << 32) | (unsigned)j); };
           if (has_b) {
             const bool ha = qa > kHitMin, hb = qb > kHitMin;
@@ -977,11 +975,12 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
     const int cell_max = rh * LW - 1;
     walk_my_slice<POW2, kSphereCostMse>(
         wl, J, s_flag[1], wave, kZWaves, shares_bwd, lane, ax, ay, r0, LW,
-        [&](int j, const float4 s, int cell_a, int cell_b, float dx, float dya, float dyb, float qa, float qb,
-            bool has_b) {
-          auto take = [&](int cell, float dy, float q) {
+        [&](int j, const float4 s, int cell_a, int cell_b, float dx, float ca, float yga, float ygb, bool ok_a,
+            bool ok_b, bool has_b) {
+          auto take = [&](int cell, float yg, bool ok) {
             const Key k = zbuf[min(cell, cell_max)];
-            if ((uint8_t)k == (uint8_t)j && q > 0.f) {
+            if ((uint8_t)k == (uint8_t)j && ok) {
+              const float dy = yg - s.y, q = ca - dy * dy;
               const float g = __uint_as_float((uint32_t)(k >> 32));
               const float w = g * __builtin_amdgcn_rsqf(q);
               a0 = __builtin_fmaf(-w, dx, a0);
@@ -990,8 +989,8 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
               a3 -= w;
             }
           };
-          take(cell_a, dya, qa);
-          if (has_b) take(cell_b, dyb, qb);
+          take(cell_a, yga, ok_a);
+          if (has_b) take(cell_b, ygb, ok_b);
         },
         [&](int j) {
           // (the slot belongs to this wave: ds_add_f32 in program order, no read-back to wait for;

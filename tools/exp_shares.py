@@ -28,7 +28,8 @@ def pack(a): return a[0] | a[1] << 8 | a[2] << 16 | a[3] << 24
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 cands = [(64, 64, 64, 64), (72, 66, 62, 56), (76, 68, 60, 52), (80, 70, 58, 48), (84, 70, 58, 44), (88, 72, 56, 40),
          (80, 72, 64, 40), (84, 74, 64, 34), (88, 76, 64, 28), (90, 78, 66, 22), (76, 70, 66, 44), (72, 70, 68, 46),
-         (92, 80, 60, 24), (86, 80, 70, 20), (96, 80, 64, 16)]
+         (92, 80, 60, 24), (86, 80, 70, 20), (96, 80, 64, 16), (88, 78, 60, 30), (84, 76, 60, 36), (88, 72, 60, 36),
+         (80, 72, 62, 42), (84, 72, 64, 36), (80, 76, 64, 36), (76, 72, 64, 44), (84, 78, 56, 38), (90, 74, 58, 34)]
 for c in cands:
     if which == "fwd":
         ops.set_tuning(ops.TUNE_FWD_SHARES, pack(c))
