@@ -41,6 +41,7 @@
 // the kernel); any other crop takes the general tile kernel (sphere_tile.h)
 // inside the same workgroup.
 #pragma once
+#include <type_traits>
 #include "sphere_tile.h"
 
 namespace shr {
@@ -208,14 +209,17 @@ __device__ __forceinline__ float axis_coord_t(const Axis &a, int u);
 // set up once; a chunk then costs its row coordinate, dy*dy and one subtraction before
 // `body(j, s, cell_a, cell_b, dx, dy_a, dy_b, q_a, q_b, has_b)` -- two consecutive chunks
 // per call (independent dependency chains).  The body gets the pixel's cell = (v - r0) * LW + u
-// in the region's LDS arrays, dx = xg - x, ca = r*r - dx*dx, the row coordinate yg and whether
-// the lane HAS a pixel in the chunk (not beyond the last row, the packing remainder, or the
-// box's right edge in a column segment); it forms q = ca - (yg - y)^2 -- the reference's
-// association -- when it needs it (the backward only for pixels the sphere owns).
+// in the region's LDS arrays, dx = xg - x, ca = r*r - dx*dx (-1 for a lane outside the packing),
+// the row coordinate yg, whether the lane HAS a pixel in the chunk (not beyond the last row,
+// the packing remainder, or the box's right edge in a column segment) and a compile-time tag:
+// false_type when that flag only repeats "inside the packing" (ca already says so).  The body
+// forms q = ca - (yg - y)^2 -- the reference's association -- when it needs it (the backward
+// only for pixels the sphere owns).
 // `end_sphere(j)` closes a run on sphere j.
-template <bool POW2, int kSphereCost, typename Body, typename EndSphere>
+template <bool POW2, int kSphereCost, bool ROWFREE, typename Body, typename EndSphere>
 __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int hi, int lane, const Axis &ax,
-                                           const Axis &ay, int r0, int LW, Body &&body, EndSphere &&end_sphere) {
+                                           const Axis &ay, int r0, int r1, int LW, Body &&body,
+                                           EndSphere &&end_sphere) {
   const float lane_mid = (float)lane + 0.5f;
   int j = __popcll(__ballot(lane < J && w.end <= lo));   // prefixes are non-decreasing
   while (j < J) {
@@ -246,29 +250,40 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
         int v = v0 + c * ph + ly;
         int cell = __mul24(v - r0, LW) + u;
         const int dcell = ph * LW;
+        const float cav = packed ? ca : -1.f;   // a lane outside the packing never hits
         if (POW2) {
           // power-of-two image: the grid coordinates are multiples of 300 / S below 2^24 --
-          // exact in fp32, so the row coordinate is carried by additions, and "a lane of the
-          // packing whose row is <= v1" is ONE comparison of coordinates (half a pixel of
-          // margin; the limit of a lane outside the packing is -huge)
+          // exact in fp32, so the row coordinate is carried by additions
           float yg = axis_coord_t<true>(ay, v);
           const float dyg = (float)ph * ay.mul;
-          const float ylim = packed ? axis_coord_t<true>(ay, v1) + 0.5f * ay.mul : -3.0e38f;
-          for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell) {
-            const float ygb = yg + dyg;
-            body(j, s, cell, cell + dcell, dx, ca, yg, ygb, yg <= ylim, ygb <= ylim, c + 1 < c_end);
+          if (ROWFREE && v1 < r1 - 1) {
+            // The box ends inside the region: the rows a last chunk reaches below it are real
+            // pixels, outside the (conservative) box -- the hit test fails there and the sphere
+            // owns none of them -- so no row test at all.  (ROWFREE: every cell of the region holds
+            // valid data.  The backward stages only the touched rows: it keeps the test.)
+            for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell)
+              body(j, s, cell, cell + dcell, dx, cav, yg, yg + dyg, packed, packed, c + 1 < c_end, std::false_type());
+          } else {
+            // clipped by the region's last row: "row <= v1" as ONE comparison of coordinates
+            // (half a pixel of margin; the limit of a lane outside the packing is -huge)
+            const float ylim = packed ? axis_coord_t<true>(ay, v1) + 0.5f * ay.mul : -3.0e38f;
+            for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell) {
+              const float ygb = yg + dyg;
+              body(j, s, cell, cell + dcell, dx, cav, yg, ygb, yg <= ylim, ygb <= ylim, c + 1 < c_end, std::true_type());
+            }
           }
         } else {
           for (; c < c_end; c += 2, v += 2 * ph, cell += 2 * dcell)
-            body(j, s, cell, cell + dcell, dx, ca, axis_coord_t<POW2>(ay, v), axis_coord_t<POW2>(ay, v + ph),
-                 packed && v <= v1, packed && v + ph <= v1, c + 1 < c_end);
+            body(j, s, cell, cell + dcell, dx, cav, axis_coord_t<POW2>(ay, v), axis_coord_t<POW2>(ay, v + ph),
+                 packed && v <= v1, packed && v + ph <= v1, c + 1 < c_end, std::true_type());
         }
       } else {   // a box wider than a wave: pw = 64, ph = 1, chunk = (row c / ncx, segment c % ncx)
         for (; c < c_end; ++c) {
           const int g = rfl((int)(((float)c + 0.5f) / (float)ncx));
           const int u = u0 + ((c - g * ncx) << 6) + lane, v = v0 + g;
           const float dx = axis_coord_t<POW2>(ax, u) - s.x;
-          body(j, s, (v - r0) * LW + u, 0, dx, rr - dx * dx, axis_coord_t<POW2>(ay, v), 0.f, u <= u1, false, false);
+          body(j, s, (v - r0) * LW + u, 0, dx, rr - dx * dx, axis_coord_t<POW2>(ay, v), 0.f, u <= u1, false, false,
+               std::true_type());
         }
       }
       end_sphere(j);
@@ -283,10 +298,10 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
 // `shares` gives the four age groups (waves 4g..4g+3) their part of the list, one byte per
 // group, oldest first, summing to 256 (the launcher normalises).  Other workgroup sizes
 // split equally.
-template <bool POW2, int kSphereCost, typename Body, typename EndSphere>
+template <bool POW2, int kSphereCost, bool ROWFREE, typename Body, typename EndSphere>
 __device__ __forceinline__ void walk_my_slice(const WaveList &w, int J, int total, int wave, int nwaves, int shares,
-                                              int lane, const Axis &ax, const Axis &ay, int r0, int LW, Body &&body,
-                                              EndSphere &&end_sphere) {
+                                              int lane, const Axis &ax, const Axis &ay, int r0, int r1, int LW,
+                                              Body &&body, EndSphere &&end_sphere) {
   wave = rfl(wave);   // everything that steers the loops is wave-uniform: keep it in SGPRs
   total = rfl(total);
   int lo, hi;
@@ -301,7 +316,7 @@ __device__ __forceinline__ void walk_my_slice(const WaveList &w, int J, int tota
     lo = (int)(((long long)wave * total) / nwaves);
     hi = (int)(((long long)(wave + 1) * total) / nwaves);
   }
-  if (lo < hi) walk_slice<POW2, kSphereCost>(w, J, lo, hi, lane, ax, ay, r0, LW, body, end_sphere);
+  if (lo < hi) walk_slice<POW2, kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere);
 }
 
 // image axis coordinate with the power-of-two case resolved at compile time
@@ -528,12 +543,13 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
     wl.sph = sph;
     wl.item = s_items[lane];
     wl.end = s_ends[lane];
-    walk_my_slice<POW2, kSphereCostFwd>(
-        wl, J, s_flag[1], wave, nwaves, shares, lane, ax, ay, r0, LW,
+    walk_my_slice<POW2, kSphereCostFwd, true>(
+        wl, J, s_flag[1], wave, nwaves, shares, lane, ax, ay, r0, r1, LW,
         [&](int j, const float4 s, int cell_a, int cell_b, float, float ca, float yga, float ygb, bool ok_a,
-            bool ok_b, bool has_b) {
+            bool ok_b, bool has_b, auto row_test) {
           const float dya = yga - s.y, dyb = ygb - s.y;
-          const float qa = ok_a ? ca - dya * dya : -1.f, qb = ok_b ? ca - dyb * dyb : -1.f;
+          float qa = ca - dya * dya, qb = ca - dyb * dyb;
+          if (decltype(row_test)::value) { qa = ok_a ? qa : -1.f; qb = ok_b ? qb : -1.f; }
           auto put = [&](Key *cell, float d) {
             if (OWNER)
               atomicMin(reinterpret_cast<unsigned long long *>(cell),
@@ -772,10 +788,10 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const int cell_max = (rh + kPadRows) * LW - 1;
     const WaveList wl = load_wave_list(s_sph, s_items, s_ends, lane);
-    walk_my_slice<POW2, kSphereCostBwd>(
-        wl, J, s_flag[1], wave, kZWaves, shares, lane, ax, ay, r0, LW,
+    walk_my_slice<POW2, kSphereCostBwd, false>(
+        wl, J, s_flag[1], wave, kZWaves, shares, lane, ax, ay, r0, r1, LW,
         [&](int j, const float4 s, int cell_a, int cell_b, float dx, float ca, float yga, float ygb, bool ok_a,
-            bool ok_b, bool has_b) {
+            bool ok_b, bool has_b, auto) {
           auto take = [&](int cell, float yg, bool ok) {
             // lanes without a pixel may point past the region: clamped, and never counted.  Most
             // chunks own nothing: only the owner byte is looked at, dy and q are formed for owned
@@ -922,12 +938,13 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
     wl.sph = sph;
     wl.item = s_items[lane];
     wl.end = s_ends[lane];
-    walk_my_slice<POW2, kSphereCostMse>(
-        wl, J, s_flag[1], wave, kZWaves, shares_fwd, lane, ax, ay, r0, LW,
+    walk_my_slice<POW2, kSphereCostMse, true>(
+        wl, J, s_flag[1], wave, kZWaves, shares_fwd, lane, ax, ay, r0, r1, LW,
         [&](int j, const float4 s, int cell_a, int cell_b, float, float ca, float yga, float ygb, bool ok_a,
-            bool ok_b, bool has_b) {
+            bool ok_b, bool has_b, auto row_test) {
           const float dya = yga - s.y, dyb = ygb - s.y;
-          const float qa = ok_a ? ca - dya * dya : -1.f, qb = ok_b ? ca - dyb * dyb : -1.f;
+          float qa = ca - dya * dya, qb = ca - dyb * dyb;
+          if (decltype(row_test)::value) { qa = ok_a ? qa : -1.f; qb = ok_b ? qb : -1.f; }
           auto put = [&](Key *cell, float d) { atomicMin(cell, ((Key)depth_key(d) << 32) | (unsigned)j); };
           if (has_b) {
             const bool ha = qa > kHitMin, hb = qb > kHitMin;
@@ -973,10 +990,10 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
     // ---- walk (backward): static slices, per-run DPP sums into the wave's LDS row ------------
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const int cell_max = rh * LW - 1;
-    walk_my_slice<POW2, kSphereCostMse>(
-        wl, J, s_flag[1], wave, kZWaves, shares_bwd, lane, ax, ay, r0, LW,
+    walk_my_slice<POW2, kSphereCostMse, true>(
+        wl, J, s_flag[1], wave, kZWaves, shares_bwd, lane, ax, ay, r0, r1, LW,
         [&](int j, const float4 s, int cell_a, int cell_b, float dx, float ca, float yga, float ygb, bool ok_a,
-            bool ok_b, bool has_b) {
+            bool ok_b, bool has_b, auto) {
           auto take = [&](int cell, float yg, bool ok) {
             const Key k = zbuf[min(cell, cell_max)];
             if ((uint8_t)k == (uint8_t)j && ok) {
