@@ -252,13 +252,10 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
             const int j = __builtin_amdgcn_readlane(owner, __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo)));
             const bool mine = owner == j;
             todo &= ~__ballot(mine);
-            const float sx = wave_sum_lane63(mine ? gx : 0.f), sy = wave_sum_lane63(mine ? gy : 0.f);
-            const float sz = wave_sum_lane63(mine ? gz : 0.f);
-            if (lane == 63) {
-              float4 t = s_part[wave * SHR_MAX_SPHERES + j];
-              t.x += sx; t.y += sy; t.z += sz;
-              s_part[wave * SHR_MAX_SPHERES + j] = t;
-            }
+            // (three sums in one transposed reduction; ds_add_f32 into the wave's own slot)
+            const float t = wave_sum4_transposed(mine ? gx : 0.f, mine ? gy : 0.f, mine ? gz : 0.f, 0.f, lane);
+            if (lane >= 60 && lane < 63)
+              atomicAdd(reinterpret_cast<float *>(s_part + wave * SHR_MAX_SPHERES + j) + (lane & 3), t);
           }
         }
       }
