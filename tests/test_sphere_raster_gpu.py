@@ -113,6 +113,35 @@ def test_random_spheres_vs_oracle(ops, oracle, N, J, H, W):
         assert np.abs(gs - og).max() <= 1e-5 * np.abs(og).max() + 1e-4
 
 
+@pytest.mark.parametrize("S", [64, 128, 256])
+def test_narrow_boxes_near_the_last_rows(ops, oracle, S):
+    """Narrow spheres (many rows per 64-lane chunk) whose boxes end on / just above the image's or a
+    row region's last row: the scan's last chunk reaches below the box there -- into rows of other
+    spheres, untouched rows and past the region.  Forward bit-exact, backward within the gradient
+    tolerance, with and without the saved owner map."""
+    rs = np.random.RandomState(S)
+    px = 300.0 / S
+    N, J = 6, 24
+    sp = np.zeros((N, J, 4), np.float32)
+    for n in range(N):
+        for j in range(J):
+            r = rs.uniform(1.2, 9.0) * px                      # boxes 2..18 px wide
+            last = rs.choice([S - 1, S - 2, S - 3, S // 2 - 1, S // 2, S // 4 - 1, rs.randint(4, S)])
+            yc = (last + rs.uniform(-0.4, 0.4) - S / 2) * px - r       # bottom edge of the disc near row `last`
+            sp[n, j] = (rs.uniform(-140, 140), yc, rs.uniform(-40, 60), r)
+    sp[:, -1, 2] = -80.0                                        # one sphere in front everywhere it reaches
+    d, a = ops.sphere_raster_fwd(dev(sp), S, S, want_argmin=True)
+    od, oa = oracle.sphere_raster_fwd(sp, S, S)
+    assert np.array_equal(bits(d.cpu().numpy()), bits(od))
+    assert np.array_equal(a.cpu().numpy(), oa)
+    gd = rs.standard_normal((N, S, S)).astype(np.float32)
+    og = oracle.sphere_raster_bwd(sp, gd)
+    for owner in (a, None):
+        gs = ops.sphere_raster_bwd(dev(sp), dev(gd), owner).cpu().numpy()
+        assert np.isfinite(gs).all()
+        assert np.abs(gs - og).max() <= 1e-5 * np.abs(og).max() + 1e-4
+
+
 def test_every_sphere_a_candidate_everywhere(ops, oracle):
     """Spheres bigger than the image, some deeper than the background: the min
     may exceed 100 only where all J spheres hit (reference min over J maps)."""
