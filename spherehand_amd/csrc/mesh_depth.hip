@@ -91,8 +91,12 @@ __device__ __forceinline__ FaceSetup face_setup_sorted(const float4 *__restrict_
   if (s.xi_min > s.xi_max) return s;
   const float ylo = fminf(fminf(s.p[0][1], s.p[1][1]), s.p[2][1]), yhi = fmaxf(fmaxf(s.p[0][1], s.p[1][1]), s.p[2][1]);
   const bool wild = !(fabsf(ylo) < 1e9f) || !(fabsf(yhi) < 1e9f);
-  s.r_lo = wild ? 0 : max(0, (int)floorf(ylo) - 1);
-  s.r_hi = wild ? src - 1 : min(src - 1, max(0, (int)ceilf(yhi) + 1));
+  // A column's span ends are edge interpolations slope * (x - xa) + ya at an x inside the edge:
+  // convex combinations of the vertices' y up to 4 roundings (<= 2.4e-7 * |y|); rows
+  // [ceil(min), trunc(max)] (.cu:89-90; a span end in (-1, 0) truncates to row 0).
+  const float yeps = 1e-5f * (fabsf(ylo) + fabsf(yhi)) + 1e-4f;
+  s.r_lo = wild ? 0 : max(0, (int)ceilf(ylo - yeps));
+  s.r_hi = wild ? src - 1 : min(src - 1, max(0, (int)floorf(yhi + yeps)));
   s.live = true;
   return s;
 }
@@ -312,8 +316,8 @@ extern "C" int shr_mesh_depth_fwd(const float *vertices, const int32_t *faces, i
   if (!vertices || (!faces && F > 0) || !depth || B < 0 || NV <= 0 || F < 0 || src_size <= 0 || S <= 0)
     return SHR_EINVAL;
   if (((uintptr_t)vertices & 15u) != 0) return SHR_EINVAL;
-  if (B > 65535 || S > 16384 || src_size > (1 << 20) || 2 * S > src_size + 1 || F > (1 << 24))
-    return SHR_ETOOLARGE;  // down-sampling only; work items pack the face index in 25 bits
+  if (B > 65535 || S > 16384 || src_size > (1 << 20) || S > src_size || F > (1 << 24))
+    return SHR_ETOOLARGE;  // no up-sampling; work items pack the face index in 25 bits
   hipStream_t s = (hipStream_t)stream;
   const float4 *v4 = reinterpret_cast<const float4 *>(vertices);
   // odd integer ratio: src = ratio * d + (ratio - 1) / 2 exactly, bilinear weights (1, 0)

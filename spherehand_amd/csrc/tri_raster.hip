@@ -9,26 +9,18 @@
 // The reference launches one single-thread block per face that walks the face's
 // pixel columns serially and CAS-loops a float min per pixel.  Here a wave takes
 // 64 faces: lanes = faces for the set-up (cull, sort by x, inverse barycentric
-// matrix), then the wave visits the surviving faces one by one with lanes = the
-// pixels of the face's box (set-up values broadcast through SGPRs).  Every
-// pixel repeats the reference's per-column span test and per-pixel arithmetic
-// verbatim (fp32, one rounding per written operator, IEEE division; the
+// matrix), then lanes = pixels of the faces' boxes -- small faces packed several
+// to a pass through LDS rows, larger ones visited alone with their values in
+// SGPRs.  Every pixel repeats the reference's per-column span test and per-pixel
+// arithmetic verbatim (fp32, one rounding per written operator, IEEE division; the
 // `1. / x` the reference evaluates in fp64 and rounds to fp32 equals the fp32
-// quotient exactly -- 53 >= 2*24+2 bits).  The z-buffer holds order-preserving
-// integer keys so the min is a native integer atomic (order independent, hence
-// deterministic); a second pass turns keys back into floats in place.
+// quotient exactly -- 53 >= 2*24+2 bits).  The float min is a native integer
+// atomic on the fp32 bits (signed min / unsigned max by sign: order independent,
+// hence deterministic); the image holds plain floats throughout: one fill pass,
+// one raster pass.
 #include "common.h"
 
 namespace shr {
-
-__device__ __forceinline__ uint32_t zkey(float d) {
-  const uint32_t b = __float_as_uint(d);
-  return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
-}
-constexpr uint32_t kZKeyInit = 0x447A0000u ^ 0x80000000u;  // zkey(1000.0f), .cu:122
-__device__ __forceinline__ float zkey_inv(uint32_t k) {
-  return __uint_as_float(k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu));
-}
 
 // CUDA double -> int32 conversion (cvt.rzi.s32.f64): truncate, saturate, NaN -> 0.
 // The operands here are fp32 values promoted to double, so fp32 compares suffice.
@@ -83,21 +75,35 @@ __device__ __forceinline__ FaceSetup face_setup(const float f[9], int width, int
   // :68-69  max(ceil(x0), 0.) / min(x2, width - 1.)  (fmax/fmin drop a NaN operand)
   s.xi_min = cvt_rz_sat(fmaxf(ceilf(p[0][0]), 0.f));
   s.xi_max = cvt_rz_sat(fminf(p[2][0], (float)width - 1.f));
-  // conservative row range of the columns' spans (the span ends are edge
-  // interpolations, inside the vertices' y range up to rounding; row 0 is always
-  // reachable: a negative span end truncates to 0, :89-90)
+  // conservative row range of the columns' spans
   const float ylo = fminf(fminf(p[0][1], p[1][1]), p[2][1]);
   const float yhi = fmaxf(fmaxf(p[0][1], p[1][1]), p[2][1]);
   const bool wild = !(fabsf(ylo) < 1e9f) || !(fabsf(yhi) < 1e9f);
-  s.r_lo = wild ? 0 : max(0, (int)floorf(ylo) - 1);
-  s.r_hi = wild ? height - 1 : min(height - 1, max(0, (int)ceilf(yhi) + 1));
+  // A column's span ends are edge interpolations slope * (x - xa) + ya at an x inside the edge:
+  // convex combinations of the vertices' y up to 4 roundings (<= 2.4e-7 * |y|); rows
+  // [ceil(min), trunc(max)] (.cu:89-90; a span end in (-1, 0) truncates to row 0).
+  const float yeps = 1e-5f * (fabsf(ylo) + fabsf(yhi)) + 1e-4f;
+  s.r_lo = wild ? 0 : max(0, (int)ceilf(ylo - yeps));
+  s.r_hi = wild ? height - 1 : min(height - 1, max(0, (int)floorf(yhi + yeps)));
   if (s.xi_min > s.xi_max) s.live = 0;
   return s;
 }
 
-// .cu:72-110 for pixel (xi, yi) of a set-up face whose values sit in SGPRs
+// Float min on the fp32 bits themselves, with native integer atomics: among non-negative
+// floats the bits order like signed integers, among negative ones like unsigned integers
+// reversed -- a signed MIN for a value whose sign bit is clear (an older negative entry is a
+// smaller signed integer and stays), an unsigned MAX for one whose sign bit is set (it beats
+// every non-negative entry, and the more negative of two negatives is the larger unsigned).
+// The image holds plain floats at all times: no decode pass.  NaN is never offered.
+__device__ __forceinline__ void zmin(float *cell, float v) {
+  const uint32_t b = __float_as_uint(v);
+  if (b >> 31) atomicMax(reinterpret_cast<unsigned int *>(cell), b);
+  else atomicMin(reinterpret_cast<int *>(cell), (int)b);
+}
+
+// .cu:72-110 for pixel (xi, yi) of a set-up face
 __device__ __forceinline__ void face_pixel(const float p[3][3], const float fi[9], int xi, int yi, int width,
-                                           int height, uint32_t *zrow_base) {
+                                           int height, float *zimg) {
   const float xf = (float)xi;
   float yi1;
   if (xf <= p[1][0]) {
@@ -123,13 +129,22 @@ __device__ __forceinline__ void face_pixel(const float p[3][3], const float fi[9
 #pragma unroll
   for (int k = 0; k < 3; k++) w[k] = w[k] / w_sum;
   const float zp = 1.0f / ((w[0] / p[0][2] + w[1] / p[1][2]) + w[2] / p[2][2]);
-  if (zp == zp) atomicMin(zrow_base + (size_t)yi * width + xi, zkey(zp));  // fminf(NaN, old) = old
+  if (zp == zp) zmin(zimg + (size_t)yi * width + xi, zp);  // fminf(NaN, old) = old
 }
+
+// Faces are small at 640x640 (a visible face of the hand mesh covers ~30 pixels): visiting
+// them one by one with 64 lanes on an 8x8 patch kept 1 lane in 8 on a pixel inside its
+// triangle.  Here a wave still sets 64 faces up with lanes = faces, parks each face's 24
+// values in LDS, and then works through GROUPS of 16 consecutive box pixels: a face of area
+// a owns ceil(a / 16) groups, a pass of the wave takes four groups -- of one face or of four
+// -- and every lane reads its own face's row (16 lanes share an address: a broadcast).
+constexpr int kFaceRow = 24;          // p[9], fi[9], x0, r_lo, bw, area, first group, 2^20 / bw
+constexpr int kGroupsPerFace = 16;    // faces with a box above 256 pixels are visited alone (below)
 
 template <bool INDEXED>
 __global__ void __launch_bounds__(256)
 tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, int B, int F, int NV, int width,
-                  int height, uint32_t *__restrict__ zbuf) {
+                  int height, float *__restrict__ zbuf) {
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int groups = (F + 63) / 64;
@@ -156,9 +171,69 @@ tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, 
     for (int k = 0; k < 9; k++) f[k] = 0.f;
   }
   FaceSetup s = face_setup(f, width, height);
-  unsigned long long live = __ballot(have && s.live);
-  uint32_t *zimg = zbuf + (size_t)b * width * height;
+  float *zimg = zbuf + (size_t)b * width * height;
+  __shared__ __attribute__((aligned(16))) float s_face[4][64][kFaceRow];
+  __shared__ uint8_t s_gface[4][64 * kGroupsPerFace];
+  const int wv = threadIdx.x >> 6;
 
+  const int bw = s.xi_max - s.xi_min + 1, bh = s.r_hi - s.r_lo + 1;
+  const bool alive = have && s.live && bh > 0 && bw > 0;
+  const long long area_ll = (long long)bw * bh;
+  const bool big = alive && area_ll > 16 * kGroupsPerFace;
+  const int area = alive && !big ? (int)area_ll : 0;
+  const int ng = (area + 15) >> 4;
+  // inclusive scan of the group counts over the wave
+  int incl = ng;
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
+  {
+    const int r0s = __builtin_amdgcn_readlane(incl, 15), r1s = __builtin_amdgcn_readlane(incl, 31);
+    const int r2s = __builtin_amdgcn_readlane(incl, 47);
+    const int row = lane >> 4;
+    incl += (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
+  }
+  const int first = incl - ng, total = __builtin_amdgcn_readlane(incl, 63);
+  {
+    float *r = s_face[wv][lane];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) r[3 * a + d] = s.p[a][d];
+#pragma unroll
+    for (int k = 0; k < 9; k++) r[9 + k] = s.fi[k];
+    r[18] = __int_as_float(s.xi_min); r[19] = __int_as_float(s.r_lo); r[20] = __int_as_float(bw);
+    r[21] = __int_as_float(area); r[22] = __int_as_float(first);
+    r[23] = __int_as_float(bw > 0 ? (int)(((1u << 20) + (unsigned)bw - 1u) / (unsigned)bw) : 0);
+    const int ngmax = (int)wave_minmax_all<false>((float)ng);
+    for (int k = 0; k < ngmax; k++)
+      if (k < ng) s_gface[wv][first + k] = (uint8_t)lane;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's LDS writes (the rows are private to the wave)
+  __builtin_amdgcn_wave_barrier();
+
+  for (int g0 = 0; g0 < total; g0 += 4) {
+    const int g = g0 + (lane >> 4);
+    if (g < total) {
+      const float4 *r4 = reinterpret_cast<const float4 *>(s_face[wv][s_gface[wv][g]]);
+      const float4 a0 = r4[0], a1 = r4[1], a2 = r4[2], a3 = r4[3], a4 = r4[4], a5 = r4[5];
+      const float p[3][3] = {{a0.x, a0.y, a0.z}, {a0.w, a1.x, a1.y}, {a1.z, a1.w, a2.x}};
+      const float fi[9] = {a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w, a4.x, a4.y};
+      const int x0 = __float_as_int(a4.z), y0 = __float_as_int(a4.w), fbw = __float_as_int(a5.x);
+      const int farea = __float_as_int(a5.y), ffirst = __float_as_int(a5.z);
+      const unsigned inv = (unsigned)__float_as_int(a5.w);
+      const int t = ((g - ffirst) << 4) + (lane & 15);
+      if (t < farea) {
+        const int ly = (int)(((unsigned)t * inv) >> 20);   // t / bw: exact for t <= 1024, bw <= 1024
+        const int lx = t - ly * fbw;
+        face_pixel(p, fi, x0 + lx, y0 + ly, width, height, zimg);
+      }
+    }
+  }
+
+  // the rare face with a large box: the whole wave on 8x8 patches of it, values through SGPRs
+  unsigned long long live = __ballot(big);
   while (live) {
     const int src_lane = __builtin_amdgcn_readfirstlane(__builtin_ctzll(live));
     live &= live - 1;
@@ -171,11 +246,8 @@ tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, 
     for (int k = 0; k < 9; k++) fi[k] = readlane_f(s.fi[k], src_lane);
     const int x0 = __builtin_amdgcn_readlane(s.xi_min, src_lane), x1 = __builtin_amdgcn_readlane(s.xi_max, src_lane);
     const int r0 = __builtin_amdgcn_readlane(s.r_lo, src_lane), r1 = __builtin_amdgcn_readlane(s.r_hi, src_lane);
-    const int bw = x1 - x0 + 1, bh = r1 - r0 + 1;
-    if (bh <= 0) continue;
-    // lanes tile the box 8 columns x 8 rows at a time
-    for (int oy = 0; oy < bh; oy += 8)
-      for (int ox = 0; ox < bw; ox += 8) {
+    for (int oy = 0; oy <= r1 - r0; oy += 8)
+      for (int ox = 0; ox <= x1 - x0; ox += 8) {
         const int xi = x0 + ox + (lane & 7), yi = r0 + oy + (lane >> 3);
         if (xi <= x1 && yi <= r1) face_pixel(p, fi, xi, yi, width, height, zimg);
       }
@@ -189,18 +261,6 @@ __global__ void zbuf_fill_kernel(uint4 *__restrict__ z, size_t n4, uint32_t key,
   const uint4 v = make_uint4(key, key, key, key);
   for (; i < n4; i += stride) z[i] = v;
   if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = key;
-}
-
-__global__ void zbuf_decode_kernel(uint4 *__restrict__ z, size_t n4, uint32_t *__restrict__ tail, int ntail) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n4; i += stride) {
-    uint4 k = z[i];
-    k.x = __float_as_uint(zkey_inv(k.x)); k.y = __float_as_uint(zkey_inv(k.y));
-    k.z = __float_as_uint(zkey_inv(k.z)); k.w = __float_as_uint(zkey_inv(k.w));
-    z[i] = k;
-  }
-  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = __float_as_uint(zkey_inv(tail[threadIdx.x]));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -251,17 +311,15 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
   const int ntail = (int)(n - n4 * 4);
   const unsigned fill_blocks = (unsigned)((n4 + 255) / 256 > 4096 ? 4096 : ((n4 + 255) / 256 ? (n4 + 255) / 256 : 1));
   hipLaunchKernelGGL(zbuf_fill_kernel, dim3(fill_blocks), dim3(256), 0, s, reinterpret_cast<uint4 *>(z), n4,
-                     kZKeyInit, z + n4 * 4, ntail);
+                     0x447A0000u /* 1000.0f, .cu:122 */, z + n4 * 4, ntail);
   if (F > 0) {
     const long long waves = (long long)B * ((F + 63) / 64);
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     if (indexed)
-      hipLaunchKernelGGL(tri_raster_kernel<true>, dim3(blocks), dim3(256), 0, s, src, faces, B, F, NV, W, H, z);
+      hipLaunchKernelGGL(tri_raster_kernel<true>, dim3(blocks), dim3(256), 0, s, src, faces, B, F, NV, W, H, depth);
     else
-      hipLaunchKernelGGL(tri_raster_kernel<false>, dim3(blocks), dim3(256), 0, s, src, faces, B, F, NV, W, H, z);
+      hipLaunchKernelGGL(tri_raster_kernel<false>, dim3(blocks), dim3(256), 0, s, src, faces, B, F, NV, W, H, depth);
   }
-  hipLaunchKernelGGL(zbuf_decode_kernel, dim3(fill_blocks), dim3(256), 0, s, reinterpret_cast<uint4 *>(z), n4,
-                     z + n4 * 4, ntail);
   return (int)hipGetLastError();
 }
 
