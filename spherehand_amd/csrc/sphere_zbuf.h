@@ -373,6 +373,23 @@ __device__ __forceinline__ void stream_store(uchar4 *p, const uchar4 v) {
   asm_store4<SHR_STORE_MODE % 10>(p, t);
 }
 
+// The touched rows' OWNER bytes (stored after the scan conversion) are the only part of the
+// output the backward reads, next, from the same XCD (crop n runs on XCD n % 8 in both
+// kernels): left in the L2 with a plain store instead of written through.  The forward alone
+// gets 0.18 us slower (dirty lines for the end-of-kernel write-back), forward + backward
+// 0.15 us faster (tools/exp_latestore.sh; -DSHR_LATE_STORE_MODE=<depth><owner> to vary).
+#ifndef SHR_LATE_STORE_MODE
+#define SHR_LATE_STORE_MODE 40
+#endif
+__device__ __forceinline__ void late_store(float4 *p, const float4 v) {
+  v4u_t t = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  asm_store16<SHR_LATE_STORE_MODE / 10>(p, t);
+}
+__device__ __forceinline__ void late_store(uchar4 *p, const uchar4 v) {
+  const uint32_t t = (uint32_t)v.x | ((uint32_t)v.y << 8) | ((uint32_t)v.z << 16) | ((uint32_t)v.w << 24);
+  asm_store4<SHR_LATE_STORE_MODE % 10>(p, t);
+}
+
 template <bool OWNER> struct KeyOf { using type = uint32_t; };
 template <> struct KeyOf<true> { using type = unsigned long long; };
 
@@ -586,12 +603,12 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
         const ulonglong2 k23 = reinterpret_cast<const ulonglong2 *>(cell)[1];
         o = make_float4(key_depth((uint32_t)(k01.x >> 32)), key_depth((uint32_t)(k01.y >> 32)),
                         key_depth((uint32_t)(k23.x >> 32)), key_depth((uint32_t)(k23.y >> 32)));
-        stream_store(aout4 + c, make_uchar4((uint8_t)k01.x, (uint8_t)k01.y, (uint8_t)k23.x, (uint8_t)k23.y));
+        late_store(aout4 + c, make_uchar4((uint8_t)k01.x, (uint8_t)k01.y, (uint8_t)k23.x, (uint8_t)k23.y));
       } else {
         const uint4 k = *reinterpret_cast<const uint4 *>(cell);
         o = make_float4(key_depth(k.x), key_depth(k.y), key_depth(k.z), key_depth(k.w));
       }
-      stream_store(out4 + c, o);
+      late_store(out4 + c, o);
     }
   } else {
     for (int p = tid; p < rh * W; p += nthr) {
