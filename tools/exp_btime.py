@@ -16,10 +16,15 @@ gs = torch.empty(N, J, 4, device=dev)
 tbuf = torch.zeros(N * 16 * 8, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 MODE = os.environ.get("MODE", "fwd_bwd")
+lib.exp_copy_records_launch.argtypes = [vp, vp, ci, ci, vp]
+rec = spheres.clone()
+COPY = os.environ.get("COPY", "0") == "1"
 for _ in range(50):
+    if COPY:   # the records the backward reads were just written by workgroup n of a preceding kernel
+        lib.exp_copy_records_launch(spheres.data_ptr(), rec.data_ptr(), N, J, st)
     if MODE == "fwd_bwd":
         ops.sphere_raster_fwd(spheres, S, S, want_argmin=True)   # as in the bench: forward, then backward
-    lib.exp_zbwd_t_launch(spheres.data_ptr(), grad.data_ptr(), owner.data_ptr(), N, J, S, S, gs.data_ptr(), 128, SHARES, tbuf.data_ptr(), st)
+    lib.exp_zbwd_t_launch((rec if COPY else spheres).data_ptr(), grad.data_ptr(), owner.data_ptr(), N, J, S, S, gs.data_ptr(), 128, SHARES, tbuf.data_ptr(), st)
 torch.cuda.synchronize()
 ref = ops.sphere_raster_bwd(spheres, grad, owner)
 print("max |diff| vs library:", (gs - ref).abs().max().item())
