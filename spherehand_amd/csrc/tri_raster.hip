@@ -8,10 +8,10 @@
 //
 // The reference launches one single-thread block per face that walks the face's
 // pixel columns serially and CAS-loops a float min per pixel.  Here a wave takes
-// 64 faces: lanes = faces for the set-up (cull, sort by x, inverse barycentric
-// matrix), then lanes = pixels of the faces' boxes -- small faces packed several
-// to a pass through LDS rows, larger ones visited alone with their values in
-// SGPRs.  Every pixel repeats the reference's per-column span test and per-pixel
+// 32 faces: lanes = faces for the set-up (cull, sort by x, inverse barycentric
+// matrix), then lanes = pixels of the faces' boxes for the span test and lanes =
+// pixels inside their span for the depth (see tri_raster_kernel below).
+// Every pixel repeats the reference's per-column span test and per-pixel
 // arithmetic verbatim (fp32, one rounding per written operator, IEEE division; the
 // `1. / x` the reference evaluates in fp64 and rounds to fp32 equals the fp32
 // quotient exactly -- 53 >= 2*24+2 bits).  The float min is a native integer
@@ -101,23 +101,26 @@ __device__ __forceinline__ void zmin(float *cell, float v) {
   else atomicMin(reinterpret_cast<int *>(cell), (int)b);
 }
 
-// .cu:72-110 for pixel (xi, yi) of a set-up face
-__device__ __forceinline__ void face_pixel(const float p[3][3], const float fi[9], int xi, int yi, int width,
-                                           int height, float *zimg) {
+// .cu:72-90: is row yi inside column xi's span of the face?  pxy = (x0, y0, x1, y1, x2, y2), sorted by x.
+__device__ __forceinline__ bool span_inside(const float pxy[6], int xi, int yi, int height) {
   const float xf = (float)xi;
   float yi1;
-  if (xf <= p[1][0]) {
-    if (p[1][0] - p[0][0] != 0.f) yi1 = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (xf - p[0][0]) + p[0][1];
-    else yi1 = p[1][1];
+  if (xf <= pxy[2]) {
+    if (pxy[2] - pxy[0] != 0.f) yi1 = (pxy[3] - pxy[1]) / (pxy[2] - pxy[0]) * (xf - pxy[0]) + pxy[1];
+    else yi1 = pxy[3];
   } else {
-    if (p[2][0] - p[1][0] != 0.f) yi1 = (p[2][1] - p[1][1]) / (p[2][0] - p[1][0]) * (xf - p[1][0]) + p[1][1];
-    else yi1 = p[1][1];
+    if (pxy[4] - pxy[2] != 0.f) yi1 = (pxy[5] - pxy[3]) / (pxy[4] - pxy[2]) * (xf - pxy[2]) + pxy[3];
+    else yi1 = pxy[3];
   }
-  const float yi2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * (xf - p[0][0]) + p[0][1];
+  const float yi2 = (pxy[5] - pxy[1]) / (pxy[4] - pxy[0]) * (xf - pxy[0]) + pxy[1];
   const int yi_min = cvt_rz_sat(fmaxf(0.f, ceilf(fminf(yi1, yi2))));
   const int yi_max = cvt_rz_sat(fminf(fmaxf(yi1, yi2), (float)height - 1.f));
-  if (yi < yi_min || yi > yi_max) return;
-  const float yf = (float)yi;
+  return yi >= yi_min && yi <= yi_max;
+}
+
+// .cu:97-110 for a pixel inside its column's span
+__device__ __forceinline__ void span_pixel(const float pz[3], const float fi[9], int xi, int yi, int width, float *zimg) {
+  const float xf = (float)xi, yf = (float)yi;
   float w[3];
   float w_sum = 0.f;
 #pragma unroll
@@ -128,18 +131,22 @@ __device__ __forceinline__ void face_pixel(const float p[3][3], const float fi[9
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) w[k] = w[k] / w_sum;
-  const float zp = 1.0f / ((w[0] / p[0][2] + w[1] / p[1][2]) + w[2] / p[2][2]);
+  const float zp = 1.0f / ((w[0] / pz[0] + w[1] / pz[1]) + w[2] / pz[2]);
   if (zp == zp) zmin(zimg + (size_t)yi * width + xi, zp);  // fminf(NaN, old) = old
 }
 
-// Faces are small at 640x640 (a visible face of the hand mesh covers ~30 pixels): visiting
-// them one by one with 64 lanes on an 8x8 patch kept 1 lane in 8 on a pixel inside its
-// triangle.  Here a wave still sets 64 faces up with lanes = faces, parks each face's 24
-// values in LDS, and then works through GROUPS of 16 consecutive box pixels: a face of area
-// a owns ceil(a / 16) groups, a pass of the wave takes four groups -- of one face or of four
-// -- and every lane reads its own face's row (16 lanes share an address: a broadcast).
-constexpr int kFaceRow = 24;          // p[9], fi[9], x0, r_lo, bw, area, first group, 2^20 / bw
-constexpr int kGroupsPerFace = 16;    // faces with a box above 256 pixels are visited alone (below)
+// A visible face of the hand mesh covers a ~16x16-pixel box at 640x640 and one box pixel in
+// three lies inside its column's span.  A wave sets 64 faces up with lanes = faces and parks
+// each face's values in an LDS row; then
+//   pass A, lanes = box pixels: faces up to 256 box pixels are worked through in GROUPS of 16
+//     consecutive box pixels, four groups -- of one face or of four -- per pass (larger faces:
+//     the whole wave on 8x8 patches, values through SGPRs); a lane only runs the SPAN TEST
+//     (3 of the 10 IEEE divisions) and queues (face, x, y) in LDS if its pixel is inside;
+//   pass B, lanes = queued pixels, 64 at a time, every lane busy: the 7 divisions of the
+//     barycentric weights and the perspective depth, then the atomic.
+constexpr int kFaceRow = 28;          // x0 y0 x1 y1 x2 y2 - - | z0 z1 z2 fi[9] | box x0, r_lo, bw, area, first group, 2^20 / bw, - -
+constexpr int kGroupsPerFace = 16;    // faces with a box above 256 pixels are visited alone
+constexpr int kFacesPerWave = 32;     // 5 KB of LDS per wave (rows, group table, queue): eight waves per SIMD fit
 
 template <bool INDEXED>
 __global__ void __launch_bounds__(256)
@@ -147,13 +154,13 @@ tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, 
                   int height, float *__restrict__ zbuf) {
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int groups = (F + 63) / 64;
+  const int groups = (F + kFacesPerWave - 1) / kFacesPerWave;
   const int b = wave_global / groups;
   if (b >= B) return;
-  const int fidx = (wave_global - b * groups) * 64 + lane;
+  const int fidx = (wave_global - b * groups) * kFacesPerWave + lane;
 
   float f[9];
-  bool have = fidx < F;
+  bool have = lane < kFacesPerWave && fidx < F;
   if (have) {
     if (INDEXED) {  // vertices [B,NV,4] + faces [F,3]: the gather of mesh/render.py:308-309 fused
 #pragma unroll
@@ -172,8 +179,9 @@ tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, 
   }
   FaceSetup s = face_setup(f, width, height);
   float *zimg = zbuf + (size_t)b * width * height;
-  __shared__ __attribute__((aligned(16))) float s_face[4][64][kFaceRow];
-  __shared__ uint8_t s_gface[4][64 * kGroupsPerFace];
+  __shared__ __attribute__((aligned(16))) float s_face[4][kFacesPerWave][kFaceRow];
+  __shared__ uint8_t s_gface[4][kFacesPerWave * kGroupsPerFace];
+  __shared__ uint2 s_queue[4][128];
   const int wv = threadIdx.x >> 6;
 
   const int bw = s.xi_max - s.xi_min + 1, bh = s.r_hi - s.r_lo + 1;
@@ -195,63 +203,87 @@ tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, 
     incl += (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
   }
   const int first = incl - ng, total = __builtin_amdgcn_readlane(incl, 63);
-  {
+  if (lane < kFacesPerWave) {
     float *r = s_face[wv][lane];
 #pragma unroll
-    for (int a = 0; a < 3; a++)
+    for (int a = 0; a < 3; a++) { r[2 * a] = s.p[a][0]; r[2 * a + 1] = s.p[a][1]; r[8 + a] = s.p[a][2]; }
 #pragma unroll
-      for (int d = 0; d < 3; d++) r[3 * a + d] = s.p[a][d];
-#pragma unroll
-    for (int k = 0; k < 9; k++) r[9 + k] = s.fi[k];
-    r[18] = __int_as_float(s.xi_min); r[19] = __int_as_float(s.r_lo); r[20] = __int_as_float(bw);
-    r[21] = __int_as_float(area); r[22] = __int_as_float(first);
-    r[23] = __int_as_float(bw > 0 ? (int)(((1u << 20) + (unsigned)bw - 1u) / (unsigned)bw) : 0);
+    for (int k = 0; k < 9; k++) r[11 + k] = s.fi[k];
+    r[20] = __int_as_float(s.xi_min); r[21] = __int_as_float(s.r_lo); r[22] = __int_as_float(bw);
+    r[23] = __int_as_float(area); r[24] = __int_as_float(first);
+    r[25] = __int_as_float(bw > 0 ? (int)(((1u << 20) + (unsigned)bw - 1u) / (unsigned)bw) : 0);
+  }
+  {
     const int ngmax = (int)wave_minmax_all<false>((float)ng);
     for (int k = 0; k < ngmax; k++)
       if (k < ng) s_gface[wv][first + k] = (uint8_t)lane;
   }
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's LDS writes (the rows are private to the wave)
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's LDS writes (rows, tables and queue are private to the wave)
   __builtin_amdgcn_wave_barrier();
+
+  int qn = 0;   // queued pixels (wave-uniform)
+  auto drain = [&](int take) {   // pass B on the last `take` queued pixels
+    if (lane < take) {
+      const uint2 e = s_queue[wv][qn - take + lane];
+      const float4 *r4 = reinterpret_cast<const float4 *>(s_face[wv][e.x]);
+      const float4 b2 = r4[2], b3 = r4[3], b4 = r4[4];
+      const float pz[3] = {b2.x, b2.y, b2.z};
+      const float fi[9] = {b2.w, b3.x, b3.y, b3.z, b3.w, b4.x, b4.y, b4.z, b4.w};
+      span_pixel(pz, fi, (int)(e.y & 0xffffu), (int)(e.y >> 16), width, zimg);
+    }
+    qn -= take;
+  };
+  auto push = [&](bool inside, int face, int xi, int yi) {
+    const unsigned long long m = __ballot(inside);
+    if (m == 0ull) return;
+    if (inside) {
+      const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      s_queue[wv][pos] = make_uint2((unsigned)face, (unsigned)xi | ((unsigned)yi << 16));
+    }
+    qn += __popcll(m);
+    if (qn >= 64) drain(64);
+  };
 
   for (int g0 = 0; g0 < total; g0 += 4) {
     const int g = g0 + (lane >> 4);
+    bool inside = false;
+    int face = 0, xi = 0, yi = 0;
     if (g < total) {
-      const float4 *r4 = reinterpret_cast<const float4 *>(s_face[wv][s_gface[wv][g]]);
-      const float4 a0 = r4[0], a1 = r4[1], a2 = r4[2], a3 = r4[3], a4 = r4[4], a5 = r4[5];
-      const float p[3][3] = {{a0.x, a0.y, a0.z}, {a0.w, a1.x, a1.y}, {a1.z, a1.w, a2.x}};
-      const float fi[9] = {a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w, a4.x, a4.y};
-      const int x0 = __float_as_int(a4.z), y0 = __float_as_int(a4.w), fbw = __float_as_int(a5.x);
-      const int farea = __float_as_int(a5.y), ffirst = __float_as_int(a5.z);
-      const unsigned inv = (unsigned)__float_as_int(a5.w);
+      face = s_gface[wv][g];
+      const float4 *r4 = reinterpret_cast<const float4 *>(s_face[wv][face]);
+      const float4 a0 = r4[0], a1 = r4[1], i0 = r4[5], i1 = r4[6];
+      const float pxy[6] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y};
+      const int x0 = __float_as_int(i0.x), y0 = __float_as_int(i0.y), fbw = __float_as_int(i0.z);
+      const int farea = __float_as_int(i0.w), ffirst = __float_as_int(i1.x);
+      const unsigned inv = (unsigned)__float_as_int(i1.y);
       const int t = ((g - ffirst) << 4) + (lane & 15);
       if (t < farea) {
         const int ly = (int)(((unsigned)t * inv) >> 20);   // t / bw: exact for t <= 1024, bw <= 1024
-        const int lx = t - ly * fbw;
-        face_pixel(p, fi, x0 + lx, y0 + ly, width, height, zimg);
+        xi = x0 + (t - ly * fbw);
+        yi = y0 + ly;
+        inside = span_inside(pxy, xi, yi, height);
       }
     }
+    push(inside, face, xi, yi);
   }
 
-  // the rare face with a large box: the whole wave on 8x8 patches of it, values through SGPRs
+  // the faces with a large box: the whole wave on 8x8 patches of one face, values through SGPRs
   unsigned long long live = __ballot(big);
   while (live) {
     const int src_lane = __builtin_amdgcn_readfirstlane(__builtin_ctzll(live));
     live &= live - 1;
-    float p[3][3], fi[9];
+    float pxy[6];
 #pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int d = 0; d < 3; d++) p[a][d] = readlane_f(s.p[a][d], src_lane);
-#pragma unroll
-    for (int k = 0; k < 9; k++) fi[k] = readlane_f(s.fi[k], src_lane);
+    for (int a = 0; a < 3; a++) { pxy[2 * a] = readlane_f(s.p[a][0], src_lane); pxy[2 * a + 1] = readlane_f(s.p[a][1], src_lane); }
     const int x0 = __builtin_amdgcn_readlane(s.xi_min, src_lane), x1 = __builtin_amdgcn_readlane(s.xi_max, src_lane);
     const int r0 = __builtin_amdgcn_readlane(s.r_lo, src_lane), r1 = __builtin_amdgcn_readlane(s.r_hi, src_lane);
     for (int oy = 0; oy <= r1 - r0; oy += 8)
       for (int ox = 0; ox <= x1 - x0; ox += 8) {
         const int xi = x0 + ox + (lane & 7), yi = r0 + oy + (lane >> 3);
-        if (xi <= x1 && yi <= r1) face_pixel(p, fi, xi, yi, width, height, zimg);
+        push(xi <= x1 && yi <= r1 && span_inside(pxy, xi, yi, height), src_lane, xi, yi);
       }
   }
+  if (qn > 0) drain(qn);
 }
 
 __global__ void zbuf_fill_kernel(uint4 *__restrict__ z, size_t n4, uint32_t key, uint32_t *__restrict__ tail,
@@ -313,7 +345,7 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
   hipLaunchKernelGGL(zbuf_fill_kernel, dim3(fill_blocks), dim3(256), 0, s, reinterpret_cast<uint4 *>(z), n4,
                      0x447A0000u /* 1000.0f, .cu:122 */, z + n4 * 4, ntail);
   if (F > 0) {
-    const long long waves = (long long)B * ((F + 63) / 64);
+    const long long waves = (long long)B * ((F + kFacesPerWave - 1) / kFacesPerWave);
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     if (indexed)
       hipLaunchKernelGGL(tri_raster_kernel<true>, dim3(blocks), dim3(256), 0, s, src, faces, B, F, NV, W, H, depth);
@@ -327,7 +359,8 @@ extern "C" int shr_tri_raster_fwd(const float *face_vertices, int B, int F, int 
                                   void *stream) {
   if (B == 0) return SHR_OK;
   if (!depth || (!face_vertices && F > 0) || B < 0 || F < 0 || W <= 0 || H <= 0) return SHR_EINVAL;
-  if ((long long)B * W * H > (1LL << 40) || (long long)B * ((F + 63) / 64) > (1LL << 31)) return SHR_ETOOLARGE;
+  if ((long long)B * W * H > (1LL << 40) || (long long)B * ((F + 31) / 32) > (1LL << 31) || W > 65535 || H > 65535)
+    return SHR_ETOOLARGE;   // (pixel coordinates travel in 16 bits)
   if (((uintptr_t)depth & 15u) != 0) return SHR_EINVAL;
   return tri_raster_common(false, face_vertices, nullptr, B, F, 0, W, H, depth, (hipStream_t)stream);
 }
@@ -336,7 +369,8 @@ extern "C" int shr_tri_raster_indexed_fwd(const float *vertices, const int32_t *
                                           int H, float *depth, void *stream) {
   if (B == 0) return SHR_OK;
   if (!depth || !vertices || (!faces && F > 0) || B < 0 || F < 0 || NV <= 0 || W <= 0 || H <= 0) return SHR_EINVAL;
-  if ((long long)B * W * H > (1LL << 40) || (long long)B * ((F + 63) / 64) > (1LL << 31)) return SHR_ETOOLARGE;
+  if ((long long)B * W * H > (1LL << 40) || (long long)B * ((F + 31) / 32) > (1LL << 31) || W > 65535 || H > 65535)
+    return SHR_ETOOLARGE;
   if ((((uintptr_t)depth | (uintptr_t)vertices) & 15u) != 0) return SHR_EINVAL;
   return tri_raster_common(true, vertices, faces, B, F, NV, W, H, depth, (hipStream_t)stream);
 }
