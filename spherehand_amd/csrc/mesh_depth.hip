@@ -90,7 +90,9 @@ __device__ __forceinline__ FaceSetup face_setup_sorted(const float4 *__restrict_
   s.xi_max = m_cvt_rz_sat(fminf(s.p[2][0], (float)src - 1.f));
   if (s.xi_min > s.xi_max) return s;
   const float ylo = fminf(fminf(s.p[0][1], s.p[1][1]), s.p[2][1]), yhi = fmaxf(fmaxf(s.p[0][1], s.p[1][1]), s.p[2][1]);
-  const bool wild = !(fabsf(ylo) < 1e9f) || !(fabsf(yhi) < 1e9f);
+  // (a face whose largest x lies in (-1, 0) still reaches column 0 -- the reference truncates x2 towards zero,
+  // .cu:69 -- and the span there is an EXTRApolation of the edges: any row)
+  const bool wild = !(fabsf(ylo) < 1e9f) || !(fabsf(yhi) < 1e9f) || s.p[2][0] < 0.f;
   // A column's span ends are edge interpolations slope * (x - xa) + ya at an x inside the edge:
   // convex combinations of the vertices' y up to 4 roundings (<= 2.4e-7 * |y|); rows
   // [ceil(min), trunc(max)] (.cu:89-90; a span end in (-1, 0) truncates to row 0).

@@ -78,7 +78,9 @@ __device__ __forceinline__ FaceSetup face_setup(const float f[9], int width, int
   // conservative row range of the columns' spans
   const float ylo = fminf(fminf(p[0][1], p[1][1]), p[2][1]);
   const float yhi = fmaxf(fmaxf(p[0][1], p[1][1]), p[2][1]);
-  const bool wild = !(fabsf(ylo) < 1e9f) || !(fabsf(yhi) < 1e9f);
+  // (a face whose largest x lies in (-1, 0) still reaches column 0 -- the reference truncates x2 towards zero,
+  // .cu:69 -- and the span there is an EXTRApolation of the edges: any row)
+  const bool wild = !(fabsf(ylo) < 1e9f) || !(fabsf(yhi) < 1e9f) || p[2][0] < 0.f;
   // A column's span ends are edge interpolations slope * (x - xa) + ya at an x inside the edge:
   // convex combinations of the vertices' y up to 4 roundings (<= 2.4e-7 * |y|); rows
   // [ceil(min), trunc(max)] (.cu:89-90; a span end in (-1, 0) truncates to row 0).

@@ -47,6 +47,7 @@ def test_tri_raster_quirks_and_edge_cases(oracle):
         [[np.nan, 1, 3], [4, 2, 3], [7, 9, 3]],
         [[3, 12, 2], [12, 3, 2], [3, 3, -2]],
         [[-40, -30, 7], [60, -20, 7], [10, 70, 7]],            # larger than the image
+        [[-0.7, 7.1, 5], [-3.2, 14.3, 7], [-9.4, 7.6, 6]],     # left of the image, x2 in (-1, 0): column 0 by truncation, rows EXTRApolated
     ], np.float32)[None]
     for fv in (tri, tri[:, ::-1], tri[:, :, [1, 0, 2], :]):
         for (W, H) in ((16, 16), (17, 9), (5, 33)):
@@ -68,6 +69,19 @@ def test_random_faces_vs_oracle(oracle):
     B, F, W, H = 3, 500, 96, 72
     c = rs.uniform(-10, [W + 10, H + 10], (B, F, 1, 2))
     fv = np.concatenate([c + rs.normal(0, 6, (B, F, 3, 2)), rs.uniform(-30, 60, (B, F, 3, 1))], -1).astype(np.float32)
+    d = depth_rasterization.forward(W, H, dev(fv)).cpu().numpy()
+    assert np.array_equal(bits(d), bits(oracle.tri_raster_fwd(fv, W, H)))
+
+
+def test_random_large_faces_vs_oracle(oracle):
+    """Boxes above 256 pixels (visited alone, 8x8 patches) mixed with small ones (16-pixel groups), depths of
+    both signs (signed-min / unsigned-max atomics on the float bits), F not a multiple of the faces per wave."""
+    import depth_rasterization
+    rs = np.random.RandomState(11)
+    B, F, W, H = 2, 333, 200, 160
+    c = rs.uniform(-20, [W + 20, H + 20], (B, F, 1, 2))
+    spread = rs.choice([3.0, 12.0, 40.0], (B, F, 1, 1))
+    fv = np.concatenate([c + rs.normal(0, 1, (B, F, 3, 2)) * spread, rs.uniform(-50, 50, (B, F, 3, 1))], -1).astype(np.float32)
     d = depth_rasterization.forward(W, H, dev(fv)).cpu().numpy()
     assert np.array_equal(bits(d), bits(oracle.tri_raster_fwd(fv, W, H)))
 
