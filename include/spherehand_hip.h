@@ -222,8 +222,8 @@ int shr_tri_raster_indexed_fwd(const float *vertices, const int32_t *faces, int 
  * only the source pixels the resize reads.  Replaces the chain
  * DepthRasterizationFunction.apply(640,640,...) / clamp / F.interpolate of
  * mesh/render.py:284-287, :310-311.  vertices[B,NV,4] in src_size pixel space, faces[F,3]
- * (winding already swapped for the right hand).  depth[B,S,S].  Needs 2*S <= src_size + 1
- * (a down-sampling). */
+ * (winding already swapped for the right hand).  depth[B,S,S].  Needs S <= src_size
+ * (no up-sampling; S == src_size is the clamped raster itself). */
 int shr_mesh_depth_fwd(const float *vertices, const int32_t *faces, int B, int NV, int F,
                        int src_size, int S, float clamp_max, float *depth, void *stream);
 

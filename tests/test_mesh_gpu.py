@@ -157,6 +157,24 @@ def test_fused_depth_render_equals_the_explicit_chain(S):
     assert (fused < 100).float().mean().item() > 0.02
 
 
+@pytest.mark.parametrize("S", [400, 500, 640])
+def test_tile_kernel_at_small_ratios(S):
+    """shr_mesh_depth_fwd accepts any S <= 640: ratios below 2 (every source pixel sampled, bilinear weights on
+    both neighbours) against the explicit raster -> clamp -> F.interpolate chain; S = 640 is the raster itself."""
+    from spherehand_amd import hand_model, ops
+    g = golden("g2_mesh.npz")
+    faces = torch.from_numpy(hand_model.load_mesh()["faces"].astype(np.int32)).cuda()[:, [0, 2, 1]].contiguous()
+    verts = dev(g["verts"])[:2].contiguous()
+    tile = ops.mesh_depth_fwd(verts, faces, S, 640, 100.0)
+    raw = ops.tri_raster_indexed_fwd(640, 640, verts, faces)
+    chain = torch.nn.functional.interpolate(torch.clamp(raw, max=100.0).unsqueeze(1), size=(S, S), mode="bilinear",
+                                            align_corners=False).squeeze(1)
+    assert (tile - chain).abs().max().item() <= 1e-5 * max(1.0, chain.abs().max().item())
+    if S == 640:
+        assert torch.equal(tile, torch.clamp(raw, max=100.0))
+    assert (tile < 100).float().mean().item() > 0.02
+
+
 def test_fused_depth_render_rand_f_and_batch():
     from spherehand_amd import hand_model
     from spherehand_amd.joint_angle import sample_poses
