@@ -1,0 +1,85 @@
+"""Randomised differential testing of the HIP kernels against the CPU oracle (run on the GPU box; the permanent
+tests in tests/ are fixed seeds, this explores).  usage: python tools/fuzz.py [seconds per family] [seed]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import depth_rasterization
+from oracle import oracle
+from spherehand_amd import ops
+oracle.build()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
+fails = 0
+
+def sphere_case():
+    global fails
+    H = int(rs.choice([8, 16, 33, 64, 96, 128, 130, 200, 256])); W = int(rs.choice([8, 16, 36, 64, 100, 128, 132, 256, 258]))
+    N = int(rs.randint(1, 5)); J = int(rs.choice([1, 2, 7, 41, 64]))
+    scale = rs.choice([20.0, 80.0, 160.0, 400.0])
+    sp = np.concatenate([rs.uniform(-scale, scale, (N, J, 2)), rs.uniform(-120, 130, (N, J, 1)),
+                         rs.uniform(0.02, 1.0, (N, J, 1)) * rs.choice([2.0, 12.0, 45.0, 300.0])], -1).astype(np.float32)
+    if rs.rand() < 0.3: sp[:, :, 3] *= rs.choice([-1.0, 1.0], (N, J))          # negative radii (|r| matters)
+    if rs.rand() < 0.2: sp[:, :, 2] = np.abs(sp[:, :, 2]) + 101                  # everything behind the background
+    mode = rs.randint(0, 4)
+    ops.set_tuning(ops.TUNE_FORCE_GENERAL, 1 if mode == 1 else 0)
+    ops.set_tuning(ops.TUNE_FWD_LDS_BYTES, 16 * 1024 if mode == 2 else 80 * 1024)
+    ops.set_tuning(ops.TUNE_FWD_OWNER_LDS_BYTES, 24 * 1024 if mode == 2 else 0)
+    ops.set_tuning(ops.TUNE_BWD_LDS_BYTES, 16 * 1024 if mode == 2 else 128 * 1024)
+    ops.set_tuning(ops.TUNE_FWD_WAVES, 4 if mode == 3 else 16)
+    d, a = ops.sphere_raster_fwd(dev(sp), H, W, want_argmin=True)
+    od, oa = oracle.sphere_raster_fwd(sp, H, W)
+    ok = np.array_equal(bits(d.cpu().numpy()), bits(od)) and np.array_equal(a.cpu().numpy(), oa)
+    gd = rs.standard_normal((N, H, W)).astype(np.float32)
+    og = oracle.sphere_raster_bwd(sp, gd)
+    for owner in (a, None):
+        gs = ops.sphere_raster_bwd(dev(sp), dev(gd), owner).cpu().numpy()
+        ok = ok and bool(np.abs(gs - og).max() <= 1e-5 * np.abs(og).max() + 2e-4)
+    tgt = rs.uniform(-50, 100, (N, H, W)).astype(np.float32)
+    if ops.sphere_raster_mse_supported(dev(sp), dev(tgt), H, W):
+        dep, sse, gsp = ops.sphere_raster_mse(dev(sp), dev(tgt))
+        e = (od.astype(np.float64) - tgt)
+        ok = ok and np.array_equal(bits(dep.cpu().numpy()), bits(od))
+        ref_sse = (e * e).reshape(N, -1).sum(1)
+        ok = ok and bool(np.abs(sse.double().cpu().numpy() - ref_sse).max() <= 1e-5 * ref_sse.max() + 1e-3)
+        og2 = oracle.sphere_raster_bwd(sp, (2 * (od - tgt)).astype(np.float32))
+        ok = ok and bool(np.abs(gsp.cpu().numpy() - og2).max() <= 2e-5 * np.abs(og2).max() + 1e-3)
+    if not ok:
+        fails += 1
+        print("SPHERE MISMATCH", dict(N=N, J=J, H=H, W=W, scale=scale, mode=mode))
+
+def tri_case():
+    global fails
+    W = int(rs.choice([5, 16, 33, 96, 200, 320])); H = int(rs.choice([7, 16, 40, 72, 160, 256]))
+    B = int(rs.randint(1, 4)); F = int(rs.choice([1, 31, 33, 64, 200, 500]))
+    c = rs.uniform(-0.2 * W, 1.2 * W, (B, F, 1, 1)) * np.array([1.0, H / W])
+    spread = rs.choice([0.7, 3.0, 12.0, 60.0], (B, F, 1, 1))
+    fv = np.concatenate([c + rs.normal(0, 1, (B, F, 3, 2)) * spread, rs.uniform(-50, 50, (B, F, 3, 1))], -1).astype(np.float32)
+    if rs.rand() < 0.3: fv[:, :, :, 0] = np.round(fv[:, :, :, 0])               # vertices on pixel columns, equal x
+    if rs.rand() < 0.2: fv[:, ::7, 1] = fv[:, ::7, 0]                            # degenerate faces
+    d = depth_rasterization.forward(W, H, dev(fv)).cpu().numpy()
+    if not np.array_equal(bits(d), bits(oracle.tri_raster_fwd(fv, W, H))):
+        fails += 1
+        print("TRI MISMATCH", dict(B=B, F=F, W=W, H=H), int((bits(d) != bits(oracle.tri_raster_fwd(fv, W, H))).sum()))
+
+def d2m_case():
+    global fails
+    S = int(rs.choice([16, 64, 100, 128])); N = int(rs.randint(1, 4)); J = int(rs.choice([1, 5, 41]))
+    depth = np.where(rs.rand(N, S, S) < rs.uniform(0.02, 0.6), rs.uniform(-60, 60, (N, S, S)), 100.0).astype(np.float32)
+    cen = rs.uniform(-120, 120, (N, J, 3)).astype(np.float32); rad = rs.uniform(1, 30, (J,)).astype(np.float32)
+    loss, grad = ops.data_to_model(dev(depth), dev(cen), dev(rad), want_grad=True)
+    ol = oracle.data_to_model_fwd(depth, cen, rad); og = oracle.data_to_model_bwd(depth, cen, rad) * depth.size   # oracle: gradient of the mean
+    ok = bool(np.abs(loss.cpu().numpy() - ol).max() <= 1e-5 * np.abs(ol).max() + 1e-4)
+    ok = ok and bool(np.abs(grad.cpu().numpy() - og).max() <= 1e-5 * np.abs(og).max() + 1e-4)
+    if not ok:
+        fails += 1
+        print("D2M MISMATCH", dict(N=N, J=J, S=S))
+
+for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case)):
+    t0 = time.time(); n = 0
+    while time.time() - t0 < budget:
+        fn(); n += 1
+    print("%s: %d cases, %d mismatches so far" % (name, n, fails))
+sys.exit(1 if fails else 0)
