@@ -42,7 +42,9 @@ __device__ __forceinline__ int m_cvt_rz_sat(float d) {
 // src = scale*(d+0.5)-0.5 clamped at 0; i0 = (int)src; i1 = i0 + (i0 < in-1); l1 = src - i0.
 struct Lin { int i0, i1; float l0, l1; };
 __device__ __forceinline__ Lin lin_index(int d, float scale, int in_size) {
-  float src = scale * ((float)d + 0.5f) - 0.5f;
+  // (one rounding: ATen's GPU kernel is compiled with contraction, scale * (d + 0.5) - 0.5 is an FMA there;
+  // the two forms differ by an ulp of the source index at non-dyadic ratios, 3e-5 of a pixel at 256)
+  float src = __builtin_fmaf(scale, (float)d + 0.5f, -0.5f);
   if (src < 0.f) src = 0.f;
   Lin r;
   r.i0 = min((int)src, in_size - 1);

@@ -1,5 +1,5 @@
 """Randomised differential testing of the HIP kernels against the CPU oracle (run on the GPU box; the permanent
-tests in tests/ are fixed seeds, this explores).  usage: python tools/fuzz.py [seconds per family] [seed]"""
+tests in tests/ are fixed seeds, this explores).  usage: python tools/fuzz.py [seconds per family] [seed] [families]"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -77,7 +77,32 @@ def d2m_case():
         fails += 1
         print("D2M MISMATCH", dict(N=N, J=J, S=S))
 
-for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case)):
+def mesh_case():
+    """fused raster + clamp + bilinear resize against the explicit chain (which is checked against the oracle above)"""
+    global fails
+    src = int(rs.choice([640, 320, 257, 96])); S = int(rs.choice([s_ for s_ in (16, 32, 64, 96, 128, 200, 256, 400) if s_ <= src]))
+    B = int(rs.randint(1, 3)); NV = int(rs.choice([12, 200, 1500])); F = int(rs.choice([1, 100, 700, 3382]))
+    xy = rs.uniform(-0.15 * src, 1.15 * src, (B, NV, 2)); z = rs.uniform(-80, 140, (B, NV, 1))
+    verts = np.concatenate([xy, z, np.ones((B, NV, 1))], -1).astype(np.float32)
+    base = rs.randint(0, NV, (F, 1)); faces = ((base + rs.randint(0, max(2, NV // rs.choice([4, 40, 400])), (F, 3))) % NV).astype(np.int32)
+    if rs.rand() < 0.5:   # spatially coherent small faces: vertices sorted along x so that neighbouring indices are neighbours
+        verts = np.take_along_axis(verts, np.argsort(verts[:, :, 0] + verts[:, :, 1] * 0.01, 1)[:, :, None], 1)
+    tile = ops.mesh_depth_fwd(dev(verts), dev(faces), S, src, 100.0)
+    raw = ops.tri_raster_indexed_fwd(src, src, dev(verts), dev(faces))
+    chain = torch.nn.functional.interpolate(torch.clamp(raw, max=100.0).unsqueeze(1), size=(S, S), mode="bilinear",
+                                            align_corners=False).squeeze(1)
+    fv = verts[:, faces.reshape(-1), :3].reshape(B, F, 3, 3)
+    ok = np.array_equal(bits(raw.cpu().numpy()), bits(oracle.tri_raster_fwd(fv, src, src)))
+    ok = ok and bool((tile - chain).abs().max().item() <= 1e-5 * max(1.0, chain.abs().max().item()))
+    if not ok:
+        fails += 1
+        print("MESH MISMATCH", dict(B=B, NV=NV, F=F, src=src, S=S), (tile - chain).abs().max().item())
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_mesh_fail.npz"), verts=verts, faces=faces, S=S, src=src,
+                 tile=tile.cpu().numpy(), chain=chain.cpu().numpy(), raw=raw.cpu().numpy())
+
+for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case)):
+    if len(sys.argv) > 3 and name not in sys.argv[3].split(","): continue
     t0 = time.time(); n = 0
     while time.time() - t0 < budget:
         fn(); n += 1
