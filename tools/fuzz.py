@@ -101,7 +101,56 @@ def mesh_case():
         np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_mesh_fail.npz"), verts=verts, faces=faces, S=S, src=src,
                  tile=tile.cpu().numpy(), chain=chain.cpu().numpy(), raw=raw.cpu().numpy())
 
-for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case)):
+_fk = None
+def fk_case():
+    """forward kinematics forward / backward against the torch-op evaluation of the same chain"""
+    global fails, _fk
+    if _fk is None:
+        from spherehand_amd import hand_model
+        from spherehand_amd.kinematicsTransformation import HandTransformationMat
+        _fk = HandTransformationMat([b["offset_matrix"].astype(np.float32) for b in hand_model.load_mesh()["bones"]]).cuda()
+    B = int(rs.choice([1, 3, 64, 300]))
+    p = (rs.uniform(-1, 1, (B, 26)) * rs.choice([0.1, 1.5, 3.2, 10.0])).astype(np.float32)
+    p[:, 3:6] = rs.uniform(-60, 60, (B, 3))
+    p1 = dev(p).requires_grad_(True); p2 = dev(p).requires_grad_(True)
+    G = dev(rs.standard_normal((B, 17, 4, 4)).astype(np.float32))
+    T1 = _fk(p1); T2 = _fk.forward_torch(p2)
+    (T1 * G).sum().backward(); (T2 * G).sum().backward()
+    ok = bool((T1 - T2).abs().max().item() <= 3e-4) and bool((p1.grad - p2.grad).abs().max().item() <= 2e-4 * max(1.0, p2.grad.abs().max().item()))
+    if not ok:
+        fails += 1
+        print("FK MISMATCH", B, (T1 - T2).abs().max().item(), (p1.grad - p2.grad).abs().max().item(), p2.grad.abs().max().item())
+
+def gn_case():
+    """NHWC GroupNorm + ReLU forward / backward against torch in fp64"""
+    global fails
+    C = int(rs.choice([32, 64, 128, 256])); G = int(rs.choice([g for g in (4, 8, 16) if C % g == 0 and (C // g) % 4 == 0]))
+    N = int(rs.randint(1, 9)); H = int(rs.choice([1, 3, 4, 8, 16, 33])); W = int(rs.choice([1, 4, 7, 16, 32]))
+    # (offset in units of the spread: fp32 cannot resolve x - mean below ulp(mean) whatever the algorithm)
+    x = (torch.from_numpy(rs.standard_normal((N, C, H, W)).astype(np.float32)) + float(rs.uniform(-3, 3))) * float(rs.choice([0.01, 1.0, 30.0]))
+    x = x.cuda().to(memory_format=torch.channels_last).requires_grad_(True)
+    gn = torch.nn.GroupNorm(G, C).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(dev(rs.standard_normal(C).astype(np.float32))); gn.bias.copy_(dev(rs.standard_normal(C).astype(np.float32) * 0.5))
+    if not ops.group_norm_relu_supported(x, G):
+        return
+    up = dev(rs.standard_normal((N, C, H, W)).astype(np.float32)).to(memory_format=torch.channels_last)
+    y = ops.group_norm_relu(x, gn); (y * up).sum().backward()
+    got = (y.detach(), x.grad.clone(), gn.weight.grad.clone(), gn.bias.grad.clone())
+    xd = x.detach().double().requires_grad_(True)
+    gd = torch.nn.GroupNorm(G, C).cuda().double(); gd.load_state_dict({k: v.double() for k, v in gn.state_dict().items()})
+    z = gd(xd)
+    if (z.abs().min() < 1e-5 * z.abs().max()).item():
+        return   # an activation on the ReLU kink: fp32 and fp64 may disagree on its sign, the gradients then differ by a whole term
+    yr = torch.relu(z); (yr * up.double()).sum().backward()
+    ref = (yr.detach(), xd.grad, gd.weight.grad, gd.bias.grad)
+    for a, b, tol in zip(got, ref, (4e-6, 4e-5, 4e-5, 4e-5)):
+        if (a.double() - b).abs().max().item() > tol * max(1.0, b.abs().max().item()):
+            fails += 1
+            print("GN MISMATCH", dict(N=N, C=C, H=H, W=W, G=G), (a.double() - b).abs().max().item(), b.abs().max().item())
+            break
+
+for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case)):
     if len(sys.argv) > 3 and name not in sys.argv[3].split(","): continue
     t0 = time.time(); n = 0
     while time.time() - t0 < budget:
