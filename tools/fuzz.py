@@ -150,7 +150,41 @@ def gn_case():
             print("GN MISMATCH", dict(N=N, C=C, H=H, W=W, G=G), (a.double() - b).abs().max().item(), b.abs().max().item())
             break
 
-for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case)):
+_mv = {}
+def mv_case():
+    """MutualProjectionLoss: the fused path (render-and-compare kernel, indexed data-to-model) against the
+    reference wiring on the separate kernels -- loss, projections, gradient w.r.t. the joints"""
+    global fails
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    from spherehand_amd.datasets import random_rotations
+    S = int(rs.choice([32, 64, 128, 256])); J = 41
+    if S not in _mv:
+        from spherehand_amd import hand_model
+        _mv[S] = MutualProjectionLoss(S, hand_model.load_mesh()).cuda()
+    crit = _mv[S]
+    B = int(rs.randint(1, 5)); V = 3
+    gen = torch.Generator().manual_seed(int(rs.randint(1 << 30)))
+    R = random_rotations(B * V, float(rs.choice([5.0, 30.0, 90.0])), generator=gen).reshape(B, V, 3, 3)
+    cam = torch.eye(4).repeat(B, V, 1, 1); cam[:, :, :3, :3] = R; cam[:, :, :3, 3] = torch.from_numpy(rs.uniform(-10, 10, (B, V, 3)).astype(np.float32))
+    inv = torch.linalg.inv(cam)
+    joints = torch.from_numpy((rs.uniform(-70, 70, (B, V, J, 3)) * np.array([1, 1, 0.5])).astype(np.float32))
+    dms = torch.from_numpy(np.where(rs.rand(B, V, S, S) < 0.2, rs.uniform(-60, 60, (B, V, S, S)), 100.0).astype(np.float32))
+    is_mv = bool(rs.rand() < 0.5)
+    out = {}
+    for fused in (True, False):
+        crit.fused = fused
+        j = joints.cuda().requires_grad_(True)
+        loss, proj = crit(cam.cuda(), inv.cuda(), j, dms.cuda(), is_mv)
+        loss.backward()
+        out[fused] = (loss.item(), proj.detach().cpu().numpy(), j.grad.cpu().numpy())
+    ok = abs(out[True][0] - out[False][0]) <= 5e-6 * abs(out[False][0]) + 1e-6
+    ok = ok and np.array_equal(bits(out[True][1]), bits(out[False][1]))
+    ok = ok and bool(np.abs(out[True][2] - out[False][2]).max() <= 5e-5 * np.abs(out[False][2]).max() + 1e-7)
+    if not ok:
+        fails += 1
+        print("MV MISMATCH", dict(B=B, S=S, is_mv=is_mv), out[True][0], out[False][0], np.abs(out[True][2] - out[False][2]).max(), np.abs(out[False][2]).max())
+
+for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case), ("mv", mv_case)):
     if len(sys.argv) > 3 and name not in sys.argv[3].split(","): continue
     t0 = time.time(); n = 0
     while time.time() - t0 < budget:
