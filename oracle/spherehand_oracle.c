@@ -9,7 +9,7 @@
  *   - sphere path (oracle_ball_render, oracle_sphere_raster_fwd/_bwd),
  *     oracle_data_to_model_*, oracle_lbs_project, oracle_fk_fwd,
  *     oracle_clamp_bilinear: PINNED against outputs of the imported PyTorch
- *     reference generated in the build container (tests/golden/*.npz, made by
+ *     reference generated in the build container (tests/golden/ (the .npz files), made by
  *     tests/golden/make_goldens_*.py) -- bit-exact for the depth maps,
  *     tolerance for summed quantities (stated in the tests).
  *   - oracle_tri_raster_fwd: PARITY UNPINNED.  The reference kernel is CUDA
