@@ -209,7 +209,8 @@ int shr_mutual_project_bwd(const float *cam, const float *inv_cam, const float *
  * depth[B,H,W] is initialised to 1000 and receives, per covered pixel, the
  * minimum over faces of the 1/z-interpolated depth.  Coverage (back-face cull,
  * per-column spans with their truncation quirks) and arithmetic follow the
- * reference kernel; the result is order independent (integer-key atomic min). */
+ * reference kernel; the result is order independent (integer atomics on the fp32
+ * bits).  depth 16-byte aligned; W, H <= 65535 (SHR_ETOOLARGE beyond). */
 int shr_tri_raster_fwd(const float *face_vertices, int B, int F, int W, int H,
                        float *depth, void *stream);
 /* Same, with the face gather of DepthRasterization.forward (mesh/render.py:308-309)
