@@ -21,15 +21,16 @@
 //             touches straight from registers; the 16 waves then take contiguous
 //             slices of the list (lanes = pixels): exact reference arithmetic per
 //             pixel, one LDS atomic min per hit.  Finally the touched rows are
-//             decoded and streamed out with full-line 16-byte nt stores -- the
-//             only HBM traffic besides the 16*J-byte sphere read.
+//             decoded and streamed out with full-line 16-byte write-through
+//             stores -- the only HBM traffic besides the 16*J-byte sphere read.
 //   backward  one workgroup per crop.  The rows some sphere touches of grad_depth
 //             and of the forward's owner map are staged into LDS (the central half
 //             speculatively with the records, the rest once they are in); the
 //             waves walk the same chunk list in static slices, accumulate the
-//             four partials of the pixels a sphere owns in registers, one DPP
-//             wave-sum per (wave, sphere) run into a private LDS slot, slots
-//             combined in wave order: deterministic, no float atomics.
+//             four partials of the pixels a sphere owns in registers, ONE
+//             transposed four-component wave reduction per (wave, sphere) run
+//             into the wave's private LDS slot, slots combined in wave order:
+//             deterministic (the slot's ds_add_f32 is only ever this wave's).
 //   fused     forward + (depth - target)^2 + backward in one kernel for the
 //             model->data term of MutualProjectionLoss (sphere_zbuf_mse_kernel).
 //
