@@ -11,9 +11,9 @@ struct QEntry { float a, b, c; int d; };  // phase 2: (xg, yg, z, -) ; phase 3: 
 
 template <bool WANT_GRAD>
 __global__ void __launch_bounds__(kD2mThreads)
-exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
-                     const float *__restrict__ radii, int J, int H, int W, float *__restrict__ loss_sum,
-                     float *__restrict__ grad_centres, int mode) {
+exp_d2m(const float *__restrict__ depth, const int *__restrict__ depth_index,
+                     const float *__restrict__ centres, const float *__restrict__ radii, int J, int H, int W,
+                     float *__restrict__ loss_sum, float *__restrict__ grad_centres, int mode) {
   __shared__ float4 s_c[SHR_MAX_SPHERES];     // (cx, cy, cz, r)
   __shared__ int s_wave_cnt[kD2mThreads / 64];
   __shared__ float s_wave_loss[kD2mThreads / 64];
@@ -26,7 +26,7 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
     const float *c = centres + ((size_t)n * J + tid) * 3;
     s_c[tid] = make_float4(c[0], c[1], c[2], radii[tid]);
   }
-  const float *dm = depth + (size_t)n * H * W;
+  const float *dm = depth + (size_t)(depth_index ? depth_index[n] : n) * H * W;
   const Axis ax = make_axis(W), ay = make_axis(H);
   const bool row4 = (W % 4 == 0) && is_aligned16(dm);
 
@@ -37,12 +37,19 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
   // ceil(W/4) x ceil(H/4) block grid): each of a thread's four 16-byte loads is contiguous
   // with its neighbours' in x, and the queue (thread order, row-major inside a block) keeps
   // neighbouring pixels together, so a wave's 64 entries have a tight bounding box (step 3).
+  // The 512 blocks of a chunk form a 32 x 16 tile visited in Morton order: 64 consecutive
+  // threads = an 8 x 8 group of blocks (32 x 32 px), 4-5 consecutive blocks = a near-square
+  // patch, so the points a wave searches together are neighbours in x AND y.
   const int nbx = (W + 3) >> 2, nby = (H + 3) >> 2;
-  const int nblocks = nbx * nby;
-  for (int base = 0; base < nblocks; base += kD2mThreads) {
+  const int tiles_x = (nbx + 31) >> 5, tiles_y = (nby + 15) >> 4;
+  auto even_bits = [](int t) { t &= 0x55; t = (t | (t >> 1)) & 0x33; return (t | (t >> 2)) & 0x0f; };
+  static_assert(kD2mThreads == 512, "tile = 32 x 16 blocks");
+  const int mx = even_bits(tid) | ((tid >> 8) << 4), my = even_bits(tid >> 1);
+  for (int tile = 0; tile < tiles_x * tiles_y; tile++) {
     // ---- 1. load the block (all four loads issued before the first use), flag foreground
-    const int blk = base + tid;
-    const int by = blk / nbx, bx = blk - by * nbx;
+    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+    const int bx = tile_x * 32 + mx, by = tile_y * 16 + my;
+    const bool inside = bx < nbx && by < nby;
     const int u0 = bx * 4, v0 = by * 4;
     float z[kD2mPix];
     int cnt = 0;
@@ -50,8 +57,7 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
     if (row4) {
       // unconditional, clamped: the four requests go out back to back (one round trip); what
       // lies outside the image is masked below
-      const int bc = min(blk, nblocks - 1);
-      const int byc = bc / nbx, bxc = bc - byc * nbx;
+      const int byc = min(by, nby - 1), bxc = min(bx, nbx - 1);
       const float4 *p0 = reinterpret_cast<const float4 *>(dm + (size_t)min(byc * 4 + 0, H - 1) * W) + bxc;
       const float4 *p1 = reinterpret_cast<const float4 *>(dm + (size_t)min(byc * 4 + 1, H - 1) * W) + bxc;
       const float4 *p2 = reinterpret_cast<const float4 *>(dm + (size_t)min(byc * 4 + 2, H - 1) * W) + bxc;
@@ -66,7 +72,7 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
       for (int g = 0; g < 4; g++) {
         const int v = v0 + g;
         float4 t = make_float4(100.f, 100.f, 100.f, 100.f);
-        if (blk < nblocks && v < H) {
+        if (inside && v < H) {
           const float *rowp = dm + (size_t)v * W + u0;
           if (u0 + 0 < W) t.x = rowp[0];
           if (u0 + 1 < W) t.y = rowp[1];
@@ -78,7 +84,7 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
     }
 #pragma unroll
     for (int k = 0; k < kD2mPix; k++) {
-      const bool in = blk < nblocks && (v0 + (k >> 2)) < H && (u0 + (k & 3)) < W;
+      const bool in = inside && (v0 + (k >> 2)) < H && (u0 + (k & 3)) < W;
       const bool fg = in && !(z[k] > 99.0f);  // mesh/render.py:138 background = d > 99
       fgmask |= (unsigned)fg << k;
       cnt += fg;
@@ -96,7 +102,7 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
       const int row = lane >> 4;
       incl += (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
     }
-    if (base > 0) __syncthreads();  // previous chunk's queue fully consumed
+    if (tile > 0) __syncthreads();  // previous chunk's queue fully consumed
     if (lane == 63) s_wave_cnt[wave] = incl;
     __syncthreads();
     int offset = incl - cnt, total_all = 0;
@@ -154,7 +160,8 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
         const float dmin = __builtin_amdgcn_sqrtf((nx * nx + ny * ny) + nz * nz);
         const float dmax = __builtin_amdgcn_sqrtf((fx * fx + fy * fy) + fz * fz);
         const float lb = fmaxf(fmaxf(dmin - cj.w, cj.w - dmax), 0.f);
-        const bool odd = __ballot((e.a != e.a) || (e.b != e.b) || (e.c != e.c) || (lane < J && lb != lb)) != 0ull;
+        const bool odd = __ballot((e.a != e.a) || (e.b != e.b) || (e.c != e.c) ||
+                                  (lane < J && (lb != lb || cj.x != cj.x || cj.y != cj.y || cj.z != cj.z || cj.w != cj.w))) != 0ull;
         float best = 0.f;
         int bj = 0;
         auto surface_distance = [&](int j) {   // lanes = points, sphere j's record through SGPRs
@@ -195,7 +202,7 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
             if (a < best || (a == best && j < bj)) { best = a; bj = j; }
           }
         }
-        if (act) loss += fminf(fmaxf(best, 0.f), 50.f);
+        if (act) loss += (best != best) ? best : fminf(fmaxf(best, 0.f), 50.f);   // torch.clamp keeps NaN
         if (WANT_GRAD) {
           float gx = 0.f, gy = 0.f, gz = 0.f;
           int owner = -1;
@@ -218,13 +225,10 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
             const int j = __builtin_amdgcn_readlane(owner, __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo)));
             const bool mine = owner == j;
             todo &= ~__ballot(mine);
-            const float sx = wave_sum_lane63(mine ? gx : 0.f), sy = wave_sum_lane63(mine ? gy : 0.f);
-            const float sz = wave_sum_lane63(mine ? gz : 0.f);
-            if (lane == 63) {
-              float4 t = s_part[wave * SHR_MAX_SPHERES + j];
-              t.x += sx; t.y += sy; t.z += sz;
-              s_part[wave * SHR_MAX_SPHERES + j] = t;
-            }
+            // (three sums in one transposed reduction; ds_add_f32 into the wave's own slot)
+            const float t = wave_sum4_transposed(mine ? gx : 0.f, mine ? gy : 0.f, mine ? gz : 0.f, 0.f, lane);
+            if (lane >= 60 && lane < 63)
+              atomicAdd(reinterpret_cast<float *>(s_part + wave * SHR_MAX_SPHERES + j) + (lane & 3), t);
           }
         }
       }
@@ -255,6 +259,6 @@ exp_d2m(const float *__restrict__ depth, const float *__restrict__ centres,
 }
 extern "C" int exp_d2m_launch(const float *depth, const float *centres, const float *radii, int N, int J, int H, int W,
                               float *loss_sum, float *grad, int mode, void *stream) {
-  hipLaunchKernelGGL(shr::exp_d2m<true>, dim3(N), dim3(shr::kD2mThreads), 0, (hipStream_t)stream, depth, centres, radii, J, H, W, loss_sum, grad, mode);
+  hipLaunchKernelGGL(shr::exp_d2m<true>, dim3(N), dim3(shr::kD2mThreads), 0, (hipStream_t)stream, depth, (const int *)nullptr, centres, radii, J, H, W, loss_sum, grad, mode);
   return (int)hipGetLastError();
 }

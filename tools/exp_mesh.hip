@@ -18,7 +18,9 @@ __device__ __forceinline__ int m_cvt_rz_sat(float d) {
 // src = scale*(d+0.5)-0.5 clamped at 0; i0 = (int)src; i1 = i0 + (i0 < in-1); l1 = src - i0.
 struct Lin { int i0, i1; float l0, l1; };
 __device__ __forceinline__ Lin lin_index(int d, float scale, int in_size) {
-  float src = scale * ((float)d + 0.5f) - 0.5f;
+  // (one rounding: ATen's GPU kernel is compiled with contraction, scale * (d + 0.5) - 0.5 is an FMA there;
+  // the two forms differ by an ulp of the source index at non-dyadic ratios, 3e-5 of a pixel at 256)
+  float src = __builtin_fmaf(scale, (float)d + 0.5f, -0.5f);
   if (src < 0.f) src = 0.f;
   Lin r;
   r.i0 = min((int)src, in_size - 1);
@@ -66,9 +68,15 @@ __device__ __forceinline__ FaceSetup face_setup_sorted(const float4 *__restrict_
   s.xi_max = m_cvt_rz_sat(fminf(s.p[2][0], (float)src - 1.f));
   if (s.xi_min > s.xi_max) return s;
   const float ylo = fminf(fminf(s.p[0][1], s.p[1][1]), s.p[2][1]), yhi = fmaxf(fmaxf(s.p[0][1], s.p[1][1]), s.p[2][1]);
-  const bool wild = !(fabsf(ylo) < 1e9f) || !(fabsf(yhi) < 1e9f);
-  s.r_lo = wild ? 0 : max(0, (int)floorf(ylo) - 1);
-  s.r_hi = wild ? src - 1 : min(src - 1, max(0, (int)ceilf(yhi) + 1));
+  // (a face whose largest x lies in (-1, 0) still reaches column 0 -- the reference truncates x2 towards zero,
+  // .cu:69 -- and the span there is an EXTRApolation of the edges: any row)
+  const bool wild = !(fabsf(ylo) < 1e9f) || !(fabsf(yhi) < 1e9f) || s.p[2][0] < 0.f;
+  // A column's span ends are edge interpolations slope * (x - xa) + ya at an x inside the edge:
+  // convex combinations of the vertices' y up to 4 roundings (<= 2.4e-7 * |y|); rows
+  // [ceil(min), trunc(max)] (.cu:89-90; a span end in (-1, 0) truncates to row 0).
+  const float yeps = 1e-5f * (fabsf(ylo) + fabsf(yhi)) + 1e-4f;
+  s.r_lo = wild ? 0 : max(0, (int)ceilf(ylo - yeps));
+  s.r_hi = wild ? src - 1 : min(src - 1, max(0, (int)floorf(yhi + yeps)));
   s.live = true;
   return s;
 }

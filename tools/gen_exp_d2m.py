@@ -15,7 +15,7 @@ k = k.replace('            s_q[slot] = e;', '            if (!(mode & 8)) s_q[sl
 exp = '#include "../spherehand_amd/csrc/common.h"\nnamespace shr {\n' + src[src.index('constexpr int kD2mThreads'):a] + k + '''}
 extern "C" int exp_d2m_launch(const float *depth, const float *centres, const float *radii, int N, int J, int H, int W,
                               float *loss_sum, float *grad, int mode, void *stream) {
-  hipLaunchKernelGGL(shr::exp_d2m<true>, dim3(N), dim3(shr::kD2mThreads), 0, (hipStream_t)stream, depth, centres, radii, J, H, W, loss_sum, grad, mode);
+  hipLaunchKernelGGL(shr::exp_d2m<true>, dim3(N), dim3(shr::kD2mThreads), 0, (hipStream_t)stream, depth, (const int *)nullptr, centres, radii, J, H, W, loss_sum, grad, mode);
   return (int)hipGetLastError();
 }
 '''
