@@ -7,7 +7,7 @@ import bench
 from spherehand_amd import ops
 dev = torch.device("cuda:0")
 spheres, grad = bench.make_inputs(0, dev)
-def t_us(fn, reps=400):
+def t_us(fn, reps=600):
     """device time per call: a captured graph of `reps` launches between two events"""
     for _ in range(20): fn()
     torch.cuda.synchronize()
@@ -26,10 +26,9 @@ st = torch.cuda.current_stream().cuda_stream
 gs = torch.empty(256, 41, 4, device=dev)
 def pack(a): return a[0] | a[1] << 8 | a[2] << 16 | a[3] << 24
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-cands = [(64, 64, 64, 64), (72, 66, 62, 56), (76, 68, 60, 52), (80, 70, 58, 48), (84, 70, 58, 44), (88, 72, 56, 40),
-         (80, 72, 64, 40), (84, 74, 64, 34), (88, 76, 64, 28), (90, 78, 66, 22), (76, 70, 66, 44), (72, 70, 68, 46),
-         (92, 80, 60, 24), (86, 80, 70, 20), (96, 80, 64, 16), (88, 78, 60, 30), (84, 76, 60, 36), (88, 72, 60, 36),
-         (80, 72, 62, 42), (84, 72, 64, 36), (80, 76, 64, 36), (76, 72, 64, 44), (84, 78, 56, 38), (90, 74, 58, 34)]
+cands = [(88, 72, 56, 40), (84, 70, 58, 44), (90, 74, 58, 34), (86, 72, 58, 40), (92, 72, 54, 38), (88, 76, 54, 38),
+         (84, 74, 58, 40), (80, 72, 60, 44), (88, 68, 58, 42), (92, 76, 56, 32), (86, 70, 56, 44), (82, 70, 60, 44),
+         (88, 72, 60, 36), (84, 72, 56, 44), (90, 70, 56, 40), (86, 74, 56, 40)]
 for c in cands:
     if which == "fwd":
         ops.set_tuning(ops.TUNE_FWD_SHARES, pack(c))
