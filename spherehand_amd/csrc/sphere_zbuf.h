@@ -155,7 +155,7 @@ constexpr int kChunkCost = 1 << kChunkShift;
 constexpr int kSphereCostFwd = 20;
 constexpr int kSphereCostBwd = 36;   // ... plus four wave reductions when a run on a sphere ends
 
-// Wave 0: build the list in LDS.  s_items[j] = (u0 | v0<<16, v1 | ph<<16, pw | ncx<<8 |
+// Wave 0: build the list in LDS.  s_items[j] = (u0 | v0<<16, v1 | ceil(2^15/pw)<<16, pw | ncx<<8 |
 // u1<<16, weight prefix before sphere j); s_ends[j] = prefix after it; a sphere weighs
 // kSphereCost + nchunks * kChunkCost (nothing when it touches no pixel).  Returns the total
 // weight (valid in every lane of wave 0).  Field widths: the launcher keeps W <= 8192 and
@@ -177,7 +177,10 @@ __device__ __forceinline__ int build_work_list(const float4 s, bool valid, const
   const int r0s = rl(incl, 15), r1s = rl(incl, 31), r2s = rl(incl, 47);
   const int row = lane >> 4;
   incl += (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
-  s_items[lane] = make_int4(it.u0 | (it.v0 << 16), (it.v1 & 0xffff) | (it.ph << 16),
+  // ceil(2^15 / pw) = floor((2^15 + pw - 1 + 1/2) / pw): the quotient is at least 1/128 from an integer and
+  // v_rcp_f32's ulp leaves 0.004 of error at this magnitude; the walk derives ph = 64 / pw from it as well
+  const int inv15 = (int)((32768.0f + (float)it.pw - 0.5f) * __builtin_amdgcn_rcpf((float)it.pw));
+  s_items[lane] = make_int4(it.u0 | (it.v0 << 16), (int)((unsigned)(it.v1 & 0xffff) | ((unsigned)inv15 << 16)),
                             it.pw | (it.ncx << 8) | ((it.u1 & 0xffff) << 16), incl - cost);
   s_ends[lane] = incl;
   *too_big = __ballot(valid && nchunks > 0 && (it.ncx > 255 || it.u1 > 65535 || it.v1 > 65535 ||
@@ -221,7 +224,6 @@ template <bool POW2, int kSphereCost, bool ROWFREE, typename Body, typename EndS
 __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int hi, int lane, const Axis &ax,
                                            const Axis &ay, int r0, int r1, int LW, Body &&body,
                                            EndSphere &&end_sphere) {
-  const float lane_mid = (float)lane + 0.5f;
   int j = __popcll(__ballot(lane < J && w.end <= lo));   // prefixes are non-decreasing
   while (j < J) {
     const int wstart = rl(w.item.w, j);
@@ -236,12 +238,11 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
       const float4 s = make_float4(readlane_f(w.sph.x, j), readlane_f(w.sph.y, j), readlane_f(w.sph.z, j),
                                    readlane_f(w.sph.w, j));
       const int u0 = geom & 0xffff, v0 = (int)((unsigned)geom >> 16);
-      const int v1 = rows & 0xffff, ph = rows >> 16;
+      const int v1 = rows & 0xffff, inv15 = (int)((unsigned)rows >> 16), ph = (inv15 << 6) >> 15;   // ph = 64 / pw
       const int pw = cols & 0xff, ncx = (cols >> 8) & 0xff, u1 = (int)((unsigned)cols >> 16);
       const float rr = s.w * s.w;
-      // lane -> (lx, ly) inside a chunk: ly = lane / pw through fp32 ((lane + 1/2) / pw is
-      // at least 1/128 away from an integer, v_rcp_f32 is good to 1 ulp)
-      const int ly = (int)(lane_mid * __builtin_amdgcn_rcpf((float)pw));
+      // lane -> (lx, ly) inside a chunk: ly = lane / pw = (lane * ceil(2^15 / pw)) >> 15, exact for lane < 64
+      const int ly = __mul24(lane, inv15) >> 15;
       const int lx = lane - __mul24(ly, pw);   // (24-bit multiplies: v_mul_lo_u32 is quarter rate)
       const bool packed = ly < ph;
       if (ncx == 1) {
