@@ -69,9 +69,18 @@ def cpu_baseline(spheres_host, grad_host, budget_s=10.0):
         el = time.perf_counter() - t0
         if el > budget_s or passes >= 400:
             break
+    # one thread, for reference: a few crops of the same batch, ~2 s
+    oracle.set_num_threads(1)
+    n1 = 16
+    t1 = time.perf_counter()
+    oracle.sphere_raster_fwd(spheres_host[:n1], S, S, want_argmin=False)
+    oracle.sphere_raster_bwd(spheres_host[:n1], grad_host[:n1])
+    one = n1 / (time.perf_counter() - t1)
+    oracle.set_num_threads(cores)
     return {"value": round(passes * BATCH / el, 1), "unit": "crops/s", "cores": cores, "kind": "port",
             "sample": "%d fwd+bwd passes over the same 256-crop 128x128 batch (%.1f s, OpenMP over crops)"
-                      % (passes, el)}
+                      % (passes, el),
+            "one_thread_crops_per_s": round(one, 1)}
 
 
 def pmc_traffic(kernel):
