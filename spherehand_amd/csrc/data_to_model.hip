@@ -211,17 +211,18 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
           // for rounding) exceeds `reach` can reach, or tie, any point's minimum: the others
           // are visited in a plain loop.
           float rem = lane < J ? lb * 0.99999f - 1e-3f : inf;
-          float reach = inf;
           best = inf;
           for (int it = 0; it < kD2mSeeds; it++) {
             const float m = wave_minmax_all<true>(rem);
-            if (!(m <= reach) || m == inf) break;
+            if (m == inf) break;
             const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(__ballot(rem == m)));
             if (lane == j) rem = inf;
             const float a = surface_distance(j);
             if (a < best || (a == best && j < bj)) { best = a; bj = j; }   // ties keep the first index
-            reach = wave_minmax_all<false>(act ? best : -inf) * 1.00001f + 1e-3f;
           }
+          // (one wave maximum after the seeds, not one per seed: a seed that could not have improved
+          // anything costs one evaluation, a wave reduction costs as much)
+          const float reach = wave_minmax_all<false>(act ? best : -inf) * 1.00001f + 1e-3f;
           unsigned long long cand = __ballot(rem <= reach && rem != inf);
           while (cand) {
             const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(cand));
