@@ -112,6 +112,24 @@ __device__ __forceinline__ float wave_minmax_all(float v) {
   return readlane_f(v, 63);
 }
 
+// Four wave minima at once, same scheme as wave_sum4_transposed: lanes 12..15 of every row
+// return the minima of components 0..3 (fminf: a NaN operand is ignored).
+__device__ __forceinline__ float wave_min4_transposed(float a0, float a1, float a2, float a3, int lane) {
+  const bool odd = lane & 1, hi = lane & 2;
+  const float k0 = odd ? a1 : a0, s0 = odd ? a0 : a1;
+  const float k1 = odd ? a3 : a2, s1 = odd ? a2 : a3;
+  const float b0 = fminf(k0, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(k0), __float_as_int(s0), 0xB1, 0xF, 0xF, false)));
+  const float b1 = fminf(k1, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(k1), __float_as_int(s1), 0xB1, 0xF, 0xF, false)));
+  const float k2 = hi ? b1 : b0, s2 = hi ? b0 : b1;
+  float c = fminf(k2, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(k2), __float_as_int(s2), 0x4E, 0xF, 0xF, false)));
+  c = dpp_minmax<0x114, 0xF, true>(c);   // row_shr:4 (lanes without a source keep their own value)
+  c = dpp_minmax<0x118, 0xF, true>(c);   // row_shr:8  -> lanes 12..15 of a row: the row's minima
+  const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(c), __float_as_uint(c), false, false);
+  c = fminf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+  const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(c), false, false);
+  return fminf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+}
+
 __device__ __forceinline__ bool is_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
 }  // namespace shr

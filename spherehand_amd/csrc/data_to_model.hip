@@ -178,9 +178,10 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
         const bool act = i < total;
         QEntry e = s_q[act ? i : i0];
         const float inf = __builtin_inff();
-        const float xlo = wave_minmax_all<true>(e.a), xhi = wave_minmax_all<false>(e.a);
-        const float ylo = wave_minmax_all<true>(e.b), yhi = wave_minmax_all<false>(e.b);
-        const float zlo = wave_minmax_all<true>(e.c), zhi = wave_minmax_all<false>(e.c);
+        // the points' bounding box: six wave minima (max = -min(-v)) in two transposed reductions
+        const float mxy = wave_min4_transposed(e.a, -e.a, e.b, -e.b, lane), mz = wave_min4_transposed(e.c, -e.c, e.c, -e.c, lane);
+        const float xlo = readlane_f(mxy, 12), xhi = -readlane_f(mxy, 13), ylo = readlane_f(mxy, 14), yhi = -readlane_f(mxy, 15);
+        const float zlo = readlane_f(mz, 12), zhi = -readlane_f(mz, 13);
         // lanes = spheres: nearest / farthest distance from the centre to the box
         const float nx = fmaxf(fmaxf(xlo - cj.x, cj.x - xhi), 0.f), fx = fmaxf(fabsf(xlo - cj.x), fabsf(xhi - cj.x));
         const float ny = fmaxf(fmaxf(ylo - cj.y, cj.y - yhi), 0.f), fy = fmaxf(fabsf(ylo - cj.y), fabsf(yhi - cj.y));

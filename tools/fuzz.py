@@ -78,13 +78,27 @@ def d2m_case():
     S = int(rs.choice([16, 64, 100, 128])); N = int(rs.randint(1, 4)); J = int(rs.choice([1, 5, 41]))
     depth = np.where(rs.rand(N, S, S) < rs.uniform(0.02, 0.6), rs.uniform(-60, 60, (N, S, S)), 100.0).astype(np.float32)
     cen = rs.uniform(-120, 120, (N, J, 3)).astype(np.float32); rad = rs.uniform(1, 30, (J,)).astype(np.float32)
+    # a point whose distance sits on the clamp at 50 (torch.clamp's kink): fp32 rounding decides whether it has a
+    # gradient, in the reference as here -- not a comparable case
+    xs = (np.arange(S) - S / 2) * 300.0 / S
+    X, Y = np.meshgrid(xs, xs)
+    for n in range(N):
+        fg = depth[n] <= 99
+        P = np.stack([X[fg], Y[fg], depth[n][fg]], -1).astype(np.float64)
+        if len(P):
+            m = np.abs(np.linalg.norm(P[:, None, :] - cen[n][None].astype(np.float64), axis=-1) - rad[None].astype(np.float64)).min(1)
+            if (np.abs(m - 50.0) < 2e-4).any() or (m < 2e-4).any():
+                return
     loss, grad = ops.data_to_model(dev(depth), dev(cen), dev(rad), want_grad=True)
     ol = oracle.data_to_model_fwd(depth, cen, rad); og = oracle.data_to_model_bwd(depth, cen, rad) * depth.size   # oracle: gradient of the mean
     ok = bool(np.abs(loss.cpu().numpy() - ol).max() <= 1e-5 * np.abs(ol).max() + 1e-4)
     ok = ok and bool(np.abs(grad.cpu().numpy() - og).max() <= 1e-5 * np.abs(og).max() + 1e-4)
     if not ok:
         fails += 1
-        print("D2M MISMATCH", dict(N=N, J=J, S=S))
+        print("D2M MISMATCH", dict(N=N, J=J, S=S), "loss diff", np.abs(loss.cpu().numpy() - ol).max(), "of", np.abs(ol).max(),
+              "grad diff", np.abs(grad.cpu().numpy() - og).max(), "of", np.abs(og).max())
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_d2m_fail.npz"), depth=depth, cen=cen, rad=rad, loss=loss.cpu().numpy(), grad=grad.cpu().numpy(), ol=ol, og=og)
 
 def mesh_case():
     """fused raster + clamp + bilinear resize against the explicit chain (which is checked against the oracle above)"""
