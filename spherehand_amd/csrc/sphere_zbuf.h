@@ -914,6 +914,13 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
   const int nunits = (nchunk + 63) >> 6;
   const float4 *tgt4 = reinterpret_cast<const float4 *>(tgt);
   float4 *out4 = reinterpret_cast<float4 *>(out);
+  // The observed image is needed after the scan conversion only (units u = wave + 16 k go to this
+  // wave whatever the spheres are): requested now, it arrives under the list building and the scan
+  // conversion instead of costing the convert pass one HBM round trip per unit.
+  constexpr int kTgtAhead = 4;   // a 128x128 crop / a 64-row region of a 256-wide one: 64 units, four per wave
+  float4 tpre[kTgtAhead];
+#pragma unroll
+  for (int k = 0; k < kTgtAhead; k++) tpre[k] = tgt4[min(((wave_s + (k << 4)) << 6) + lane, nchunk - 1)];
   int ua = 0, ub = nunits;
   if (bg_wave) {   // rows no sphere touches: depth = background, stored while wave 0 builds the list
     int cv0, cv1;
@@ -978,14 +985,13 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
     __syncthreads();
 
     // ---- convert: error, its square, gradient image in place ---------------------------------
-    for (int u = wave_s; u < nunits; u += kZWaves) {
+    auto convert_unit = [&](int u, const float4 t) {
       const int c = (u << 6) + lane;
-      if (c >= nchunk) continue;
-      const float4 t = tgt4[c];
+      if (c >= nchunk) return;
       if (u < ua || u >= ub) {   // background rows (already stored)
         const float e0 = kBackground - t.x, e1 = kBackground - t.y, e2 = kBackground - t.z, e3 = kBackground - t.w;
         sse += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
-        continue;
+        return;
       }
       int v, x;
       if (POW2 || w4_shift >= 0) { v = c >> w4_shift; x = (c & (w4 - 1)) << 2; }
@@ -1003,6 +1009,13 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
       k23.y = ((Key)__float_as_uint(2.f * e3) << 32) | (k23.y & 0xffu);
       cell[0] = k01;
       cell[1] = k23;
+    };
+#pragma unroll
+    for (int k = 0; k < kTgtAhead; k++)
+      if (wave_s + (k << 4) < nunits) convert_unit(wave_s + (k << 4), tpre[k]);
+    for (int u = wave_s + (kTgtAhead << 4); u < nunits; u += kZWaves) {
+      const int c = (u << 6) + lane;
+      convert_unit(u, tgt4[min(c, nchunk - 1)]);
     }
     __syncthreads();
 
