@@ -207,7 +207,35 @@ def mv_case():
         fails += 1
         print("MV MISMATCH", dict(B=B, S=S, is_mv=is_mv), out[True][0], out[False][0], np.abs(out[True][2] - out[False][2]).max(), np.abs(out[False][2]).max())
 
-for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case), ("mv", mv_case)):
+def sa_case():
+    """soft-argmax (RecoverXYZCoordinateFromHeatmap) forward / backward against the torch ops in fp64"""
+    global fails
+    from spherehand_amd.util_modules import RecoverXYZCoordinateFromHeatmap
+    S = int(rs.choice([8, 16, 32])); J = int(rs.choice([2, 14, 41])); N = int(rs.randint(1, 12))
+    hm = torch.from_numpy((rs.standard_normal((N, 2 * J, S, S)) * rs.choice([0.1, 0.6, 3.0])).astype(np.float32)).cuda()
+    if rs.rand() < 0.5: hm = hm.to(memory_format=torch.channels_last)
+    hm = hm.requires_grad_(True)
+    if not ops.soft_argmax_supported(hm, J):
+        return
+    rec = RecoverXYZCoordinateFromHeatmap(S, S, 0.01).cuda()
+    up = dev(rs.standard_normal((N, J, 3)).astype(np.float32))
+    xyz = rec.from_output(hm); (xyz * up).sum().backward()
+    hd = hm.detach().double().requires_grad_(True)
+    ref = RecoverXYZCoordinateFromHeatmap(S, S, 0.01).cuda().double().forward(hd[:, :J], hd[:, J:])
+    (ref * up.double()).sum().backward()
+    # yardstick: the same torch formulation in fp32 (its own distance from fp64 on these inputs)
+    h32 = hm.detach().clone().requires_grad_(True)
+    t32 = rec.forward(h32[:, :J], h32[:, J:]); (t32 * up).sum().backward()
+    ex_t = (t32.detach().double() - ref.detach()).abs().max().item(); eg_t = (h32.grad.double() - hd.grad).abs().max().item()
+    ok = bool((xyz.detach().double() - ref.detach()).abs().max().item() <= 4e-5 * max(1.0, ref.abs().max().item()) + 4 * ex_t)
+    # (rare sharply peaked maps of one or two joints: up to 1e-4 of the largest gradient entry, torch fp32 5e-6..5e-5)
+    ok = ok and bool((hm.grad.double() - hd.grad).abs().max().item() <= 1.5e-4 * max(1.0, hd.grad.abs().max().item()) + 4 * eg_t)
+    if not ok:
+        fails += 1
+        print("SOFT-ARGMAX MISMATCH", dict(N=N, J=J, S=S), (xyz.detach().double() - ref.detach()).abs().max().item(),
+              (hm.grad.double() - hd.grad).abs().max().item(), hd.grad.abs().max().item(), "torch fp32:", ex_t, eg_t)
+
+for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case), ("mv", mv_case), ("sa", sa_case)):
     if len(sys.argv) > 3 and name not in sys.argv[3].split(","): continue
     t0 = time.time(); n = 0
     while time.time() - t0 < budget:
