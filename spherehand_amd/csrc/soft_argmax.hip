@@ -13,27 +13,38 @@
 
 namespace shr {
 
-struct SoftArgmaxStats { float m, z, u, v, r, d; };
+// u, v are kept RELATIVE to the pixel (xm, ym) of the largest logit: u = xm + cu.  A sharply peaked map has
+// cu ~ 0, and the backward's x - u = (x - xm) - cu keeps its relative precision there (computed against the
+// absolute u, an ulp of u -- 1e-6 px -- times 20 p du was up to 4e-4 of the largest gradient entry).
+struct SoftArgmaxStats { float m, z, cu, cv, r, d; int xm, ym; };
 
 // wave-wide stats of key-point j from the LDS slab (uvm = its uv map, dm = its depth map, npx pixels)
 __device__ __forceinline__ SoftArgmaxStats soft_argmax_stats(const float *uvm, const float *dm, int npx, int w, int lane) {
-  float m = -__builtin_inff();
-  for (int p = lane; p < npx; p += 64) m = fmaxf(m, uvm[p]);
-  m = wave_minmax_all<false>(m);
+  float lm = -__builtin_inff();
+  int lp = 0;
+  for (int p = lane; p < npx; p += 64) {
+    const float a = uvm[p];
+    if (a > lm) { lm = a; lp = p; }
+  }
+  const float m = wave_minmax_all<false>(lm);
+  // the first lane that holds the maximum names the anchor pixel (any pixel would do: it only centres the sums)
+  const unsigned long long holders = __ballot(lm == m);
+  const int pm = holders ? __builtin_amdgcn_readlane(lp, __builtin_amdgcn_readfirstlane(__builtin_ctzll(holders))) : 0;
+  const int ym = pm / w, xm = pm - ym * w;
   float z = 0.f, su = 0.f, sv = 0.f, r = 0.f, sd = 0.f;
   for (int p = lane; p < npx; p += 64) {
     const float a = uvm[p];
     const float e = __expf(20.0f * (a - m));
     const int y = p / w, x = p - y * w;
-    z += e; su += e * (float)x; sv += e * (float)y;
+    z += e; su += e * (float)(x - xm); sv += e * (float)(y - ym);
     const float rl = fmaxf(a, 0.f);
     r += rl; sd += dm[p] * rl;
   }
   SoftArgmaxStats s;
-  s.m = m;
+  s.m = m; s.xm = xm; s.ym = ym;
   s.z = readlane_f(wave_sum_lane63(z), 63);
-  s.u = readlane_f(wave_sum_lane63(su), 63) / s.z;
-  s.v = readlane_f(wave_sum_lane63(sv), 63) / s.z;
+  s.cu = readlane_f(wave_sum_lane63(su), 63) / s.z;
+  s.cv = readlane_f(wave_sum_lane63(sv), 63) / s.z;
   s.r = readlane_f(wave_sum_lane63(r), 63) + 1e-5f;
   s.d = readlane_f(wave_sum_lane63(sd), 63) / s.r;
   return s;
@@ -62,7 +73,7 @@ soft_argmax_kernel(const float *__restrict__ hm, long long sn, long long sc, lon
     if (!BACKWARD) {
       if (lane == 0) {
         float *o = xyz + ((size_t)n * J + j) * 3;
-        o[0] = (s.u - cx) * inv_fx; o[1] = (s.v - cy) * inv_fy; o[2] = s.d * d_scale;
+        o[0] = (((float)s.xm - cx) + s.cu) * inv_fx; o[1] = (((float)s.ym - cy) + s.cv) * inv_fy; o[2] = s.d * d_scale;
       }
     } else {
       const float *g = grad_xyz + ((size_t)n * J + j) * 3;
@@ -72,7 +83,7 @@ soft_argmax_kernel(const float *__restrict__ hm, long long sn, long long sc, lon
         const float a = uvm[p], dval = dm[p];
         const float pr = __expf(20.0f * (a - s.m)) * inv_z;
         const int y = p / w, x = p - y * w;
-        float ga = 20.0f * pr * (du * ((float)x - s.u) + dv * ((float)y - s.v));
+        float ga = 20.0f * pr * (du * ((float)(x - s.xm) - s.cu) + dv * ((float)(y - s.ym) - s.cv));
         if (a > 0.f) ga += dd * (dval - s.d) * inv_r;
         uvm[p] = ga;
         dm[p] = dd * fmaxf(a, 0.f) * inv_r;

@@ -211,7 +211,7 @@ def sa_case():
     """soft-argmax (RecoverXYZCoordinateFromHeatmap) forward / backward against the torch ops in fp64"""
     global fails
     from spherehand_amd.util_modules import RecoverXYZCoordinateFromHeatmap
-    S = int(rs.choice([8, 16, 32])); J = int(rs.choice([2, 14, 41])); N = int(rs.randint(1, 12))
+    S = int(rs.choice([8, 16, 32])); J = int(rs.choice([1, 2, 14, 41])); N = int(rs.randint(1, 12))
     hm = torch.from_numpy((rs.standard_normal((N, 2 * J, S, S)) * rs.choice([0.1, 0.6, 3.0])).astype(np.float32)).cuda()
     if rs.rand() < 0.5: hm = hm.to(memory_format=torch.channels_last)
     hm = hm.requires_grad_(True)
@@ -228,8 +228,7 @@ def sa_case():
     t32 = rec.forward(h32[:, :J], h32[:, J:]); (t32 * up).sum().backward()
     ex_t = (t32.detach().double() - ref.detach()).abs().max().item(); eg_t = (h32.grad.double() - hd.grad).abs().max().item()
     ok = bool((xyz.detach().double() - ref.detach()).abs().max().item() <= 4e-5 * max(1.0, ref.abs().max().item()) + 4 * ex_t)
-    # (rare sharply peaked maps of one or two joints: up to 1e-4 of the largest gradient entry, torch fp32 5e-6..5e-5)
-    ok = ok and bool((hm.grad.double() - hd.grad).abs().max().item() <= 1.5e-4 * max(1.0, hd.grad.abs().max().item()) + 4 * eg_t)
+    ok = ok and bool((hm.grad.double() - hd.grad).abs().max().item() <= 4e-5 * max(1.0, hd.grad.abs().max().item()) + 4 * eg_t)
     if not ok:
         fails += 1
         print("SOFT-ARGMAX MISMATCH", dict(N=N, J=J, S=S), (xyz.detach().double() - ref.detach()).abs().max().item(),
