@@ -234,7 +234,30 @@ def sa_case():
         print("SOFT-ARGMAX MISMATCH", dict(N=N, J=J, S=S), (xyz.detach().double() - ref.detach()).abs().max().item(),
               (hm.grad.double() - hd.grad).abs().max().item(), hd.grad.abs().max().item(), "torch fp32:", ex_t, eg_t)
 
-for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case), ("mv", mv_case), ("sa", sa_case)):
+_pl = None
+def pl_case():
+    """CollisionLoss + BoneLengthLoss in one launch against the torch modules (values and gradients)"""
+    global fails, _pl
+    from spherehand_amd.render import BoneLengthLoss, CollisionLoss
+    if _pl is None:
+        _pl = (CollisionLoss().cuda(), BoneLengthLoss().cuda())
+    cc, bc = _pl
+    B = int(rs.randint(1, 9)); V = int(rs.choice([1, 3]))
+    xyz = (rs.standard_normal((B, V, 41, 3)) * rs.choice([2.0, 15.0, 60.0])).astype(np.float32)
+    wa, wb = float(rs.uniform(0.1, 2)), float(rs.uniform(0.1, 2))
+    a = dev(xyz).requires_grad_(True)
+    ca, ba = cc(a), bc(a); (ca * wa + ba * wb).backward()
+    b = dev(xyz).requires_grad_(True)
+    col, bone = ops.PairLosses.apply(b.reshape(B, -1, 3), 41, 11, 6, float(cc.min_sq_dist), bc.joint_1.to(torch.int32),
+                                     bc.joint_2.to(torch.int32), bc.min_length.reshape(-1).clone(), bc.max_length.reshape(-1).clone())
+    (col * wa + bone * wb).backward()
+    ok = abs(col.item() - ca.item()) <= 2e-5 * max(1.0, abs(ca.item())) and abs(bone.item() - ba.item()) <= 2e-5 * max(1.0, abs(ba.item()))
+    ok = ok and bool((b.grad - a.grad).abs().max().item() <= 2e-5 * max(1.0, a.grad.abs().max().item()))
+    if not ok:
+        fails += 1
+        print("PAIR-LOSS MISMATCH", dict(B=B, V=V), col.item(), ca.item(), bone.item(), ba.item(), (b.grad - a.grad).abs().max().item(), a.grad.abs().max().item())
+
+for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case), ("mv", mv_case), ("sa", sa_case), ("pl", pl_case)):
     if len(sys.argv) > 3 and name not in sys.argv[3].split(","): continue
     t0 = time.time(); n = 0
     while time.time() - t0 < budget:
