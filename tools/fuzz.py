@@ -234,6 +234,26 @@ def sa_case():
         print("SOFT-ARGMAX MISMATCH", dict(N=N, J=J, S=S), (xyz.detach().double() - ref.detach()).abs().max().item(),
               (hm.grad.double() - hd.grad).abs().max().item(), hd.grad.abs().max().item(), "torch fp32:", ex_t, eg_t)
 
+_skin = None
+def lbs_case():
+    """skinning + camera against the oracle, bit for bit (random bone matrices, with / without camera and rand_f)"""
+    global fails, _skin
+    if _skin is None:
+        from spherehand_amd import hand_model
+        _skin = hand_model.sparse_skin(hand_model.load_mesh())
+    start, bone, wv = _skin
+    B = int(rs.randint(1, 6))
+    T = (rs.standard_normal((B, 17, 4, 4)) * rs.choice([0.5, 1.0, 30.0])).astype(np.float32)
+    mode = int(rs.randint(0, 3))
+    cam = None if mode == 0 else (float(rs.uniform(0, 640)), float(rs.uniform(0, 640)), float(rs.uniform(0.5, 4)), float(rs.uniform(0.5, 4)))
+    rf = rs.uniform(0.8, 1.2, (B,)).astype(np.float32) if mode == 2 else None
+    rh = bool(rs.rand() < 0.5)
+    out = ops.lbs_project(dev(T), dev(start), dev(bone), dev(wv), rh, cam, None if rf is None else dev(rf)).cpu().numpy()
+    o = oracle.lbs_project(T, start, bone, wv, rh, cam, rf)
+    if not np.array_equal(bits(out), bits(o)):
+        fails += 1
+        print("LBS MISMATCH", dict(B=B, mode=mode, right_hand=rh), np.abs(out - o).max())
+
 _pl = None
 def pl_case():
     """CollisionLoss + BoneLengthLoss in one launch against the torch modules (values and gradients)"""
@@ -257,7 +277,7 @@ def pl_case():
         fails += 1
         print("PAIR-LOSS MISMATCH", dict(B=B, V=V), col.item(), ca.item(), bone.item(), ba.item(), (b.grad - a.grad).abs().max().item(), a.grad.abs().max().item())
 
-for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case), ("mv", mv_case), ("sa", sa_case), ("pl", pl_case)):
+for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case), ("mv", mv_case), ("sa", sa_case), ("pl", pl_case), ("lbs", lbs_case)):
     if len(sys.argv) > 3 and name not in sys.argv[3].split(","): continue
     t0 = time.time(); n = 0
     while time.time() - t0 < budget:
