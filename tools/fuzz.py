@@ -254,6 +254,36 @@ def lbs_case():
         fails += 1
         print("LBS MISMATCH", dict(B=B, mode=mode, right_hand=rh), np.abs(out - o).max())
 
+_hm = {}
+def hm_case():
+    """heat-map painting + back-projection (no-grad kernels) against the torch ops of the same module"""
+    global fails, _fk
+    from spherehand_amd import hand_model
+    from spherehand_amd.render import Hand3DHeatmapRender
+    if _fk is None:
+        fk_case()
+    S = int(rs.choice([8, 16, 32]))
+    if S not in _hm:
+        _hm[S] = Hand3DHeatmapRender(hand_model.load_mesh()["bones"], S).cuda()
+    B = int(rs.randint(1, 20))
+    p = (rs.uniform(-1, 1, (B, 26)) * rs.choice([0.3, 1.5, 3.0])).astype(np.float32); p[:, 3:6] = rs.uniform(-40, 40, (B, 3))
+    T = _fk(dev(p)).detach()
+    rf = dev(rs.uniform(0.85, 1.15, (B,)).astype(np.float32)) if rs.rand() < 0.5 else None
+    uv, ds = float(rs.choice([1.0, 0.5])), float(rs.choice([0.01, 1.0]))
+    with torch.no_grad():
+        a = _hm[S](T, rf, uv, ds)
+    with torch.enable_grad():
+        b = _hm[S](T, rf, uv, ds)
+    # (the depth map is gated by uv_hm > 0.05: pixels whose Gaussian sits on the threshold may go either way)
+    off_gate = (b[0] / uv - 0.05).abs() > 1e-5
+    for k, (x, y, tol) in enumerate(zip(a, b, (4e-6, 1e-6, 4e-4))):
+        if k == 1:
+            x, y = x * off_gate, y * off_gate
+        if x.shape != y.shape or (x - y).abs().max().item() > tol * max(1.0, y.abs().max().item()):
+            fails += 1
+            print("HEATMAP MISMATCH", dict(B=B, S=S, uv=uv, ds=ds, rand_f=rf is not None), (x - y).abs().max().item(), y.abs().max().item())
+            break
+
 _pl = None
 def pl_case():
     """CollisionLoss + BoneLengthLoss in one launch against the torch modules (values and gradients)"""
@@ -277,7 +307,7 @@ def pl_case():
         fails += 1
         print("PAIR-LOSS MISMATCH", dict(B=B, V=V), col.item(), ca.item(), bone.item(), ba.item(), (b.grad - a.grad).abs().max().item(), a.grad.abs().max().item())
 
-for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case), ("mv", mv_case), ("sa", sa_case), ("pl", pl_case), ("lbs", lbs_case)):
+for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case), ("mv", mv_case), ("sa", sa_case), ("pl", pl_case), ("lbs", lbs_case), ("hm", hm_case)):
     if len(sys.argv) > 3 and name not in sys.argv[3].split(","): continue
     t0 = time.time(); n = 0
     while time.time() - t0 < budget:
