@@ -76,3 +76,28 @@ def test_soft_argmax_kernels_match_the_torch_formulation(layout):
     (ref * up.double()).sum().backward()
     assert (got_x.double() - ref.detach()).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
     assert (got_g.double() - hd.grad).abs().max().item() <= 2e-5 * max(1.0, hd.grad.abs().max().item())
+
+
+def test_soft_argmax_sharply_peaked_maps_keep_their_gradient_precision():
+    """Logits x 20 spanning hundreds (a nearly one-hot softmax): x - u must not be formed against the absolute
+    expectation (an ulp of u times 20 p du was 4e-4 of the largest gradient entry); bar = the torch ops' own fp32
+    distance from fp64 on the same inputs, x4, plus 4e-5."""
+    from spherehand_amd import ops
+    from spherehand_amd.util_modules import RecoverXYZCoordinateFromHeatmap
+    g = torch.Generator().manual_seed(11)
+    worst = 0.0
+    for N, J, S in ((6, 2, 32), (5, 1, 32), (8, 2, 16), (3, 41, 16)):
+        hm = (torch.randn(N, 2 * J, S, S, generator=g) * 3.0).cuda().requires_grad_(True)
+        assert ops.soft_argmax_supported(hm, J)
+        rec = RecoverXYZCoordinateFromHeatmap(S, S, 0.01).cuda()
+        up = torch.randn(N, J, 3, generator=g).cuda()
+        (rec.from_output(hm) * up).sum().backward()
+        h32 = hm.detach().clone().requires_grad_(True)
+        (rec.forward(h32[:, :J], h32[:, J:]) * up).sum().backward()
+        hd = hm.detach().double().requires_grad_(True)
+        (RecoverXYZCoordinateFromHeatmap(S, S, 0.01).cuda().double().forward(hd[:, :J], hd[:, J:]) * up.double()).sum().backward()
+        err = (hm.grad.double() - hd.grad).abs().max().item()
+        err_t = (h32.grad.double() - hd.grad).abs().max().item()
+        assert err <= 4e-5 * max(1.0, hd.grad.abs().max().item()) + 4 * err_t, (N, J, S, err, err_t)
+        worst = max(worst, err / max(1.0, hd.grad.abs().max().item()))
+    assert worst < 2e-4
