@@ -175,6 +175,24 @@ def test_tile_kernel_at_small_ratios(S):
     assert (tile < 100).float().mean().item() > 0.02
 
 
+@pytest.mark.parametrize("src,S", [(257, 200), (320, 96), (96, 64)])
+def test_tile_kernel_non_dyadic_source_index(src, S):
+    """Non-dyadic resize ratios: the source index scale * (d + 0.5) - 0.5 is one FMA in ATen's GPU kernel; formed
+    with two roundings it is off by an ulp (3e-5 px at 256) and the bilinear weights with it (tools/fuzz.py, mesh)."""
+    from spherehand_amd import hand_model, ops
+    g = golden("g2_mesh.npz")
+    faces = torch.from_numpy(hand_model.load_mesh()["faces"].astype(np.int32)).cuda()[:, [0, 2, 1]].contiguous()
+    verts = dev(g["verts"])[:2].clone()
+    verts[:, :, 0:2] *= src / 640.0
+    verts = verts.contiguous()
+    tile = ops.mesh_depth_fwd(verts, faces, S, src, 100.0)
+    raw = ops.tri_raster_indexed_fwd(src, src, verts, faces)
+    chain = torch.nn.functional.interpolate(torch.clamp(raw, max=100.0).unsqueeze(1), size=(S, S), mode="bilinear",
+                                            align_corners=False).squeeze(1)
+    assert (tile - chain).abs().max().item() <= 1e-5 * max(1.0, chain.abs().max().item())
+    assert (tile < 100).float().mean().item() > 0.02
+
+
 def test_fused_depth_render_rand_f_and_batch():
     from spherehand_amd import hand_model
     from spherehand_amd.joint_angle import sample_poses
