@@ -128,13 +128,6 @@ int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W,
                           float *depth, float *sse_partial,
                           float *grad_spheres_partial, void *stream);
 
-/* y = relu(GroupNorm(x)) for channels-last (NHWC) fp32 activations x[N][HW][C], forward and
- * backward: the `F.relu(self.bnK(x))` pairs of network/hourglass.py:28-31 without the NCHW
- * round trips of torch's GroupNorm.  G groups of C/G consecutive channels, biased variance,
- * eps inside the root (torch.nn.GroupNorm).  mean / rstd are [N][G] (saved for the backward).
- * The backward returns dx, PER-SAMPLE partials dgamma_partial / dbeta_partial [N][C] and, when
- * dgamma / dbeta [C] are not NULL, their sums over the samples (in order: deterministic).  shr_group_norm_relu_supported: C % 32 == 0 and C/G in
- * {4, 8, 16, 32}; buffers 16-byte aligned. */
 /* CollisionLoss and BoneLengthLoss (mesh/render.py:145-206) on M samples of J sphere centres (sample m at
  * joints + m*sample_stride floats, [J][3]) with their gradients, one launch.  Collision pairs: spheres
  * 0..num_palm-1 (palm) against every finger sphere, and finger spheres of different fingers (finger f =
@@ -176,6 +169,14 @@ int shr_heatmap_paint(const float *uvd, int BJ, int S, float sigma, float uv_sca
 int shr_depth_noise(const float *depth, const float *normal3, int B, int H, int W,
                     float sigma_xy, float sigma_z, float *out, void *stream);
 
+/* y = relu(GroupNorm(x)) for channels-last (NHWC) fp32 activations x[N][HW][C], forward and
+ * backward: the `F.relu(self.bnK(x))` pairs of network/hourglass.py:28-31 without the NCHW
+ * round trips of torch's GroupNorm.  G groups of C/G consecutive channels, biased variance,
+ * eps inside the root (torch.nn.GroupNorm).  mean / rstd are [N][G] (saved for the backward).
+ * The backward returns dx, PER-SAMPLE partials dgamma_partial / dbeta_partial [N][C] and, when
+ * dgamma / dbeta [C] are not NULL, their sums over the samples (in order: deterministic).
+ * shr_group_norm_relu_supported: C % 32 == 0 and C/G in
+ * {4, 8, 16, 32}; buffers 16-byte aligned. */
 int shr_group_norm_relu_supported(int C, int G);
 int shr_group_norm_relu_fwd(const float *x, const float *gamma, const float *beta,
                             int N, int C, int HW, int G, float eps,
