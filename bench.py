@@ -151,6 +151,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        # the launcher's world size, --gpus and what RCCL actually connected must agree
+        assert dist.get_world_size() == world == args.gpus, \
+            "launched %d ranks (RCCL sees %d) but --gpus %d" % (world, dist.get_world_size(), args.gpus)
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)                               # one RCCL all-reduce over xGMI: counts the ranks
+        assert int(seen.item()) == world, "RCCL all-reduce saw %d ranks, expected %d" % (int(seen.item()), world)
+        rccl_ranks = int(seen.item())
+    else:
+        assert args.gpus == 1, "--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus)
+        rccl_ranks = 1
 
     from spherehand_amd import _lib
     lib = _lib.lib()
@@ -234,7 +244,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: batch-256 128x128 sphere raster fwd+bwd, 41 spheres/crop, "
                                    "JointAngleDataset poses (seed 0), grad N(0,1)",
                        "crops_per_gpu": BATCH, "image": [S, S], "spheres_per_crop": J,
-                       "launch": args.launch, "parallelism": "batch-sharded x%d, no data-path collective" % world},
+                       "launch": args.launch, "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                       "rccl_ranks": rccl_ranks},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,

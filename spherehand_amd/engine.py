@@ -27,6 +27,8 @@ import torch.utils.data as data
 from .criterion import HeatmapEstimationNetwork, MultiTaskLoss, average_joint_error, combine_loss
 from .hand_model import load_mesh
 from .joint_angle import JointAngleDataset
+from .pose_denoiser import default_pose_denoiser
+from .pose_vae import default_pose_vae
 from .util_modules import DepthResample, HandSynthesizer
 
 
@@ -128,7 +130,7 @@ class Engine:
     can be passed instead."""
 
     def __init__(self, opts, mesh=None, real_train_dataset=None, real_eval_dataset=None, device=None,
-                 prior_loss=None):
+                 prior_loss=None, pose_denoiser=None):
         self.env = DistEnv(device)
         dev = self.env.device
         S = getattr(opts, 'image_size', 64)
@@ -139,12 +141,16 @@ class Engine:
             # MIOpen's NHWC kernels: hourglass fwd+bwd on 123 crops 25.0 -> 14.0 ms on MI355X (fp32, same math)
             self.network = self.network.to(memory_format=torch.channels_last)
         self.ddp_network = self.env.wrap(self.network)
+        if opts.prior and prior_loss is None:
+            prior_loss = default_pose_vae()        # PoseVae(41*3, 32, 'mesh/model/pose_vae.pth'), create_network...:164
         self.criterion = MultiTaskLoss(opts.synthesize, opts.mv_projection, opts.mv_consistency, opts.temporal,
                                        prior_loss if opts.prior else None, opts.collision, opts.bone_length, c,
                                        image_size=S, heatmap_size=c.heatmap_size).to(dev)
         self.hand_synthesizer = None
         if opts.synthesize and dev.type == 'cuda':
             self.hand_synthesizer = HandSynthesizer(c.mesh, S, c.heatmap_size, c.uv_hm_scale, c.depth_scale).to(dev)
+        # network/engine.py:71-73: the frozen palm re-predictor the Eval metric goes through
+        self.pose_denoiser = (pose_denoiser if pose_denoiser is not None else default_pose_denoiser()).to(dev).eval()
         self.depth_sampler = DepthResample(0.95, opts.depth_resample).to(dev) if getattr(opts, 'depth_resample', 0) else None
         self.num_stacks = opts.num_stacks
         self.temporal_smooth = opts.temporal
@@ -236,13 +242,17 @@ class Engine:
     # ------------------------------------------------------------------ steps
     def step(self, real_batch=None, pose_parameter=None, train=True, is_mv=True):
         """One optimisation (or evaluation) step.  Returns (loss_terms, metrics,
-        result, projected_dms); tensors stay on the device."""
+        result, projected_dms); tensors stay on the device.  The metric follows the
+        reference: in training the raw network output of every view (engine.py:207-210,
+        :369-370), in evaluation VIEW 0 ONLY after the pose denoiser (engine.py:200-206)
+        -- that is the "NYU mean 3D joint error"."""
         net = self.ddp_network if train else self.network
         synt_target = real_target = None
         kwargs = {}
         if pose_parameter is not None:
             synt_dms, uv_hms, d_hms, xyz = self.hand_synthesizer(pose_parameter.to(self.env.device))
-            if self.depth_sampler is not None:
+            if self.depth_sampler is not None and real_batch is not None:
+                # only the mixed epoch resamples the synthetic crops (engine.py:352-353; _epoch_with_synt does not)
                 synt_dms = self.depth_sampler(synt_dms).squeeze(1)
             kwargs['synt_dms'] = synt_dms
             synt_target = {'uv_hms': uv_hms, 'd_hms': d_hms, 'xyz_pts': xyz}
@@ -257,7 +267,13 @@ class Engine:
         loss_terms, projected = self.criterion(result, synt_target=synt_target, real_target=real_target)
         metrics = {}
         if gt_joints is not None:
-            metrics['avg_joint_error'] = average_joint_error(gt_joints, result['real_xyz'][-1].detach())
+            est = result['real_xyz'][-1].detach()
+            if not train:
+                with torch.no_grad():
+                    metrics['avg_joint_error'] = average_joint_error(
+                        gt_joints[:, 0].unsqueeze(1), self.pose_denoiser(est[:, 0]).unsqueeze(1))
+            else:
+                metrics['avg_joint_error'] = average_joint_error(gt_joints, est)
         if train:
             combine_loss(loss_terms).backward()
             self.optimizer.step()

@@ -40,8 +40,12 @@ class RecoverXYZCoordinateFromHeatmap(nn.Module):
         self.depth_scale = 1.0 / depth_scale
         self.fx, self.fy = width / 300.0, height / 300.0
         self.cx, self.cy = width / 2, height / 2
-        self.register_buffer('u_grid', torch.arange(width, dtype=torch.float32).view(1, 1, 1, width))
-        self.register_buffer('v_grid', torch.arange(height, dtype=torch.float32).view(1, 1, height, 1))
+        # full [1,1,H,W] grids: they are part of network_state_dict (HeatmapEstimationNetwork.xyz_recover),
+        # so the shapes are the reference's (network/util_modules.py:174-181) and checkpoints interoperate
+        u = torch.arange(width, dtype=torch.float32).view(1, 1, 1, width).expand(1, 1, height, width)
+        v = torch.arange(height, dtype=torch.float32).view(1, 1, height, 1).expand(1, 1, height, width)
+        self.register_buffer('u_grid', u.contiguous())
+        self.register_buffer('v_grid', v.contiguous())
 
     def from_output(self, hm):
         """xyz from the network's raw output hm [N,2J,h,w] (uv maps | depth maps): one kernel per direction on

@@ -153,3 +153,59 @@ def test_synth_post_kernels_match_the_torch_modules():
     with torch.no_grad():
         z = DepthNoise(64, 64).cuda()(dm)
     assert z.shape == dm.shape and ((z - dm).abs() > 0).float().mean().item() > 0.3
+
+
+def test_pose_denoiser_on_gpu_matches_reference():
+    """The shipped denoiser on the device vs the imported reference's outputs (g9): 1e-5 of the 100-mm scale."""
+    from spherehand_amd.pose_denoiser import default_pose_denoiser
+    g = golden("g9_priors.npz")
+    dn = default_pose_denoiser().cuda()
+    out = dn(dev(g["dn_in"])[:, 0])
+    assert np.abs(out.cpu().numpy() - g["dn_out"]).max() <= 1e-5 * 100
+    from spherehand_amd.criterion import average_joint_error
+    ev = average_joint_error(dev(g["metric_gt"])[:, 0].unsqueeze(1), out.unsqueeze(1))
+    assert abs(float(ev) - float(g["metric_eval"])) <= 1e-5 * float(g["metric_eval"])
+
+
+def test_run_engine_eval_on_nyu_shards_reports_the_reference_metric(tmp_path, capsys):
+    """BASELINE configs[2] end to end without the absent assets: NYU-format shards on disk ->
+    `run_engine` (default mode = evaluation, every loss term on incl. the VAE prior) -> the printed
+    `avg_joint_error` is the reference's definition (network/engine.py:158-159, :200-206, :262-263): batches of 8
+    in order, view 0 only, PoseDenoiser first, mean of the per-batch means."""
+    from spherehand_amd import hand_model, run_engine
+    from spherehand_amd.criterion import HeatmapEstimationNetwork, average_joint_error
+    from spherehand_amd.datasets import SyntheticMultiviewDataset, create_nyu_dataset, write_nyu_shard
+    from spherehand_amd.pose_denoiser import default_pose_denoiser
+    mesh = hand_model.load_mesh()
+    ds = SyntheticMultiviewDataset(mesh, 20, 64, seed=5)
+    for split, sl in (("train", slice(0, 8)), ("test", slice(0, 20))):
+        os.makedirs(tmp_path / "nyu" / split)
+        # two shards per split (the reader concatenates mv_data_0, mv_data_1, ...)
+        n = (sl.stop - sl.start) // 2
+        for k, s in enumerate((slice(sl.start, sl.start + n), slice(sl.start + n, sl.stop))):
+            write_nyu_shard(str(tmp_path / "nyu" / split / ("mv_data_%d" % k)), ds.dms[s].numpy(), ds.gt[s].numpy(),
+                            ds.cam[s].numpy())
+    torch.manual_seed(3)
+    net = HeatmapEstimationNetwork(16, 0.01, 41, 1)
+    ckpt = str(tmp_path / "self-supervised.pth")
+    torch.save({"epoch": 0, "network_state_dict": net.state_dict()}, ckpt)
+    summary = run_engine.main(["--dataset_dir", str(tmp_path / "nyu"), "--model_dir", str(tmp_path / "out"),
+                               "--initial_model", ckpt])
+    assert "avg_joint_error" in capsys.readouterr().out
+    # the same number by hand
+    net = net.cuda().to(memory_format=torch.channels_last).eval()
+    dn = default_pose_denoiser().cuda()
+    test = create_nyu_dataset(str(tmp_path / "nyu" / "test"))
+    assert len(test) == 20
+    per_batch = []
+    with torch.no_grad():
+        for s in range(0, 20, 8):
+            items = [test[i] for i in range(s, min(s + 8, 20))]
+            dms = torch.from_numpy(np.stack([it[0] for it in items])).cuda()
+            gt = torch.from_numpy(np.stack([it[1] for it in items])).cuda()
+            xyz = net(real_dms=dms * 0.01)["real_xyz"][-1]
+            per_batch.append(float(average_joint_error(gt[:, 0].unsqueeze(1), dn(xyz[:, 0]).unsqueeze(1))))
+    expect = float(np.mean(per_batch))
+    got = summary["metric"]["avg_joint_error"]
+    assert abs(got - expect) <= 1e-5 * expect, (got, expect)
+    assert "pose_prior" in summary["loss"] and "mv_projection" in summary["loss"]
