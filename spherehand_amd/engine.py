@@ -133,6 +133,11 @@ class Engine:
                  prior_loss=None, pose_denoiser=None):
         self.env = DistEnv(device)
         dev = self.env.device
+        if getattr(opts, 'deterministic', False):
+            # MIOpen's default backward-weights solvers accumulate with float atomics: the hourglass gradient
+            # then varies run to run (up to 3e-3 of its largest entry on MI355X, tools/debug_determinism.py).
+            # This project's own kernels are deterministic by construction (no float atomics anywhere).
+            torch.backends.cudnn.deterministic = True
         S = getattr(opts, 'image_size', 64)
         self.constant = Constant(mesh, S)
         c = self.constant

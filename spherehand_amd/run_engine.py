@@ -31,6 +31,8 @@ def build_parser():
                    help='use N sphere-rendered multiview samples in place of the NYU shards')
     p.add_argument('--steps_per_epoch', default=None, type=int)
     p.add_argument('--log_every', default=100, type=int)
+    p.add_argument('--deterministic', default=False, action='store_true',
+                   help='deterministic MIOpen solvers (run-to-run reproducible hourglass gradients)')
     return p
 
 

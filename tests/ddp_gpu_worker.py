@@ -19,10 +19,13 @@ GLOBAL_REAL, GLOBAL_SYNT = 8, 12
 
 
 def make_opts(model_dir):
-    return SimpleNamespace(synthesize=True, mv_projection=True, mv_consistency=True, temporal=False, prior=False,
-                           collision=True, bone_length=True, mode='Train', model_dir=model_dir, initial_model=None,
+    on = os.environ.get('SHR_DDP_TERMS', 'synthesize,mv_projection,mv_consistency,collision,bone_length').split(',')
+    return SimpleNamespace(synthesize='synthesize' in on, mv_projection='mv_projection' in on,
+                           mv_consistency='mv_consistency' in on, temporal=False, prior=False,
+                           collision='collision' in on, bone_length='bone_length' in on, mode='Train', model_dir=model_dir, initial_model=None,
                            restore_from_model=None, restore_from_epoch=-1, num_stacks=1, epoch=3, dataset_dir=None,
-                           depth_resample=0, lr=1e-3, tag='ddpgpu', image_size=64, log_every=1)
+                           depth_resample=0, lr=1e-3, tag='ddpgpu', image_size=64, log_every=1,
+                           deterministic=True)
 
 
 class ShardedSynth:
@@ -69,9 +72,11 @@ def run(out_path, model_dir):
     grads = {k: p.grad.detach().cpu().clone() for k, p in eng.network.named_parameters()}
     params = {k: p.detach().cpu().clone() for k, p in eng.network.named_parameters()}
     vals = {k: float(v) for k, v in terms.items()}
-    vals['collision'] /= world                              # back to this rank's share of the global sum ...
+    if 'collision' in vals:
+        vals['collision'] /= world                              # back to this rank's share of the global sum ...
     means = eng.env.mean_scalars(vals)
-    means['collision'] *= world                             # ... whose mean x world is the global sum
+    if 'collision' in means:
+        means['collision'] *= world                             # ... whose mean x world is the global sum
     metric = eng.env.mean_scalars({k: float(v) for k, v in metrics.items()})
     if eng.env.is_main:
         torch.save({'grads': grads, 'params': params, 'terms': means, 'metric': metric, 'world': eng.env.world,
