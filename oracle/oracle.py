@@ -119,11 +119,21 @@ def data_to_model_bwd(depth, centres, radii):
     return out
 
 
-def tri_raster_fwd(face_vertices, W, H):
+def fma_variant():
+    """The SAME source compiled with FMA contraction (-ffp-contract=fast -mfma): a sensitivity probe for
+    the triangle kernel (what nvcc's default -fmad=true might do to the reference), never the oracle."""
+    so = os.path.join(_HERE, "libspherehand_oracle_fma.so")
+    src = os.path.join(_HERE, "spherehand_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libspherehand_oracle_fma.so"])
+    return ctypes.CDLL(so)
+
+
+def tri_raster_fwd(face_vertices, W, H, handle=None):
     fv = _f32(face_vertices)
     B, F = fv.shape[0], fv.shape[1]
     out = np.empty((B, H, W), np.float32)
-    _chk(lib().oracle_tri_raster_fwd(_p(fv), B, F, W, H, _p(out)), "oracle_tri_raster_fwd")
+    _chk((handle or lib()).oracle_tri_raster_fwd(_p(fv), B, F, W, H, _p(out)), "oracle_tri_raster_fwd")
     return out
 
 

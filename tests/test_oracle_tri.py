@@ -140,6 +140,56 @@ def test_oracle_clamp_bilinear_vs_reference(oracle):
     assert int((g["depth64"][0] < 100).sum()) == 956       # SURVEY appendix A (host-compiled reference kernel)
 
 
+def test_rest_pose_statistics_of_the_reference_kernel(oracle):
+    """What SURVEY 2.3 / App. A measured on the reference kernel body at the rest pose: 1794 of 3382 faces
+    culled (.cu:33) and 956 foreground pixels in the 64x64 DepthRender.  (SURVEY also quotes a raw minimum of
+    -74 297; that value is the 1/z interpolation next to a zero of w0/z0+w1/z1+w2/z2 on a face straddling z = 0
+    (.cu:109) and moves by a factor with the last bit of a vertex -- this oracle gives -7230.78 on the
+    reference's own fp32 vertices, the FMA-contracted build -6922.72; it is recorded, not asserted equal.)"""
+    g = golden("g2_mesh.npz")
+    assert np.abs(g["params"][0]).max() == 0.0
+    f = g["face_vertices"][0].reshape(-1, 9)
+    culled = (f[:, 7] - f[:, 1]) * (f[:, 3] - f[:, 0]) < (f[:, 4] - f[:, 1]) * (f[:, 6] - f[:, 0])
+    assert int(culled.sum()) == 1794 and len(f) == 3382
+    assert int((g["depth64"][0] < 100).sum()) == 956
+    raw = oracle.tri_raster_fwd(g["face_vertices"][:1], 640, 640)
+    assert raw.min() < -1000.0 and raw.min() == g["raw640_min"][0]
+
+
+def test_tri_fma_sensitivity(oracle):
+    """Parity of this kernel is UNPINNED (no nvcc here); this quantifies what that can cost.  nvcc contracts
+    mul+add into FMA by default; which products it fuses is not recoverable, so the restatement is compiled a
+    second time with contraction allowed everywhere (-ffp-contract=fast -mfma) and compared with the oracle of
+    record (-ffp-contract=off) on g2's four poses.  Measured (this test prints the table):
+      * 640x640 raster: 12-21 % of the pixels differ in their last bits, NO pixel changes coverage, and
+        1.3-3.1 % of the covered pixels move by more than 1e-4 relative -- all of them 1/z interpolations on
+        faces that straddle z = 0 (.cu:109), where the value is the reciprocal of a near-cancelling sum;
+      * after clamp(max=100) + bilinear resize: at most 5 / 12 / 68 of the 64^2 / 128^2 / 256^2 output pixels
+        differ by more than 1e-4 of the image's maximum, every other pixel agrees to <= 1e-4.
+    So "<= 1e-4 relative L-inf against the CUDA rasterizer" is attainable everywhere except at a handful of
+    near-singular pixels per image whose value the reference itself does not determine beyond its compiler."""
+    g = golden("g2_mesh.npz")
+    fv = g["face_vertices"]
+    a = oracle.tri_raster_fwd(fv, 640, 640)
+    b = oracle.tri_raster_fwd(fv, 640, 640, oracle.fma_variant())
+    assert np.array_equal(a < 1000, b < 1000)                       # coverage never flips
+    for i in range(4):
+        cov = a[i] < 1000
+        rel = np.abs(a[i] - b[i])[cov] / np.maximum(np.abs(a[i][cov]), 1e-30)
+        frac_bits = float((a[i] != b[i]).mean())
+        frac_far = float((rel > 1e-4).mean())
+        print("pose %d: 640^2 px differing %.1f %%, covered px beyond 1e-4 rel: %.2f %% (max rel %.3g)"
+              % (i, 100 * frac_bits, 100 * frac_far, rel.max()))
+        assert 0.05 < frac_bits < 0.30 and frac_far < 0.05
+    for S, cap in ((64, 8), (128, 16), (256, 96)):
+        da, db = oracle.clamp_bilinear(a, S, S, 100.0), oracle.clamp_bilinear(b, S, S, 100.0)
+        for i in range(4):
+            diff = np.abs(da[i] - db[i])
+            far = int((diff > 1e-4 * np.abs(da[i]).max()).sum())
+            print("S=%d pose %d: %d px beyond 1e-4 of max, L-inf %.3g" % (S, i, far, diff.max() / np.abs(da[i]).max()))
+            assert far <= cap
+
+
 def test_oracle_fk_vs_reference(oracle):
     from spherehand_amd import hand_model
     g = golden("g3_batch256.npz")
