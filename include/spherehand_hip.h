@@ -57,6 +57,8 @@ int shr_device_info(char *name_host, int name_len, int *num_cu_host);
  * one byte per group, oldest in the low byte, any scale (normalised internally). */
 #define SHR_TUNE_FWD_SHARES 6
 #define SHR_TUNE_BWD_SHARES 7
+#define SHR_TUNE_D2M_WAVES 8       /* waves per workgroup of the data->model kernel: 0 = by batch size, 4, 8 or 16 */
+#define SHR_TUNE_D2M_BAND_UNITS 9  /* 256-pixel units per band handed to a wave: 0 = by crop size */
 int shr_set_tuning(int key, int value);
 /* Self-test: adds to *mismatches (device, caller-zeroed u64) the number of fp32
  * bit patterns in [lo_bits, hi_bits) where the rasterizer's internal square root
@@ -109,6 +111,18 @@ int shr_data_to_model_indexed(const float *depth, const int32_t *depth_index,
                               const float *centres, const float *radii,
                               int N, int J, int H, int W, float *loss_sum,
                               float *grad_centres, void *stream);
+/* The same in `parts` PARTIAL results per crop (1, 2 or 4): crop n's loss sum is
+ * loss_parts[n*parts] + ... + loss_parts[n*parts + parts-1], likewise grad_parts[N*parts][J][3] -- large crops
+ * are split over several workgroups on different CUs, and the caller adds the partials (fixed order:
+ * deterministic).  shr_data_to_model_parts() returns the split this library prefers for a problem size
+ * (1 below 192 x 192 pixels, else 2).  depth_index may be NULL (crop n reads image n).  The sums are accumulated
+ * as fixed-point integers inside the kernel: a crop's result is bit-reproducible and does not depend on the
+ * launch shape. */
+int shr_data_to_model_parts(int N, int H, int W);
+int shr_data_to_model_partial(const float *depth, const int32_t *depth_index,
+                              const float *centres, const float *radii,
+                              int N, int J, int H, int W, int parts, float *loss_parts,
+                              float *grad_parts, void *stream);
 
 /* Fused render-and-compare: the model->data term of mesh/multiview_utility.py:98-101 and
  * :107-113 (MSELoss(BallRender(...).min(), observed)) with its whole backward, one

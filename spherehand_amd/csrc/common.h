@@ -130,6 +130,22 @@ __device__ __forceinline__ float wave_min4_transposed(float a0, float a1, float 
   return fminf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
 }
 
+// Correctly rounded fp32 square root for x in [0.01, 1e12] (sphere_zbuf.h documents the range and the
+// exhaustive test): v_sqrt_f32 (<= 1 ulp) corrected by the exact residuals of its two neighbours.
+__device__ __forceinline__ float sqrt_rn(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float dn = __uint_as_float(__float_as_uint(s) - 1u);
+  const float up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float e_dn = __builtin_fmaf(-dn, s, x);
+  const float e_up = __builtin_fmaf(-up, s, x);
+  float r = (e_dn <= 0.0f) ? dn : s;
+  r = (e_up > 0.0f) ? up : r;
+  return r;
+}
+
+int d2m_set_waves(int waves);        // data_to_model.hip: launch-shape hooks behind SHR_TUNE_D2M_WAVES /
+int d2m_set_band_units(int units);  // SHR_TUNE_D2M_BAND_UNITS
+
 __device__ __forceinline__ bool is_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
 }  // namespace shr

@@ -12,307 +12,483 @@
 //                           -sign(dist - r_j) * (p - c_j) / dist
 // and the caller scales it by upstream / (N*H*W).
 //
-// The nearest surface can be ANY sphere (no culling is valid), but only ~15 % of
-// the pixels are foreground, so each 4096-pixel chunk is first compacted:
-//   1. coalesced 16-byte depth loads, foreground flags, deterministic block scan;
-//   2. foreground pixels packed into an LDS queue (lanes fully used from here);
-//   3. each wave bounds the J spheres against the bounding box of its 64 queue entries
-//      (lanes = spheres) and searches only the candidates that can be nearest (lanes =
-//      points) and adds the clamped distance;
-//   4. the gradient vectors of a wave's 64 points are summed per owner with DPP wave
-//      sums into the wave's private LDS row; rows are combined in wave order:
-//      deterministic, no atomics.
-// One workgroup per crop.  HBM: reads 4*H*W + 12*J + 4*J bytes per crop.
+// Design (round 2; the round-1 kernel pruned per 64 points with wave-wide boxes and seeds and was
+// bound by the latency of those reductions and of one-point-per-lane dependent chains):
+//   * every WAVE is independent until the final combine.  The crop is cut into UNITS of 256
+//     consecutive pixels (one 16-byte load per lane) and BANDS of consecutive units (a few rows to a
+//     few dozen), dealt round-robin to the waves, two or more per wave: every wave carries an equal
+//     share of the hand while the points it searches together stay neighbours.  Three units' loads
+//     are in flight per wave, across band boundaries;
+//   * a wave keeps the ~15 % foreground pixels of a unit and appends them -- lane order,
+//     ballot/mbcnt prefix -- to its own ring in LDS as 8-byte (v << 16 | u, z) entries; whenever
+//     256 entries are there (and at the end of the band) it searches them, FOUR neighbouring points
+//     per lane: a sphere's record is read once for the 256 points (uniform-address ds_read_b128 =
+//     an LDS broadcast), ~11 VALU instructions per (point, sphere), four independent chains per lane;
+//   * the points of a search lie in a thin strip of rows [y_lo, y_hi] (first / last ring entry:
+//     256 points are ~5 rows of a hand), and | ||p - c|| - r | >= dist_y(c, strip) - r, so with
+//     lanes = spheres one ballot gives the spheres whose y extent meets the strip.  They are
+//     searched first; the largest of the running minima (one wave maximum per search) then bounds
+//     what any other sphere would have to beat, and only spheres whose gap is below it are
+//     searched as well -- exact (a pruned sphere can neither win nor tie);
+//   * the loss and the gradient are accumulated as FIXED-POINT integers (2^-20 mm / 2^-26 per
+//     unit-vector component; 64-bit LDS atomics on one table per workgroup, a lane's four points
+//     combined first when they share their owner): integer sums do not depend on their order, so
+//     the result is bit-reproducible AND independent of the launch shape, without any per-owner
+//     wave reduction (the round-1 ballot loop over distinct owners was a third of the kernel).
+// A non-finite sphere record or depth value sends the search through the exact index-order loop
+// (torch.min / clamp propagate NaN).  HBM: reads 4*H*W + 12*J + 4*J bytes per crop.
+
+#include <type_traits>
 
 #include "common.h"
 
 namespace shr {
 
-constexpr int kD2mThreads = 512;   // 8 waves: two workgroups per CU overlap one crop's loads with the other's search
-constexpr int kD2mPix = 16;                           // a 4x4-pixel block per thread per chunk (4 x 16-byte loads in flight);
-                                                      // 1024 threads = 16384 px = a whole 128x128 crop
-constexpr int kD2mQueue = 2048;                       // queue entries (32 KB); denser chunks take extra passes
+constexpr int kD2mK = 4;                    // points per lane per search
+constexpr int kD2mGroup = 64 * kD2mK;       // entries per full search
+constexpr int kD2mCap = 512;                // ring entries per wave (< 256 left over + <= 256 new per unit)
+constexpr float kLossScale = 1048576.f;     // 2^20: loss in units of 2^-20 mm (e <= 50 -> < 2^26 per point)
+constexpr float kGradScale = 67108864.f;    // 2^26 per unit-vector component
 
-constexpr int kD2mSeeds = 3;                           // best-first visits before the candidate set is fixed
+// A wave's position in its sequence of units: band `band` = units band * band_units .. (clipped).  Bands are handed
+// out DYNAMICALLY inside the workgroup (an LDS counter): the sums are order-independent integers, so which wave
+// takes which band changes nothing in the result, and no wave idles at the final barrier while a sibling still
+// has rows of the hand to search.
+struct D2mUnitIter {
+  int band, unit, unit_end;
+  bool done;
+  __device__ void seek(int b, int nbands, int band_units, int units, int parts = 1, int part = 0) {
+    band = b;
+    done = b * parts + part >= nbands;
+    unit = (b * parts + part) * band_units;
+    unit_end = min(units, unit + band_units);
+  }
+};
 
-struct QEntry { float a, b, c; int d; };  // phase 2: (xg, yg, z, -) ; phase 3: (gx, gy, gz, owner)
-
-template <bool WANT_GRAD>
-__global__ void __launch_bounds__(kD2mThreads)
+template <bool WANT_GRAD, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
 data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ depth_index,
                      const float *__restrict__ centres, const float *__restrict__ radii, int J, int H, int W,
-                     float *__restrict__ loss_sum, float *__restrict__ grad_centres) {
-  __shared__ float4 s_c[SHR_MAX_SPHERES];     // (cx, cy, cz, r)
-  __shared__ int s_wave_cnt[kD2mThreads / 64];
-  __shared__ float s_wave_loss[kD2mThreads / 64];
-  __shared__ QEntry s_q[kD2mQueue];           // 32 KB
-  __shared__ float4 s_part[(kD2mThreads / 64) * SHR_MAX_SPHERES];   // [wave][sphere] gradient partials
+                     int band_units, int parts, float *__restrict__ loss_sum, float *__restrict__ grad_centres) {
+  __shared__ float4 s_c[SHR_MAX_SPHERES];                 // (cx, cy, cz, r)
+  __shared__ int s_odd, s_nan;                            // non-finite sphere table / a NaN loss term
+  __shared__ unsigned long long s_loss;                   // fixed-point loss sum
+  __shared__ unsigned long long s_acc[WANT_GRAD ? SHR_MAX_SPHERES * 4 : 1];   // fixed-point gradient rows [sphere][x,y,z,-]
+  __shared__ uint2 s_q[WAVES][kD2mCap];                   // per-wave rings of foreground pixels
+  __shared__ int s_next_band;                             // bands are handed out dynamically (see below)
+  __shared__ int s_bandq[WAVES][8];                       // per wave: bands its loads have entered, not yet processed
 
-  const int n = blockIdx.x;
+  const int n = blockIdx.x / parts, part = blockIdx.x - n * parts;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < J) {
-    const float *c = centres + ((size_t)n * J + tid) * 3;
-    s_c[tid] = make_float4(c[0], c[1], c[2], radii[tid]);
+  if (wave == 0) {
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < J) {
+      const float *p = centres + ((size_t)n * J + lane) * 3;
+      c = make_float4(p[0], p[1], p[2], radii[lane]);
+      s_c[lane] = c;
+    }
+    const float inf = __builtin_inff();
+    const bool bad = !(fabsf(c.x) < inf) || !(fabsf(c.y) < inf) || !(fabsf(c.z) < inf) || !(fabsf(c.w) < inf);
+    const bool any = __ballot(bad) != 0ull;
+    if (lane == 0) { s_odd = any; s_nan = 0; s_loss = 0ull; s_next_band = WAVES; }
   }
+  if (WANT_GRAD)
+    for (int i = tid; i < SHR_MAX_SPHERES * 4; i += WAVES * 64) s_acc[i] = 0ull;
+  __syncthreads();
+  const bool table_odd = s_odd != 0;
+  // lanes = spheres: this lane's record for the box bounds
+  const float4 cj = lane < J ? s_c[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned long long all = J >= 64 ? ~0ull : ((1ull << J) - 1ull);
+
   const float *dm = depth + (size_t)(depth_index ? depth_index[n] : n) * H * W;
   const Axis ax = make_axis(W), ay = make_axis(H);
-  const bool row4 = (W % 4 == 0) && is_aligned16(dm);
+  const bool vec4 = (W % 4 == 0) && is_aligned16(dm);
+  const int P = H * W;
+  const int units = (P + 255) >> 8, nbands = (units + band_units - 1) / band_units;
+  const int wshift = (W & (W - 1)) == 0 ? __builtin_ctz(W) : -1;
+  uint2 *ring = s_q[wave];
+  long long loss_fx = 0;
 
-  float loss = 0.f;
-  if (WANT_GRAD) s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);   // 1024 = 16 waves x 64 spheres
+  // a sphere's record by an explicit LDS read whose wait is placed by hand (see stage 1 below)
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const unsigned table_base = (unsigned)(size_t)s_c;
+  auto lds_request = [&](int j) {
+    f4 r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(table_base + 16u * (unsigned)j));
+    return r;
+  };
+  auto lds_arrived = [&](f4 &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)); };
 
-  // Threads own 4x4-pixel blocks (block id = chunk base + thread id, row-major over the
-  // ceil(W/4) x ceil(H/4) block grid): each of a thread's four 16-byte loads is contiguous
-  // with its neighbours' in x, and the queue (thread order, row-major inside a block) keeps
-  // neighbouring pixels together, so a wave's 64 entries have a tight bounding box (step 3).
-  // The 512 blocks of a chunk form a 32 x 16 tile visited in Morton order: 64 consecutive
-  // threads = an 8 x 8 group of blocks (32 x 32 px), 4-5 consecutive blocks = a near-square
-  // patch, so the points a wave searches together are neighbours in x AND y.
-  const int nbx = (W + 3) >> 2, nby = (H + 3) >> 2;
-  const int tiles_x = (nbx + 31) >> 5, tiles_y = (nby + 15) >> 4;
-  auto even_bits = [](int t) { t &= 0x55; t = (t | (t >> 1)) & 0x33; return (t | (t >> 2)) & 0x0f; };
-  static_assert(kD2mThreads == 512, "tile = 32 x 16 blocks");
-  const int mx = even_bits(tid) | ((tid >> 8) << 4), my = even_bits(tid >> 1);
-  for (int tile = 0; tile < tiles_x * tiles_y; tile++) {
-    // ---- 1. load the block (all four loads issued before the first use), flag foreground
-    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-    const int bx = tile_x * 32 + mx, by = tile_y * 16 + my;
-    const bool inside = bx < nbx && by < nby;
-    const int u0 = bx * 4, v0 = by * 4;
-    float z[kD2mPix];
-    int cnt = 0;
-    unsigned fgmask = 0;
-    if (row4) {
-      // unconditional, clamped: the four requests go out back to back (one round trip); what
-      // lies outside the image is masked below
-      const int byc = min(by, nby - 1), bxc = min(bx, nbx - 1);
-      const float4 *p0 = reinterpret_cast<const float4 *>(dm + (size_t)min(byc * 4 + 0, H - 1) * W) + bxc;
-      const float4 *p1 = reinterpret_cast<const float4 *>(dm + (size_t)min(byc * 4 + 1, H - 1) * W) + bxc;
-      const float4 *p2 = reinterpret_cast<const float4 *>(dm + (size_t)min(byc * 4 + 2, H - 1) * W) + bxc;
-      const float4 *p3 = reinterpret_cast<const float4 *>(dm + (size_t)min(byc * 4 + 3, H - 1) * W) + bxc;
-      const float4 t0 = *p0, t1 = *p1, t2 = *p2, t3 = *p3;
-      z[0] = t0.x; z[1] = t0.y; z[2] = t0.z; z[3] = t0.w;
-      z[4] = t1.x; z[5] = t1.y; z[6] = t1.z; z[7] = t1.w;
-      z[8] = t2.x; z[9] = t2.y; z[10] = t2.z; z[11] = t2.w;
-      z[12] = t3.x; z[13] = t3.y; z[14] = t3.z; z[15] = t3.w;
+  // ---- the search over `count` (<= 64 K) ring entries starting at `head`; lane l takes the K
+  // consecutive entries K l .. K l + K - 1 (neighbouring pixels: mostly one owner) -------------------
+  auto search = [&](auto kc, int head, int count) {
+    constexpr int K = decltype(kc)::value;
+    float px[K], py[K], pz[K], best[K];
+    int bj[K];
+    bool valid[K];
+    bool zbad = false;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+      const int idx = K * lane + i;
+      valid[i] = idx < count;
+      const uint2 e = ring[(head + (valid[i] ? idx : 0)) & (kD2mCap - 1)];
+      px[i] = axis_coord(ax, (int)(e.x & 0xffffu));
+      py[i] = axis_coord(ay, (int)(e.x >> 16));
+      pz[i] = __uint_as_float(e.y);
+      zbad |= !(fabsf(pz[i]) < __builtin_inff());
+    }
+    auto eval = [&](const float4 c, int j, bool tie_rule) {
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        const float dx = px[i] - c.x, dy = py[i] - c.y, dz = pz[i] - c.z;
+        const float t = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        const float a = fabsf(__builtin_amdgcn_sqrtf(t) - c.w);   // <= 1 ulp root: the loss is continuous
+        const bool lt = tie_rule ? (a < best[i] || (a == best[i] && j < bj[i])) : (a < best[i]);
+        bj[i] = lt ? j : bj[i];
+        best[i] = lt ? a : best[i];
+      }
+    };
+#ifdef EXP_NOSEARCH
+#pragma unroll
+    for (int i = 0; i < K; i++) { best[i] = px[i] + py[i] + pz[i]; bj[i] = 0; }
+    if (J < 0) {
+#else
+    if (!table_odd && __ballot(zbad) == 0ull) {
+#endif
+      // All inputs finite: no NaN can arise (an overflowing distance is +inf).  Strip bounds with
+      // lanes = spheres: rows of the first / last entry (pixel order inside a band).
+      const int v_lo = __builtin_amdgcn_readfirstlane((int)(ring[head & (kD2mCap - 1)].x >> 16));
+      const int v_hi = __builtin_amdgcn_readfirstlane((int)(ring[(head + count - 1) & (kD2mCap - 1)].x >> 16));
+      const float y_lo = axis_coord(ay, v_lo), y_hi = axis_coord(ay, v_hi);
+      // <= | ||p - c_j|| - r_j | for every point of the strip, up to the rounding the margins below cover
+      const float lb = fmaxf(fmaxf(y_lo - cj.y, cj.y - y_hi), 0.f) - cj.w;
+      unsigned long long m1 = __ballot(!(lb > 1e-3f)) & all;     // the sphere's y extent meets the strip (or nearly)
+      if (m1 == 0ull) m1 = all;
+#ifdef EXP_BRUTE
+      m1 = all;
+#endif
+#pragma unroll
+      for (int i = 0; i < K; i++) { best[i] = __builtin_inff(); bj[i] = 0; }
+      // stage 1, ascending j, strict '<': ties keep the first index (torch.min's convention).
+      // The NEXT sphere's record is requested before the current one is evaluated (explicit ds_read_b128 +
+      // s_waitcnt: left to itself hipcc reads the record at the top of the iteration and waits for it at once,
+      // one exposed LDS round trip per sphere).
+      {
+        unsigned long long m = m1;
+        int j = __builtin_ctzll(m);
+        f4 c = lds_request(j);
+        lds_arrived(c);
+        while (true) {
+          m &= m - 1;
+          const int jn = m ? __builtin_ctzll(m) : j;
+          f4 cn = lds_request(jn);
+          eval(make_float4(c.x, c.y, c.z, c.w), j, false);
+          lds_arrived(cn);
+          if (!m) break;
+          j = jn; c = cn;
+        }
+      }
+      // stage 2: what could still win or tie.  A point whose minimum stays above 50 is worth exactly 50
+      // with no gradient whatever the owner, so 50 caps the reach.
+      unsigned long long m2 = all & ~m1;
+#ifdef EXP_STAGE1ONLY
+      m2 = 0;
+#endif
+      if (m2) {
+        float wmax = -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < K; i++) wmax = fmaxf(wmax, valid[i] ? best[i] : -__builtin_inff());
+        const float reach = fminf(wave_minmax_all<false>(wmax), 50.f) * 1.00001f + 1e-3f;
+        m2 &= __ballot(!(lb * 0.99999f > reach));
+        if (m2) {
+          int j = __builtin_ctzll(m2);
+          f4 c = lds_request(j);
+          lds_arrived(c);
+          while (true) {
+            m2 &= m2 - 1;
+            const int jn = m2 ? __builtin_ctzll(m2) : j;
+            f4 cn = lds_request(jn);
+            eval(make_float4(c.x, c.y, c.z, c.w), j, true);
+            lds_arrived(cn);
+            if (!m2) break;
+            j = jn; c = cn;
+          }
+        }
+      }
+    }
+#ifdef EXP_NOSEARCH
+    else if (J < 0) {
+#else
+    else {
+#endif
+      // a NaN / infinity somewhere: every sphere in index order with torch.min's NaN rule
+      for (int j = 0; j < J; j++) {
+        const float4 c = s_c[j];
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+          const float dx = px[i] - c.x, dy = py[i] - c.y, dz = pz[i] - c.z;
+          const float a = fabsf(__builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) - c.w);
+          if (j == 0 || ((best[i] == best[i]) && (a < best[i] || a != a))) { best[i] = a; bj[i] = j; }
+        }
+      }
+    }
+    bool nan = false;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+      if (valid[i]) {
+        if (best[i] != best[i]) nan = true;           // torch.clamp keeps NaN: the crop's loss is NaN
+        else loss_fx += (long long)__float2int_rn(fminf(fmaxf(best[i], 0.f), 50.f) * kLossScale);
+      }
+    }
+    if (nan) s_nan = 1;
+    if (WANT_GRAD) {
+      int g[K][3];
+      bool live[K];
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        const float4 c = s_c[bj[i]];
+        const float dx = px[i] - c.x, dy = py[i] - c.y, dz = pz[i] - c.z;
+        const float t2 = (dx * dx + dy * dy) + dz * dz;
+        // the sign decides the gradient's direction: correctly rounded root, as a host sqrtf
+        const float dist = (t2 >= 0.01f && t2 <= 1e12f) ? sqrt_rn(t2) : __builtin_sqrtf(t2);
+        const float t = dist - c.w;
+        live[i] = valid[i] && best[i] <= 50.f && dist != 0.f && t != 0.f && dist < __builtin_inff();
+        const float k = (t > 0.f ? -kGradScale : kGradScale) * __builtin_amdgcn_rcpf(dist);
+        g[i][0] = live[i] ? __float2int_rn(k * dx) : 0;
+        g[i][1] = live[i] ? __float2int_rn(k * dy) : 0;
+        g[i][2] = live[i] ? __float2int_rn(k * dz) : 0;
+      }
+      // a lane's K points are neighbouring pixels: those sharing point 0's owner go with it
+#pragma unroll
+      for (int i = 1; i < K; i++) {
+        const bool same = live[i] && live[0] && bj[i] == bj[0];
+        g[0][0] += same ? g[i][0] : 0; g[0][1] += same ? g[i][1] : 0; g[0][2] += same ? g[i][2] : 0;
+        live[i] = live[i] && !same;
+      }
+#pragma unroll
+      for (int i = 0; i < K; i++) {
+        if (live[i]) {
+          unsigned long long *row = s_acc + bj[i] * 4;
+#ifdef EXP_NOATOMIC
+          s_acc[tid & 255] = (unsigned long long)(g[i][0] + g[i][1] + g[i][2]);
+          if (J < 0)
+#endif
+          {
+            atomicAdd(row + 0, (unsigned long long)(long long)g[i][0]);
+            atomicAdd(row + 1, (unsigned long long)(long long)g[i][1]);
+            atomicAdd(row + 2, (unsigned long long)(long long)g[i][2]);
+          }
+        }
+      }
+    }
+  };
+
+  // ---- this wave's units: three loads in flight, compact, search ------------------------------
+  auto load_unit = [&](const D2mUnitIter &it, float z[4]) {
+    z[0] = z[1] = z[2] = z[3] = 100.f;
+    if (it.done) return;
+    const int p = it.unit * 256 + lane * 4;
+    if (vec4) {
+      if (p < P) {
+        const float4 t = *reinterpret_cast<const float4 *>(dm + p);
+        z[0] = t.x; z[1] = t.y; z[2] = t.z; z[3] = t.w;
+      }
     } else {
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int v = v0 + g;
-        float4 t = make_float4(100.f, 100.f, 100.f, 100.f);
-        if (inside && v < H) {
-          const float *rowp = dm + (size_t)v * W + u0;
-          if (u0 + 0 < W) t.x = rowp[0];
-          if (u0 + 1 < W) t.y = rowp[1];
-          if (u0 + 2 < W) t.z = rowp[2];
-          if (u0 + 3 < W) t.w = rowp[3];
+      for (int c = 0; c < 4; c++)
+        if (p + c < P) z[c] = dm[p + c];
+    }
+  };
+  // the LOAD iterator draws the bands (it runs three units ahead and may be up to three bands ahead: the drawn
+  // bands wait in a 4-entry queue), the PROCESS iterator follows the same sequence
+  int q_put = 0, q_get = 0;
+  auto advance_load = [&](D2mUnitIter &it) {
+    if (it.done) return;
+    if (++it.unit >= it.unit_end) {
+      int b = 0;
+      if (lane == 0) b = atomicAdd(&s_next_band, 1);
+      b = __builtin_amdgcn_readfirstlane(b);
+      if (lane == 0) s_bandq[wave][q_put & 7] = b;
+      q_put++;
+      it.seek(b, nbands, band_units, units, parts, part);
+    }
+  };
+  auto advance_proc = [&](D2mUnitIter &it) {
+    if (it.done) return;
+    if (++it.unit >= it.unit_end) {
+      const int b = __builtin_amdgcn_readfirstlane(s_bandq[wave][q_get & 7]);
+      q_get++;
+      it.seek(b, nbands, band_units, units, parts, part);
+    }
+  };
+  D2mUnitIter itp, itl;
+  itp.seek(wave, nbands, band_units, units, parts, part);
+  itl = itp;
+#ifndef D2M_DEPTH
+#define D2M_DEPTH 2      // units in flight per wave (2: 55 us, 3: 59, 4: 58, 6: 69 for 1152 crops @128^2 -- registers)
+#endif
+  float zq[D2M_DEPTH][4];
+#pragma unroll
+  for (int d = 0; d < D2M_DEPTH; d++) { load_unit(itl, zq[d]); advance_load(itl); }
+  float (&z0)[4] = zq[0];
+  int head = 0, tail = 0;                         // ring positions (monotonic; masked on use)
+  while (!itp.done) {
+    const int p0 = itp.unit * 256 + lane * 4;
+    // foreground flags (mesh/render.py:138: background = d > 99), exclusive prefix in pixel order
+    bool fg[4];
+    int before = 0, total = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      fg[c] = (p0 + c < P) && !(z0[c] > 99.0f);
+      const unsigned long long m = __ballot(fg[c]);
+      before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, before));
+      total += __builtin_popcountll(m);
+    }
+    if (total) {
+      // `before` = flagged pixels of LOWER lanes over all four components: this lane's entries start there
+      // (a lane's four pixels are consecutive: pixel order)
+      int pos = tail + before;
+      int vc, uc;
+      if (wshift >= 0) { vc = p0 >> wshift; uc = p0 & (W - 1); }
+      else { vc = p0 / W; uc = p0 - vc * W; }
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        while (uc >= W) { uc -= W; vc++; }      // never taken when W % 4 == 0
+        if (fg[c]) {
+          ring[pos & (kD2mCap - 1)] = make_uint2(((unsigned)vc << 16) | (unsigned)uc, __float_as_uint(z0[c]));
+          pos++;
         }
-        z[4 * g] = t.x; z[4 * g + 1] = t.y; z[4 * g + 2] = t.z; z[4 * g + 3] = t.w;
+        uc++;
       }
+      tail += total;
+    }
+    const bool band_end = itp.unit + 1 >= itp.unit_end;
+    if (tail - head >= kD2mGroup || (band_end && tail > head)) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // full searches; at the end of a band also what is left (a search never spans two bands)
+      while (true) {
+        const int avail = tail - head;
+        const int take = avail >= kD2mGroup ? kD2mGroup : ((band_end && avail > 192) ? avail : 0);
+        if (!take) break;
+        search(std::integral_constant<int, 4>(), head, take);
+        head += take;
+      }
+      if (band_end && tail > head) {
+        if (tail - head > 128) search(std::integral_constant<int, 3>(), head, tail - head);
+        else if (tail - head > 64) search(std::integral_constant<int, 2>(), head, tail - head);
+        else search(std::integral_constant<int, 1>(), head, tail - head);
+        head = tail;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
-    for (int k = 0; k < kD2mPix; k++) {
-      const bool in = inside && (v0 + (k >> 2)) < H && (u0 + (k & 3)) < W;
-      const bool fg = in && !(z[k] > 99.0f);  // mesh/render.py:138 background = d > 99
-      fgmask |= (unsigned)fg << k;
-      cnt += fg;
-    }
-    // deterministic exclusive scan of cnt over the workgroup (queue order = thread order):
-    // 4 DPP steps inside each row of 16 lanes, then the row totals via SGPR broadcasts
-    int incl = cnt;
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);  // row_shr:1
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);  // row_shr:2
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);  // row_shr:4
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);  // row_shr:8
-    {
-      const int r0s = __builtin_amdgcn_readlane(incl, 15), r1s = __builtin_amdgcn_readlane(incl, 31);
-      const int r2s = __builtin_amdgcn_readlane(incl, 47);
-      const int row = lane >> 4;
-      incl += (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
-    }
-    if (tile > 0) __syncthreads();  // previous chunk's queue fully consumed
-    if (lane == 63) s_wave_cnt[wave] = incl;
-    __syncthreads();
-    int offset = incl - cnt, total_all = 0;
-    for (int w = 0; w < kD2mThreads / 64; w++) {
-      const int c = s_wave_cnt[w];
-      if (w < wave) offset += c;
-      total_all += c;
-    }
-    // a chunk with more foreground than the queue holds is consumed in several passes
-    for (int q0 = 0; q0 < total_all; q0 += kD2mQueue) {
-    const int total = min(kD2mQueue, total_all - q0);
-    if (q0 > 0) __syncthreads();
-    // ---- 2. compact ---------------------------------------------------------------------
-    {
-      int slot = offset - q0;
-      const float xg0 = axis_coord(ax, u0), xg1 = axis_coord(ax, u0 + 1), xg2 = axis_coord(ax, u0 + 2),
-                  xg3 = axis_coord(ax, u0 + 3);
+    for (int c = 0; c < 4; c++) {
 #pragma unroll
-      for (int k = 0; k < kD2mPix; k++) {
-        if ((fgmask >> k) & 1u) {
-          if (slot >= 0 && slot < kD2mQueue) {
-            QEntry e;
-            e.a = (k & 3) == 0 ? xg0 : ((k & 3) == 1 ? xg1 : ((k & 3) == 2 ? xg2 : xg3));
-            e.b = axis_coord(ay, v0 + (k >> 2));
-            e.c = z[k];
-            e.d = 0;
-            s_q[slot] = e;
-          }
-          ++slot;
-        }
-      }
+      for (int d = 0; d + 1 < D2M_DEPTH; d++) zq[d][c] = zq[d + 1][c];
     }
-    __syncthreads();
-    // ---- 3. nearest-surface search per foreground pixel ------------------------------
-    // A wave takes 64 consecutive queue entries (neighbouring pixels in scan order).  With
-    // lanes = spheres it bounds a_j = | ||p - c_j|| - r_j | from below over the points' bounding
-    // box (lb_j), then lanes = points visit the few spheres with the smallest lb_j first, after
-    // which the running minima are millimetres (the points lie on the model's surface) and
-    // only spheres whose lb_j is below the largest of them remain candidates (10-15 of 41).
-    // Bounds carry a rounding slack; a NaN anywhere disables the pruning.
-    {
-      const float4 cj = lane < J ? s_c[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int i0 = wave * 64; i0 < total; i0 += kD2mThreads) {
-        const int i = i0 + lane;
-        const bool act = i < total;
-        QEntry e = s_q[act ? i : i0];
-        const float inf = __builtin_inff();
-        // the points' bounding box: six wave minima (max = -min(-v)) in two transposed reductions
-        const float mxy = wave_min4_transposed(e.a, -e.a, e.b, -e.b, lane), mz = wave_min4_transposed(e.c, -e.c, e.c, -e.c, lane);
-        const float xlo = readlane_f(mxy, 12), xhi = -readlane_f(mxy, 13), ylo = readlane_f(mxy, 14), yhi = -readlane_f(mxy, 15);
-        const float zlo = readlane_f(mz, 12), zhi = -readlane_f(mz, 13);
-        // lanes = spheres: nearest / farthest distance from the centre to the box
-        const float nx = fmaxf(fmaxf(xlo - cj.x, cj.x - xhi), 0.f), fx = fmaxf(fabsf(xlo - cj.x), fabsf(xhi - cj.x));
-        const float ny = fmaxf(fmaxf(ylo - cj.y, cj.y - yhi), 0.f), fy = fmaxf(fabsf(ylo - cj.y), fabsf(yhi - cj.y));
-        const float nz = fmaxf(fmaxf(zlo - cj.z, cj.z - zhi), 0.f), fz = fmaxf(fabsf(zlo - cj.z), fabsf(zhi - cj.z));
-        const float dmin = __builtin_amdgcn_sqrtf((nx * nx + ny * ny) + nz * nz);
-        const float dmax = __builtin_amdgcn_sqrtf((fx * fx + fy * fy) + fz * fz);
-        const float lb = fmaxf(fmaxf(dmin - cj.w, cj.w - dmax), 0.f);
-        const bool odd = __ballot((e.a != e.a) || (e.b != e.b) || (e.c != e.c) ||
-                                  (lane < J && (lb != lb || cj.x != cj.x || cj.y != cj.y || cj.z != cj.z || cj.w != cj.w))) != 0ull;
-        float best = 0.f;
-        int bj = 0;
-        auto surface_distance = [&](int j) {   // lanes = points, sphere j's record through SGPRs
-          const float cx = readlane_f(cj.x, j), cy = readlane_f(cj.y, j), cz = readlane_f(cj.z, j);
-          const float cr = readlane_f(cj.w, j);
-          const float dx = e.a - cx, dy = e.b - cy, dz = e.c - cz;
-          const float dist = __builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz);  // <= 1 ulp: loss is continuous
-          return fabsf(dist - cr);
-        };
-        if (odd) {   // a NaN somewhere: every sphere, in index order (torch.min: NaN wins, ties keep first)
-          for (int j = 0; j < J; j++) {
-            const float a = surface_distance(j);
-            if (j == 0 || ((best == best) && (a < best || a != a))) { best = a; bj = j; }
-          }
-        } else {
-          // Two stages.  (1) Best first: visit the kD2mSeeds unvisited spheres with the smallest
-          // lower bounds; the largest of the 64 running minima (`reach`) is then small, the
-          // points lie on the model's surface.  (2) No sphere whose lower bound (discounted
-          // for rounding) exceeds `reach` can reach, or tie, any point's minimum: the others
-          // are visited in a plain loop.
-          float rem = lane < J ? lb * 0.99999f - 1e-3f : inf;
-          best = inf;
-          for (int it = 0; it < kD2mSeeds; it++) {
-            const float m = wave_minmax_all<true>(rem);
-            if (m == inf) break;
-            const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(__ballot(rem == m)));
-            if (lane == j) rem = inf;
-            const float a = surface_distance(j);
-            if (a < best || (a == best && j < bj)) { best = a; bj = j; }   // ties keep the first index
-          }
-          // (one wave maximum after the seeds, not one per seed: a seed that could not have improved
-          // anything costs one evaluation, a wave reduction costs as much)
-          const float reach = wave_minmax_all<false>(act ? best : -inf) * 1.00001f + 1e-3f;
-          unsigned long long cand = __ballot(rem <= reach && rem != inf);
-          while (cand) {
-            const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(cand));
-            cand &= cand - 1;
-            const float a = surface_distance(j);
-            if (a < best || (a == best && j < bj)) { best = a; bj = j; }
-          }
-        }
-        if (act) loss += (best != best) ? best : fminf(fmaxf(best, 0.f), 50.f);   // torch.clamp keeps NaN
-        if (WANT_GRAD) {
-          float gx = 0.f, gy = 0.f, gz = 0.f;
-          int owner = -1;
-          if (act) {
-            const float4 c = s_c[bj];
-            const float dx = e.a - c.x, dy = e.b - c.y, dz = e.c - c.z;
-            const float dist = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);
-            const float t = dist - c.w;
-            const float sgn = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
-            const bool live = (best <= 50.f) && (dist != 0.f) && (sgn != 0.f);
-            const float k = live ? -(sgn / dist) : 0.f;
-            gx = k * dx; gy = k * dy; gz = k * dz;
-            owner = live ? bj : -1;
-          }
-          // the 64 neighbouring points have 2-4 distinct owners: one DPP wave sum per owner
-          // into this wave's private LDS row (fixed order: deterministic)
-          unsigned long long todo = __ballot(owner >= 0);
-          while (todo) {
-            const int j = __builtin_amdgcn_readlane(owner, __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo)));
-            const bool mine = owner == j;
-            todo &= ~__ballot(mine);
-            // (three sums in one transposed reduction; ds_add_f32 into the wave's own slot)
-            const float t = wave_sum4_transposed(mine ? gx : 0.f, mine ? gy : 0.f, mine ? gz : 0.f, 0.f, lane);
-            if (lane >= 60 && lane < 63)
-              atomicAdd(reinterpret_cast<float *>(s_part + wave * SHR_MAX_SPHERES + j) + (lane & 3), t);
-          }
-        }
-      }
-    }
-    }  // passes
+    load_unit(itl, zq[D2M_DEPTH - 1]); advance_load(itl);
+    advance_proc(itp);
   }
 
-  // ---- reductions ---------------------------------------------------------------------------
-  loss = wave_sum_lane63(loss);
-  if (lane == 63) s_wave_loss[wave] = loss;
+  // ---- combine ----------------------------------------------------------------------------------
+  if (loss_fx) atomicAdd(&s_loss, (unsigned long long)loss_fx);
   __syncthreads();
-  if (tid == 0) {
-    float t = 0.f;
-    for (int w = 0; w < kD2mThreads / 64; w++) t += s_wave_loss[w];
-    loss_sum[n] = t;
-  }
-  if (WANT_GRAD && tid < J) {   // combine the waves' partials in wave order
-    float gx = 0.f, gy = 0.f, gz = 0.f;
-    for (int w = 0; w < kD2mThreads / 64; w++) {
-      const float4 a = s_part[w * SHR_MAX_SPHERES + tid];
-      gx += a.x; gy += a.y; gz += a.z;
-    }
-    float *o = grad_centres + ((size_t)n * J + tid) * 3;
-    o[0] = gx; o[1] = gy; o[2] = gz;
+  if (tid == 0)
+    loss_sum[blockIdx.x] = s_nan ? __builtin_nanf("") : (float)((double)(long long)s_loss * (1.0 / (double)kLossScale));
+  if (WANT_GRAD && tid < J * 3) {
+    const int j = tid / 3, c = tid - j * 3;
+    grad_centres[(size_t)blockIdx.x * J * 3 + tid] = (float)((double)(long long)s_acc[j * 4 + c] * (1.0 / (double)kGradScale));
   }
 }
 
 }  // namespace shr
 
 namespace {
-int launch_d2m(const float *depth, const int32_t *depth_index, const float *centres, const float *radii, int N, int J,
-               int H, int W, float *loss_sum, float *grad_centres, void *stream) {
+int g_d2m_waves = 0;   // 0 = by batch size (SHR_TUNE_D2M_WAVES)
+int g_d2m_band = 0;    // 0 = by crop size (SHR_TUNE_D2M_BAND_UNITS)
+
+template <bool WANT_GRAD>
+void launch_d2m_waves(int waves, const float *depth, const int32_t *depth_index, const float *centres,
+                      const float *radii, int N, int J, int H, int W, int band_units, int parts, float *loss_sum,
+                      float *grad_centres, hipStream_t s) {
   using namespace shr;
+  const dim3 grid((unsigned)(N * parts));
+  if (waves >= 16)
+    hipLaunchKernelGGL((data_to_model_kernel<WANT_GRAD, 16>), grid, dim3(1024), 0, s, depth, depth_index, centres, radii,
+                       J, H, W, band_units, parts, loss_sum, grad_centres);
+  else if (waves >= 8)
+    hipLaunchKernelGGL((data_to_model_kernel<WANT_GRAD, 8>), grid, dim3(512), 0, s, depth, depth_index, centres, radii,
+                       J, H, W, band_units, parts, loss_sum, grad_centres);
+  else
+    hipLaunchKernelGGL((data_to_model_kernel<WANT_GRAD, 4>), grid, dim3(256), 0, s, depth, depth_index, centres, radii,
+                       J, H, W, band_units, parts, loss_sum, grad_centres);
+}
+
+int launch_d2m(const float *depth, const int32_t *depth_index, const float *centres, const float *radii, int N, int J,
+               int H, int W, int parts, float *loss_sum, float *grad_centres, void *stream) {
   if (N == 0) return SHR_OK;
   if (!depth || !centres || !radii || !loss_sum || N < 0 || J <= 0 || H <= 0 || W <= 0) return SHR_EINVAL;
-  if (J > SHR_MAX_SPHERES || (long long)H * W > (1LL << 30)) return SHR_ETOOLARGE;
+  if (parts != 1 && parts != 2 && parts != 4) return SHR_EINVAL;
+  // ring entries pack (v, u) into 16 bits each
+  if (J > SHR_MAX_SPHERES || (long long)H * W > (1LL << 30) || H > 65535 || W > 65535 ||
+      (long long)N * parts > 0x7fffffffLL)
+    return SHR_ETOOLARGE;
   hipStream_t s = (hipStream_t)stream;
+  // waves per workgroup: enough waves in flight to fill 256 CUs x 4 SIMDs whatever the batch size
+  const long long wgs = (long long)N * parts;
+  const int waves = g_d2m_waves ? g_d2m_waves : (wgs >= 1024 ? 4 : (wgs >= 384 ? 8 : 16));
+  // bands of consecutive units, handed out dynamically: small enough to balance the waves, large enough that the
+  // remainder search at the end of every band stays a small share (measured best: 2 units at 128 x 128 with four
+  // waves, 4-8 at 256 x 256)
+  const int units = (int)(((long long)H * W + 255) >> 8);
+  int band_units = units / (8 * waves * parts);
+  if (band_units > 8) band_units = 8;
+  if (g_d2m_band) band_units = g_d2m_band;
+  if (band_units < 1) band_units = 1;
   if (grad_centres)
-    hipLaunchKernelGGL(data_to_model_kernel<true>, dim3((unsigned)N), dim3(kD2mThreads), 0, s, depth, depth_index,
-                       centres, radii, J, H, W, loss_sum, grad_centres);
+    launch_d2m_waves<true>(waves, depth, depth_index, centres, radii, N, J, H, W, band_units, parts, loss_sum,
+                           grad_centres, s);
   else
-    hipLaunchKernelGGL(data_to_model_kernel<false>, dim3((unsigned)N), dim3(kD2mThreads), 0, s, depth, depth_index,
-                       centres, radii, J, H, W, loss_sum, grad_centres);
+    launch_d2m_waves<false>(waves, depth, depth_index, centres, radii, N, J, H, W, band_units, parts, loss_sum,
+                            grad_centres, s);
   return (int)hipGetLastError();
 }
 }  // namespace
 
+// launch-shape hooks behind shr_set_tuning (results never depend on them: the sums are integers)
+int shr::d2m_set_waves(int waves) {
+  if (waves != 0 && waves != 4 && waves != 8 && waves != 16) return SHR_EINVAL;
+  g_d2m_waves = waves;
+  return SHR_OK;
+}
+int shr::d2m_set_band_units(int units) {
+  if (units < 0 || units > 4096) return SHR_EINVAL;
+  g_d2m_band = units;
+  return SHR_OK;
+}
+
 extern "C" int shr_data_to_model(const float *depth, const float *centres, const float *radii, int N, int J, int H,
                                  int W, float *loss_sum, float *grad_centres, void *stream) {
-  return launch_d2m(depth, nullptr, centres, radii, N, J, H, W, loss_sum, grad_centres, stream);
+  return launch_d2m(depth, nullptr, centres, radii, N, J, H, W, 1, loss_sum, grad_centres, stream);
 }
 
 extern "C" int shr_data_to_model_indexed(const float *depth, const int32_t *depth_index, const float *centres,
                                          const float *radii, int N, int J, int H, int W, float *loss_sum,
                                          float *grad_centres, void *stream) {
   if (!depth_index && N > 0) return SHR_EINVAL;
-  return launch_d2m(depth, depth_index, centres, radii, N, J, H, W, loss_sum, grad_centres, stream);
+  return launch_d2m(depth, depth_index, centres, radii, N, J, H, W, 1, loss_sum, grad_centres, stream);
+}
+
+// Large crops are split over several workgroups (on different CUs): the kernel then writes `parts` partial
+// results per crop and the caller adds them (fixed order: deterministic).
+extern "C" int shr_data_to_model_parts(int N, int H, int W) {
+  (void)N;
+  return (long long)H * W >= 192LL * 192LL ? 2 : 1;
+}
+
+extern "C" int shr_data_to_model_partial(const float *depth, const int32_t *depth_index, const float *centres,
+                                         const float *radii, int N, int J, int H, int W, int parts,
+                                         float *loss_parts, float *grad_parts, void *stream) {
+  return launch_d2m(depth, depth_index, centres, radii, N, J, H, W, parts, loss_parts, grad_parts, stream);
 }

@@ -111,6 +111,8 @@ extern "C" int shr_set_tuning(int key, int value) {
       if (value < 1 || value > 16) return SHR_EINVAL;
       g_tune.fwd_waves = value;
       return SHR_OK;
+    case SHR_TUNE_D2M_WAVES: return d2m_set_waves(value);
+    case SHR_TUNE_D2M_BAND_UNITS: return d2m_set_band_units(value);
     case SHR_TUNE_FWD_SHARES:
     case SHR_TUNE_BWD_SHARES: {
       // four bytes, oldest group first; normalised to sum 256 with every group >= 1

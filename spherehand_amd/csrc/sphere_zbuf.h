@@ -73,16 +73,6 @@ __device__ __forceinline__ float key_depth(uint32_t k) {
 // residuals of its two neighbours -- the same correction hipcc's sqrtf() applies,
 // without its denormal-scaling prologue.  Checked against sqrtf() on every fp32
 // value in [0.01, 1e12] (tests/test_sphere_raster_gpu.py::test_sqrt_rn_exhaustive).
-__device__ __forceinline__ float sqrt_rn(float x) {
-  const float s = __builtin_amdgcn_sqrtf(x);
-  const float dn = __uint_as_float(__float_as_uint(s) - 1u);
-  const float up = __uint_as_float(__float_as_uint(s) + 1u);
-  const float e_dn = __builtin_fmaf(-dn, s, x);
-  const float e_up = __builtin_fmaf(-up, s, x);
-  float r = (e_dn <= 0.0f) ? dn : s;
-  r = (e_up > 0.0f) ? up : r;
-  return r;
-}
 
 __device__ __forceinline__ bool sphere_is_tame(const float4 s) {
   return fabsf(s.x) < 1e6f && fabsf(s.y) < 1e6f && fabsf(s.w) < 1e6f;  // false for NaN/Inf

@@ -84,7 +84,7 @@ def sphere_raster_bwd(spheres, grad_depth, argmin=None):
 
 
 TUNE_FWD_LDS_BYTES, TUNE_FWD_OWNER_LDS_BYTES, TUNE_BWD_LDS_BYTES, TUNE_FORCE_GENERAL, TUNE_FWD_WAVES = 1, 2, 3, 4, 5
-TUNE_FWD_SHARES, TUNE_BWD_SHARES = 6, 7
+TUNE_FWD_SHARES, TUNE_BWD_SHARES, TUNE_D2M_WAVES, TUNE_D2M_BAND_UNITS = 6, 7, 8, 9
 
 
 def set_tuning(key, value):
@@ -116,7 +116,9 @@ class SphereDepthRaster(torch.autograd.Function):
 def _check_index(index, n, m, name):
     if index.dtype != torch.int32 or index.dim() != 1 or index.numel() != n or not index.is_cuda or not index.is_contiguous():
         raise RuntimeError("%s must be a contiguous int32 CUDA tensor with one entry per crop" % name)
-    # (values are image numbers in [0, %d): the caller builds them, they are not read back here)
+    # PRECONDITION (not checked here -- reading the values back would synchronise the stream): every entry is an
+    # image number in [0, m).  The kernels index the image stack with it unchecked; MutualProjectionLoss builds
+    # and caches its index tensors once per (B, V, device), in range by construction.
 
 
 def sphere_raster_mse_supported(spheres, target, H, W):
@@ -195,17 +197,21 @@ def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
     J = centres.shape[1]
     if radii.numel() != J:
         raise RuntimeError("radii must have J entries")
+    if depth_index is not None:
+        _check_index(depth_index, N, depth.shape[0], "depth_index")
+    lib = _lib.lib()
+    R = lib.shr_data_to_model_parts(N, int(H), int(W))     # large crops: R partial results per crop, added here
     with _on(depth.device):
-        loss_sum = torch.empty(N, dtype=torch.float32, device=depth.device)
-        grad = torch.empty((N, J, 3), dtype=torch.float32, device=depth.device) if want_grad else None
-        if depth_index is None:
-            _lib.check(_lib.lib().shr_data_to_model(_ptr(depth), _ptr(centres), _ptr(radii), N, J, H, W,
-                                                    _ptr(loss_sum), _ptr(grad), _stream()), "shr_data_to_model")
+        loss_sum = torch.empty((N, R), dtype=torch.float32, device=depth.device)
+        grad = torch.empty((N, R, J, 3), dtype=torch.float32, device=depth.device) if want_grad else None
+        _lib.check(lib.shr_data_to_model_partial(_ptr(depth), _ptr(depth_index), _ptr(centres), _ptr(radii), N, J, H, W, R,
+                                                 _ptr(loss_sum), _ptr(grad), _stream()), "shr_data_to_model_partial")
+        if R > 1:
+            loss_sum = loss_sum.sum(1)
+            grad = grad.sum(1) if want_grad else None
         else:
-            _check_index(depth_index, N, depth.shape[0], "depth_index")
-            _lib.check(_lib.lib().shr_data_to_model_indexed(_ptr(depth), _ptr(depth_index), _ptr(centres), _ptr(radii),
-                                                            N, J, H, W, _ptr(loss_sum), _ptr(grad), _stream()),
-                       "shr_data_to_model_indexed")
+            loss_sum = loss_sum.view(N)
+            grad = grad.view(N, J, 3) if want_grad else None
     return (loss_sum, grad) if want_grad else loss_sum
 
 
