@@ -15,8 +15,15 @@ scaling, no data-path collective -- crops are independent); value =
 crops of all ranks / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 (the driver's contract), with
-  roofline      the dominant kernel's algorithmic HBM bytes / its mean launch
-                duration (HIP events on the launching stream) vs the 8 TB/s peak
+  roofline      the dominant kernel's algorithmic HBM bytes / its MEAN launch
+                duration (HIP events on the launching stream) vs the 8 TB/s peak;
+                `large_batch` repeats it at 1152 and 9216 crops per launch (more
+                crops than CUs), which separates the launch floor of a 256-crop
+                launch from what the kernels sustain;
+  secondary     (N=1) the other kernels of the path at the sizes DESIGN.md quotes,
+                each with its own roofline fraction: config 5's per-GPU multiview
+                loss, the triangle path, the fused render-and-compare, a hipGraph
+                replay of the headline step, the reference-sized training step;
   cpu_baseline  the CPU oracle (oracle/, a port of the reference algorithm)
                 timed on this host on the same batch, rank 0, N=1 only.
 """
@@ -129,6 +136,193 @@ def timed_steps(step, steps, warmup, dist, device):
     return elapsed
 
 
+def mean_launch_us(fn, stream, reps=200, batches=5, warm=20):
+    """MEAN duration of one launch of fn(stream_handle): HIP events on the launching stream around `batches`
+    runs of `reps` back-to-back launches (all of them averaged: what rocprofv3's AverageNs reports)."""
+    sh = stream.cuda_stream
+    for _ in range(warm):
+        fn(sh)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    total = 0.0
+    for _ in range(batches):
+        e0.record(stream)
+        for _ in range(reps):
+            fn(sh)
+        e1.record(stream)
+        e1.synchronize()
+        total += e0.elapsed_time(e1) * 1e3
+    return total / (reps * batches)
+
+
+def roof(bytes_per_launch, us):
+    gbs = bytes_per_launch / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch)}
+
+
+def large_batch(lib, _lib, dev, stream):
+    """The headline kernels at more crops than CUs (1152 = config 5's per-GPU share, 9216 = its node-wide count):
+    us per launch, us per 256 crops, roofline fraction on the same algorithmic bytes per crop."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.joint_angle import sample_poses
+    from spherehand_amd.kinematicsTransformation import HandTransformationMat
+    from spherehand_amd.render import HandBallPrimitiveRender
+    mesh = hand_model.load_mesh()
+    fk = HandTransformationMat([b["offset_matrix"].astype("float32") for b in mesh["bones"]]).to(dev)
+    hbr = HandBallPrimitiveRender(mesh["bones"], S, S).to(dev)
+    out = {}
+    for n in (1152, 9216):
+        with torch.no_grad():
+            sph = hbr.spheres(fk(sample_poses(n, seed=7).to(dev))).contiguous()
+        depth = torch.empty(n, S, S, device=dev)
+        owner = torch.empty(n, S, S, device=dev, dtype=torch.uint8)
+        grad = torch.randn(n, S, S, device=dev)
+        gs = torch.empty(n, J, 4, device=dev)
+        p = [t.data_ptr() for t in (sph, depth, owner, grad, gs)]
+        reps = 40 if n == 1152 else 8
+        f = mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_fwd(p[0], n, J, S, S, p[1], p[2], s), "fwd"),
+                           stream, reps, 3, 3)
+        b = mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_bwd(p[0], p[3], p[2], n, J, S, S, p[4], s), "bwd"),
+                           stream, reps, 3, 3)
+        bf, bb = n * (4 * S * S + S * S + 16 * J), n * (4 * S * S + S * S + 32 * J)
+        out[str(n)] = {"fwd_us": round(f, 2), "bwd_us": round(b, 2), "fwd_us_per_256": round(f * 256 / n, 3),
+                       "bwd_us_per_256": round(b * 256 / n, 3), "fwd_frac": roof(bf, f)["frac"],
+                       "bwd_frac": roof(bb, b)["frac"], "crops_per_s_fwd_bwd": round(n / ((f + b) * 1e-6), 1)}
+        del sph, depth, owner, grad, gs
+    return out
+
+
+def secondary(lib, _lib, dev, stream, graph_step_us):
+    """The other kernels of the path (rank 0, N=1), inputs resident in HBM, HIP events on the launching stream.
+    Algorithmic bytes per crop are DESIGN.md section 4's (what must cross HBM once)."""
+    import numpy as np
+    from types import SimpleNamespace
+    import depth_rasterization
+    from spherehand_amd import hand_model, ops
+    from spherehand_amd.datasets import SyntheticMultiviewDataset
+    from spherehand_amd.joint_angle import sample_poses
+    from spherehand_amd.kinematicsTransformation import HandTransformationMat
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    from spherehand_amd.render import DepthRender
+    mesh = hand_model.load_mesh()
+    sec = {"headline_step_graph_replay_us": round(graph_step_us, 3)}
+
+    def torch_us(fn, reps, batches=3, warm=3):       # torch-launched work on the current (= launching) stream
+        return mean_launch_us(lambda _s: fn(), stream, reps, batches, warm)
+
+    # ---- BASELINE config 5, per-GPU share: 128 samples x 3 x 3 view pairs = 1152 crops @256x256 ----------
+    B5, S5 = 128, 256
+    ds = SyntheticMultiviewDataset(mesh, B5, S5, seed=0, device=dev)
+    crit = MutualProjectionLoss(S5, mesh).to(dev)
+    real, cam, inv = ds.dms.to(dev), ds.cam.to(dev), ds.inv_cam.to(dev)
+    joints = (ds.joints.to(dev) + torch.randn(ds.joints.shape, device=dev)).requires_grad_(True)
+
+    def mv_step():
+        joints.grad = None
+        loss, _ = crit(cam, inv, joints, real, True)
+        loss.backward()
+    n5 = B5 * 9
+    t_mv = torch_us(mv_step, 10)
+    with torch.no_grad():
+        _, pts = crit.mutual_projection(cam, inv, joints.detach())
+    obs = real.view(B5 * 3, S5, S5).contiguous()
+    index = (torch.arange(B5, device=dev, dtype=torch.int32).view(B5, 1, 1) * 3 +
+             torch.arange(3, device=dev, dtype=torch.int32).view(1, 1, 3)).expand(B5, 3, 3).reshape(-1).contiguous()
+    cen = pts.squeeze(-1).reshape(n5, J, 3).contiguous()
+    rad = crit.data_to_model_criterion.radiuses.view(-1).contiguous()
+    sph = torch.cat([cen, rad.view(1, J, 1).expand(n5, J, 1)], -1).contiguous()
+    R = lib.shr_data_to_model_parts(n5, S5, S5)
+    ls = torch.empty(n5 * R, device=dev); gr = torch.empty(n5 * R, J, 3, device=dev)
+    a = [t.data_ptr() for t in (obs, index, cen, rad, ls, gr)]
+    t_d2m = mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_partial(a[0], a[1], a[2], a[3], n5, J, S5, S5, R,
+                                                                               a[4], a[5], s), "d2m"), stream, 20, 3, 3)
+    Rm = lib.shr_sphere_raster_mse_regions(S5, S5)
+    dep = torch.empty(n5, S5, S5, device=dev); sse = torch.empty(n5 * Rm, device=dev)
+    gsp = torch.empty(n5 * Rm, J, 4, device=dev)
+    m = [t.data_ptr() for t in (sph, obs, index, dep, sse, gsp)]
+    t_mse = mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_mse(m[0], n5, J, S5, S5, m[1], m[2], m[3], m[4],
+                                                                           m[5], s), "mse"), stream, 20, 3, 3)
+    sec["config5_per_gpu_1152_crops_256x256"] = {
+        "mutual_projection_loss_fwd_bwd_us": round(t_mv, 1),
+        "crops_per_s": round(n5 / (t_mv * 1e-6), 1),
+        # data->model: every pair reads its observed image once (4 S^2) + the 41 records
+        "data_to_model_kernel": dict(us=round(t_d2m, 1), workgroups_per_crop=R, **roof(n5 * (4 * S5 * S5 + 16 * J), t_d2m)),
+        # fused render-and-compare: reads the observed image, writes the projection (returned by the loss)
+        "sphere_zbuf_mse_kernel": dict(us=round(t_mse, 1), **roof(n5 * (8 * S5 * S5 + 32 * J), t_mse)),
+    }
+    del ds, crit, real, obs, dep, gsp, gr
+
+    # the same two kernels at 128x128 (1152 crops)
+    ds = SyntheticMultiviewDataset(mesh, B5, S, seed=0, device=dev)
+    crit = MutualProjectionLoss(S, mesh).to(dev)
+    with torch.no_grad():
+        _, pts = crit.mutual_projection(ds.cam.to(dev), ds.inv_cam.to(dev), ds.joints.to(dev) + 1.0)
+    obs = ds.dms.to(dev).view(B5 * 3, S, S).contiguous()
+    cen = pts.squeeze(-1).reshape(n5, J, 3).contiguous()
+    R = lib.shr_data_to_model_parts(n5, S, S)
+    ls = torch.empty(n5 * R, device=dev); gr = torch.empty(n5 * R, J, 3, device=dev)
+    a = [t.data_ptr() for t in (obs, index, cen, rad, ls, gr)]
+    t_d2m = mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_partial(a[0], a[1], a[2], a[3], n5, J, S, S, R,
+                                                                               a[4], a[5], s), "d2m"), stream, 40, 3, 3)
+    sec["data_to_model_kernel_1152_crops_128x128"] = dict(us=round(t_d2m, 1), **roof(n5 * (4 * S * S + 16 * J), t_d2m))
+    del ds, crit, obs
+
+    # ---- fused render-and-compare at the headline batch (256 crops @128x128, with the depth output) -------
+    spheres, _ = make_inputs(0, dev)
+    tgt = torch.full((BATCH, S, S), 100.0, device=dev); tgt[:, 32:96, 32:96] = 0.0
+    dep = torch.empty(BATCH, S, S, device=dev); sse = torch.empty(BATCH, device=dev); gsp = torch.empty(BATCH, J, 4, device=dev)
+    m = [t.data_ptr() for t in (spheres, tgt, dep, sse, gsp)]
+    t = mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_mse(m[0], BATCH, J, S, S, m[1], None, m[2], m[3], m[4], s),
+                                            "mse"), stream, 200, 3, 20)
+    sec["fused_render_and_compare_256_crops_128x128"] = dict(us=round(t, 2), **roof(BATCH * (8 * S * S + 32 * J), t))
+
+    # ---- triangle path: DepthRender (skinning + fused raster/clamp/resize) and the literal 640x640 drop-in ----
+    fkm = HandTransformationMat([b["offset_matrix"].astype("float32") for b in mesh["bones"]]).to(dev)
+    dr = DepthRender(mesh, S).to(dev)
+    with torch.no_grad():
+        T = fkm(sample_poses(BATCH, seed=1).to(dev))
+        verts = dr.lbs(T, dr.camera, None).contiguous()
+        fv = verts[:, dr.rasterizer.faces, 0:3].reshape(BATCH, -1, 3, 3).contiguous()
+    nv, nf = verts.shape[1], dr.rasterizer.num_faces
+    with torch.no_grad():
+        t_dr = torch_us(lambda: dr(T), 20)
+    outd = torch.empty(BATCH, S, S, device=dev)
+    v = [verts.data_ptr(), dr.rasterizer.faces_i32.data_ptr(), outd.data_ptr()]
+    t_md = mean_launch_us(lambda s: _lib.check(lib.shr_mesh_depth_fwd(v[0], v[1], BATCH, nv, nf, 640, S, 100.0, v[2], s),
+                                               "mesh_depth"), stream, 20, 3, 3)
+    # SURVEY 8d: vertices (16 NV B) + shared indices + the S x S output per crop
+    sec["depth_render_256_crops_128x128"] = {"module_us": round(t_dr, 1),
+                                             "mesh_depth_kernel": dict(us=round(t_md, 1), **roof(BATCH * (16 * nv + 4 * S * S) + 12 * nf, t_md))}
+    raw = torch.empty(BATCH, 640, 640, device=dev)
+    r = [fv.data_ptr(), raw.data_ptr()]
+    t_tri = mean_launch_us(lambda s: _lib.check(lib.shr_tri_raster_fwd(r[0], BATCH, nf, 640, 640, r[1], s), "tri"),
+                           stream, 5, 3, 2)
+    sec["depth_rasterization_forward_640x640_256_crops"] = dict(us=round(t_tri, 1), **roof(BATCH * (36 * nf + 4 * 640 * 640), t_tri))
+    del raw, fv
+
+    # ---- reference-sized training step: 25 x 3 real + 48 synthetic crops @64x64, every loss term on ------------
+    import tempfile
+    from spherehand_amd.engine import Engine
+    o = SimpleNamespace(synthesize=True, mv_projection=True, mv_consistency=True, temporal=False, prior=False,
+                        collision=True, bone_length=True, mode="Train", model_dir=tempfile.mkdtemp(), initial_model=None,
+                        restore_from_model=None, restore_from_epoch=-1, num_stacks=1, epoch=3, dataset_dir=None,
+                        depth_resample=0, lr=1e-3, tag="b", image_size=64, log_every=10 ** 9, real_batch=25, synt_batch=48)
+    ds = SyntheticMultiviewDataset(mesh, 50, 64, seed=0, device=dev)
+    eng = Engine(o, mesh=mesh, real_train_dataset=ds, real_eval_dataset=ds, device=dev)
+    eng.network.train()
+    realb = [torch.stack([ds[i][k] for i in range(25)]) for k in range(4)]
+    pose = sample_poses(48, seed=1)
+    for _ in range(8):
+        eng.step(realb, pose, True, True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        eng.step(realb, pose, True, True)
+    torch.cuda.synchronize(dev)
+    sec["training_step_25x3_real_48_synt_64x64_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
+    return sec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +331,7 @@ def main():
     ap.add_argument("--launch", choices=["direct", "graph"], default="direct",
                     help="direct: two C-ABI calls per step; graph: one hipGraph replay per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the large-batch and secondary measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -195,28 +390,24 @@ def main():
 
         elapsed = timed_steps(step, args.steps, args.warmup, dist, dev)
 
-        # per-kernel mean launch duration: HIP events on the launching stream
-        # around R back-to-back launches of one kernel
-        def kernel_us(fn, reps=200):
-            for _ in range(20):
-                fn(sh)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            best = None
-            for _ in range(5):
-                e0.record(stream)
-                for _ in range(reps):
-                    fn(sh)
-                e1.record(stream)
-                e1.synchronize()
-                us = e0.elapsed_time(e1) * 1e3 / reps
-                best = us if best is None else min(best, us)
-            return best
+        def kernel_us(fn, reps=200, batches=5, warm=20):
+            return mean_launch_us(fn, stream, reps, batches, warm)
         fwd_us = kernel_us(fwd)
         bwd_us = kernel_us(bwd)
         # context for the roofline: what ONE plain fill launch of the depth output (16.8 of the
         # forward's 21.1 MB, no arithmetic, same stream) takes at this batch size -- the practical
         # ceiling of any kernel that has to write a 256-crop batch per launch
         fill_us = kernel_us(lambda _s: depth.fill_(100.0))
+        big = sec = None
+        if rank == 0 and world == 1 and not args.no_secondary:
+            # one hipGraph replay of the headline step (forward + backward as one graph launch)
+            g2 = torch.cuda.CUDAGraph()
+            fwd(sh); bwd(sh); stream.synchronize()
+            with torch.cuda.graph(g2, stream=stream):
+                fwd(sh); bwd(sh)
+            graph_us = mean_launch_us(lambda _s: g2.replay(), stream, 200, 3, 20)
+            big = large_batch(lib, _lib, dev, stream)
+            sec = secondary(lib, _lib, dev, stream, graph_us)
 
     if rank == 0:
         # algorithmic bytes ("u8 argmin saved" variant: 165 808 B/crop fwd+bwd @128):
@@ -251,8 +442,14 @@ def main():
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes,
                          "launch_us": {"fwd": round(fwd_us, 3), "bwd": round(bwd_us, 3)},
+                         "launch_us_is": "mean of 1000 back-to-back launches (HIP events)",
+                         "frac_fwd": roof(bytes_fwd, fwd_us)["frac"], "frac_bwd": roof(bytes_bwd, bwd_us)["frac"],
                          "plain_fill_of_the_depth_output_us": round(fill_us, 3)},
         }
+        if big is not None:
+            out["roofline"]["large_batch"] = big
+        if sec is not None:
+            out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spheres.cpu().numpy(), grad.cpu().numpy())
         print(json.dumps(out), flush=True)

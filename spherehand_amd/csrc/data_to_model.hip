@@ -33,7 +33,7 @@
 //   * the loss and the gradient are accumulated as FIXED-POINT integers (2^-20 mm / 2^-26 per
 //     unit-vector component; 64-bit LDS atomics on one table per workgroup, a lane's four points
 //     combined first when they share their owner): integer sums do not depend on their order, so
-//     the result is bit-reproducible AND independent of the launch shape, without any per-owner
+//     the result is bit-reproducible AND (one workgroup per crop) independent of the launch shape, without any per-owner
 //     wave reduction (the round-1 ballot loop over distinct owners was a third of the kernel).
 // A non-finite sphere record or depth value sends the search through the exact index-order loop
 // (torch.min / clamp propagate NaN).  HBM: reads 4*H*W + 12*J + 4*J bytes per crop.
