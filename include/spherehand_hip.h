@@ -154,6 +154,20 @@ int shr_pair_losses(const float *joints, long long sample_stride, int M, int J, 
                     float *coll_sum, float *bone_lo_sum, float *bone_hi_sum,
                     float *grad_coll, float *grad_bone_lo, float *grad_bone_hi, void *stream);
 
+/* MultiviewConsistencyLoss (mesh/multiview_utility.py:138-167, hm_weight = None) with its gradient: cam [B,V,4,4]
+ * (canonical = R joint + t, t in COLUMN 3), joints [B,V,J,3], V <= 8.  loss_sum[b] = sum over views, joints and
+ * coordinates of (canonical - median over the views)^2 with torch.median's lower median; grad_joints [B,V,J,3]
+ * (may be NULL) = d loss_sum[b] / d joints, the median's gradient routed to the view it was taken from.  The
+ * caller applies MSELoss's 1/(B*V*J*3) and the weight. */
+int shr_mv_consistency(const float *cam, const float *joints, int B, int V, int J, float *loss_sum,
+                       float *grad_joints, void *stream);
+
+/* DepthResample.forward (network/util_modules.py:10-43) on N scaled depth crops: pixels whose uniform[N][H][W]
+ * draw exceeds sample_ratio become 1.0, then the module's fixed 3x3 or 5x5 Gaussian with zero padding
+ * (out must not alias depth). */
+int shr_depth_resample(const float *depth, const float *uniform, int N, int H, int W, float sample_ratio,
+                       int kernel_size, float *out, void *stream);
+
 /* Soft-argmax read-out of the network's heat-maps (network/util_modules.py:164-201), forward and
  * backward: hm[N][2J][h][w] fp32 with element (n, c, y, x) at n*stride_n + c*stride_c + (y*w + x)*stride_px
  * (NCHW: stride_c = h*w, stride_px = 1; channels-last: stride_c = 1, stride_px = 2J).  Channels 0..J-1 are
@@ -192,14 +206,18 @@ int shr_depth_noise(const float *depth, const float *normal3, int B, int H, int 
  * shr_group_norm_relu_supported: C % 32 == 0 and C/G in
  * {4, 8, 16, 32}; buffers 16-byte aligned. */
 int shr_group_norm_relu_supported(int C, int G);
-int shr_group_norm_relu_fwd(const float *x, const float *gamma, const float *beta,
+/* pre_bias [C] (may be NULL): the bias of the convolution that produced x, added on the fly (y = relu(GN(x +
+ * pre_bias))): the convolution then runs without its bias-add pass and the backward returns that bias's
+ * gradient (dpre [C], per-sample partials dpre_partial [N][C]; both NULL when pre_bias is) with dx, instead of
+ * a separate reduction over dx. */
+int shr_group_norm_relu_fwd(const float *x, const float *pre_bias, const float *gamma, const float *beta,
                             int N, int C, int HW, int G, float eps,
                             float *y, float *mean, float *rstd, void *stream);
-int shr_group_norm_relu_bwd(const float *x, const float *dy, const float *gamma,
+int shr_group_norm_relu_bwd(const float *x, const float *pre_bias, const float *dy, const float *gamma,
                             const float *beta, const float *mean, const float *rstd,
                             int N, int C, int HW, int G, float *dx,
-                            float *dgamma_partial, float *dbeta_partial,
-                            float *dgamma, float *dbeta, void *stream);
+                            float *dgamma_partial, float *dbeta_partial, float *dpre_partial,
+                            float *dgamma, float *dbeta, float *dpre, void *stream);
 
 
 /* View-to-view projection of the sphere centres ---------------------------------

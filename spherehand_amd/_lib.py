@@ -15,7 +15,7 @@ import torch  # noqa: F401  (device memory, streams: the plumbing this library s
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libspherehand_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -35,6 +35,8 @@ SIGNATURES = {
     "shr_data_to_model_partial": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "shr_sphere_raster_mse_regions": ([_i, _i], _i),
     "shr_pair_losses": ([_vp, ctypes.c_longlong, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "shr_mv_consistency": ([_vp, _vp, _i, _i, _i, _vp, _vp, _vp], _i),
+    "shr_depth_resample": ([_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp], _i),
     "shr_soft_argmax_supported": ([_i, _i, _i], _i),
     "shr_soft_argmax_fwd": ([_vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _i, _i, _i, _i, _f, _f, _f, _f, _f,
                              _vp, _vp], _i),
@@ -43,8 +45,8 @@ SIGNATURES = {
     "shr_heatmap_paint": ([_vp, _i, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp], _i),
     "shr_depth_noise": ([_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp], _i),
     "shr_group_norm_relu_supported": ([_i, _i], _i),
-    "shr_group_norm_relu_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp], _i),
-    "shr_group_norm_relu_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "shr_group_norm_relu_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp], _i),
+    "shr_group_norm_relu_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "shr_sphere_raster_mse": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "shr_mutual_project_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "shr_mutual_project_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),

@@ -54,7 +54,8 @@ __device__ __forceinline__ float4 gn_channel_total(float4 v, float4 (*s_w4)[8], 
 }
 
 __global__ void __launch_bounds__(kGnThreads)
-group_norm_relu_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+group_norm_relu_fwd_kernel(const float *__restrict__ x, const float *__restrict__ pre_bias,
+                           const float *__restrict__ gamma, const float *__restrict__ beta,
                            int C, int HW, int G, float eps, float *__restrict__ y, float *__restrict__ mean_out,
                            float *__restrict__ rstd_out) {
   __shared__ float s_w[4][8];
@@ -67,16 +68,21 @@ group_norm_relu_fwd_kernel(const float *__restrict__ x, const float *__restrict_
   float4 *ys = reinterpret_cast<float4 *>(y + (size_t)n * HW * C + c);
   const int stride4 = C >> 2;                    // float4 per pixel
   const float inv_m = 1.0f / (float)(cpg * HW);
+  // the producing convolution's bias, added on the fly (x' = x + pre_bias[c]): the convolution then runs without
+  // its bias-add kernel, and the backward returns the bias gradient with dx (no separate reduction)
+  const float4 pb = pre_bias ? *reinterpret_cast<const float4 *>(pre_bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 
   float s = 0.f;
   for (int p = p0; p < HW; p += 32) {
-    const float4 v = xs[(size_t)p * stride4];
+    float4 v = xs[(size_t)p * stride4];
+    v.x += pb.x; v.y += pb.y; v.z += pb.z; v.w += pb.w;
     s += (v.x + v.y) + (v.z + v.w);
   }
   const float mean = gn_group_total(s, cpg, s_w, wave, lane) * inv_m;
   float q = 0.f;
   for (int p = p0; p < HW; p += 32) {
-    const float4 v = xs[(size_t)p * stride4];
+    float4 v = xs[(size_t)p * stride4];
+    v.x += pb.x; v.y += pb.y; v.z += pb.z; v.w += pb.w;
     const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
     q += (a * a + b * b) + (cc * cc + d * d);
   }
@@ -86,7 +92,8 @@ group_norm_relu_fwd_kernel(const float *__restrict__ x, const float *__restrict_
   const float4 ga = *reinterpret_cast<const float4 *>(gamma + c), be = *reinterpret_cast<const float4 *>(beta + c);
   const float4 sc = make_float4(ga.x * rstd, ga.y * rstd, ga.z * rstd, ga.w * rstd);
   for (int p = p0; p < HW; p += 32) {
-    const float4 v = xs[(size_t)p * stride4];
+    float4 v = xs[(size_t)p * stride4];
+    v.x += pb.x; v.y += pb.y; v.z += pb.z; v.w += pb.w;
     float4 o;
     o.x = fmaxf((v.x - mean) * sc.x + be.x, 0.f);
     o.y = fmaxf((v.y - mean) * sc.y + be.y, 0.f);
@@ -100,10 +107,12 @@ group_norm_relu_fwd_kernel(const float *__restrict__ x, const float *__restrict_
 // s1 = sum_group dy' * gamma, s2 = sum_group dy' * gamma * xhat; per-sample partials of
 // dgamma = sum dy' * xhat and dbeta = sum dy' (the caller sums them over the samples).
 __global__ void __launch_bounds__(kGnThreads)
-group_norm_relu_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gamma,
+group_norm_relu_bwd_kernel(const float *__restrict__ x, const float *__restrict__ pre_bias,
+                           const float *__restrict__ dy, const float *__restrict__ gamma,
                            const float *__restrict__ beta, const float *__restrict__ mean_in,
                            const float *__restrict__ rstd_in, int C, int HW, int G, float *__restrict__ dx,
-                           float *__restrict__ dgamma_part, float *__restrict__ dbeta_part) {
+                           float *__restrict__ dgamma_part, float *__restrict__ dbeta_part,
+                           float *__restrict__ dpre_part) {
   __shared__ float4 s_w4[4][8];
   const int n = blockIdx.y, c0 = blockIdx.x * kGnBlockC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -117,10 +126,13 @@ group_norm_relu_bwd_kernel(const float *__restrict__ x, const float *__restrict_
   const int stride4 = C >> 2;
   const float mean = mean_in[(size_t)n * G + g], rstd = rstd_in[(size_t)n * G + g];
   const float4 ga = *reinterpret_cast<const float4 *>(gamma + c), be = *reinterpret_cast<const float4 *>(beta + c);
+  const float4 pb = pre_bias ? *reinterpret_cast<const float4 *>(pre_bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 
   float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int p = p0; p < HW; p += 32) {
-    const float4 v = xs[(size_t)p * stride4], d = ds[(size_t)p * stride4];
+    float4 v = xs[(size_t)p * stride4];
+    const float4 d = ds[(size_t)p * stride4];
+    v.x += pb.x; v.y += pb.y; v.z += pb.z; v.w += pb.w;
     const float h0 = (v.x - mean) * rstd, h1 = (v.y - mean) * rstd, h2 = (v.z - mean) * rstd, h3 = (v.w - mean) * rstd;
     const float d0 = (h0 * ga.x + be.x > 0.f) ? d.x : 0.f, d1 = (h1 * ga.y + be.y > 0.f) ? d.y : 0.f;
     const float d2 = (h2 * ga.z + be.z > 0.f) ? d.z : 0.f, d3 = (h3 * ga.w + be.w > 0.f) ? d.w : 0.f;
@@ -141,8 +153,11 @@ group_norm_relu_bwd_kernel(const float *__restrict__ x, const float *__restrict_
   if (cpg >= 32) { t1 += __shfl_xor(t1, 4); t2 += __shfl_xor(t2, 4); }
   const float inv_m = 1.0f / (float)(cpg * HW);
   const float m1 = t1 * inv_m, m2 = t2 * inv_m;
+  float4 so = make_float4(0.f, 0.f, 0.f, 0.f);     // sum of dx per channel = the producing convolution's bias gradient
   for (int p = p0; p < HW; p += 32) {
-    const float4 v = xs[(size_t)p * stride4], d = ds[(size_t)p * stride4];
+    float4 v = xs[(size_t)p * stride4];
+    const float4 d = ds[(size_t)p * stride4];
+    v.x += pb.x; v.y += pb.y; v.z += pb.z; v.w += pb.w;
     const float h0 = (v.x - mean) * rstd, h1 = (v.y - mean) * rstd, h2 = (v.z - mean) * rstd, h3 = (v.w - mean) * rstd;
     const float d0 = (h0 * ga.x + be.x > 0.f) ? d.x : 0.f, d1 = (h1 * ga.y + be.y > 0.f) ? d.y : 0.f;
     const float d2 = (h2 * ga.z + be.z > 0.f) ? d.z : 0.f, d3 = (h3 * ga.w + be.w > 0.f) ? d.w : 0.f;
@@ -152,6 +167,11 @@ group_norm_relu_bwd_kernel(const float *__restrict__ x, const float *__restrict_
     o.z = rstd * (d2 * ga.z - (m1 + h2 * m2));
     o.w = rstd * (d3 * ga.w - (m1 + h3 * m2));
     os[(size_t)p * stride4] = o;
+    so.x += o.x; so.y += o.y; so.z += o.z; so.w += o.w;
+  }
+  if (dpre_part) {                                   // (uniform)
+    const float4 D = gn_channel_total(so, s_w4, wave, lane);
+    if (tid < 8) *reinterpret_cast<float4 *>(dpre_part + (size_t)n * C + c) = D;
   }
 }
 
@@ -159,25 +179,31 @@ group_norm_relu_bwd_kernel(const float *__restrict__ x, const float *__restrict_
 // workgroup: lane s sums the samples n = s (mod 8), the eight partial sums are added in order:
 // deterministic.
 __global__ void __launch_bounds__(256)
-group_norm_param_grad_kernel(const float *__restrict__ dg_part, const float *__restrict__ db_part, int N, int C,
-                             float *__restrict__ dgamma, float *__restrict__ dbeta) {
-  __shared__ float s_a[8][32], s_b[8][32];
+group_norm_param_grad_kernel(const float *__restrict__ dg_part, const float *__restrict__ db_part,
+                             const float *__restrict__ dp_part, int N, int C,
+                             float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dpre) {
+  __shared__ float s_a[8][32], s_b[8][32], s_p[8][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
-  float a = 0.f, b = 0.f;
+  float a = 0.f, b = 0.f, q = 0.f;
   if (c < C) {
 #pragma unroll 4
-    for (int n = sl; n < N; n += 8) { a += dg_part[(size_t)n * C + c]; b += db_part[(size_t)n * C + c]; }
+    for (int n = sl; n < N; n += 8) {
+      a += dg_part[(size_t)n * C + c]; b += db_part[(size_t)n * C + c];
+      if (dp_part) q += dp_part[(size_t)n * C + c];
+    }
   }
   s_a[sl][cl] = a;
   s_b[sl][cl] = b;
+  s_p[sl][cl] = q;
   __syncthreads();
   if (sl == 0 && c < C) {
-    float ta = 0.f, tb = 0.f;
+    float ta = 0.f, tb = 0.f, tp = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; k++) { ta += s_a[k][cl]; tb += s_b[k][cl]; }
+    for (int k = 0; k < 8; k++) { ta += s_a[k][cl]; tb += s_b[k][cl]; tp += s_p[k][cl]; }
     dgamma[c] = ta;
     dbeta[c] = tb;
+    if (dpre) dpre[c] = tp;
   }
 }
 
@@ -191,35 +217,40 @@ bool gn_supported(int C, int G) {
 
 extern "C" int shr_group_norm_relu_supported(int C, int G) { return shr::gn_supported(C, G) ? 1 : 0; }
 
-extern "C" int shr_group_norm_relu_fwd(const float *x, const float *gamma, const float *beta, int N, int C, int HW, int G,
-                                       float eps, float *y, float *mean, float *rstd, void *stream) {
+extern "C" int shr_group_norm_relu_fwd(const float *x, const float *pre_bias, const float *gamma, const float *beta, int N,
+                                       int C, int HW, int G, float eps, float *y, float *mean, float *rstd,
+                                       void *stream) {
   using namespace shr;
   if (N == 0) return SHR_OK;
   if (!x || !gamma || !beta || !y || !mean || !rstd || N < 0 || HW <= 0) return SHR_EINVAL;
-  if (!gn_supported(C, G) || ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta)) & 15u)) return SHR_EINVAL;
+  if (!gn_supported(C, G) ||
+      ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)pre_bias)) & 15u))
+    return SHR_EINVAL;
   if (N > 65535) return SHR_ETOOLARGE;
   hipLaunchKernelGGL(group_norm_relu_fwd_kernel, dim3((unsigned)(C / kGnBlockC), (unsigned)N), dim3(kGnThreads), 0,
-                     (hipStream_t)stream, x, gamma, beta, C, HW, G, eps, y, mean, rstd);
+                     (hipStream_t)stream, x, pre_bias, gamma, beta, C, HW, G, eps, y, mean, rstd);
   return (int)hipGetLastError();
 }
 
-extern "C" int shr_group_norm_relu_bwd(const float *x, const float *dy, const float *gamma, const float *beta,
-                                       const float *mean, const float *rstd, int N, int C, int HW, int G, float *dx,
-                                       float *dgamma_partial, float *dbeta_partial, float *dgamma, float *dbeta,
-                                       void *stream) {
+extern "C" int shr_group_norm_relu_bwd(const float *x, const float *pre_bias, const float *dy, const float *gamma,
+                                       const float *beta, const float *mean, const float *rstd, int N, int C, int HW,
+                                       int G, float *dx, float *dgamma_partial, float *dbeta_partial,
+                                       float *dpre_partial, float *dgamma, float *dbeta, float *dpre, void *stream) {
   using namespace shr;
   if (N == 0) return SHR_OK;
   if (!x || !dy || !gamma || !beta || !mean || !rstd || !dx || !dgamma_partial || !dbeta_partial || N < 0 || HW <= 0)
     return SHR_EINVAL;
   if (!gn_supported(C, G) ||
       ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)dgamma_partial |
-         (uintptr_t)dbeta_partial)) & 15u))
+         (uintptr_t)dbeta_partial | (uintptr_t)pre_bias | (uintptr_t)dpre_partial)) & 15u))
     return SHR_EINVAL;
+  if ((pre_bias != nullptr) != (dpre_partial != nullptr)) return SHR_EINVAL;
   if (N > 65535) return SHR_ETOOLARGE;
   hipLaunchKernelGGL(group_norm_relu_bwd_kernel, dim3((unsigned)(C / kGnBlockC), (unsigned)N), dim3(kGnThreads), 0,
-                     (hipStream_t)stream, x, dy, gamma, beta, mean, rstd, C, HW, G, dx, dgamma_partial, dbeta_partial);
+                     (hipStream_t)stream, x, pre_bias, dy, gamma, beta, mean, rstd, C, HW, G, dx, dgamma_partial,
+                     dbeta_partial, dpre_partial);
   if (dgamma && dbeta)
     hipLaunchKernelGGL(group_norm_param_grad_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
-                       dgamma_partial, dbeta_partial, N, C, dgamma, dbeta);
+                       dgamma_partial, dbeta_partial, dpre_partial, N, C, dgamma, dbeta, dpre);
   return (int)hipGetLastError();
 }

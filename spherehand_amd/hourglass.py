@@ -10,7 +10,7 @@ stem + stacks) so that its checkpoints (`network_state_dict` with keys
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import group_norm_relu
+from .ops import conv_then_group_norm_relu, group_norm_relu
 
 
 class Bottleneck(nn.Module):
@@ -28,9 +28,12 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        y = self.conv1(group_norm_relu(x, self.bn1))        # NHWC GroupNorm+ReLU kernel on the GPU path
-        y = self.conv2(group_norm_relu(y, self.bn2))
-        y = self.conv3(group_norm_relu(y, self.bn3))
+        # NHWC GroupNorm+ReLU kernels on the GPU path; conv1's / conv2's bias rides in the kernel that normalises
+        # their output (no bias-add pass, the bias gradient comes back with dx)
+        y = group_norm_relu(x, self.bn1)
+        y = conv_then_group_norm_relu(y, self.conv1, self.bn2)
+        y = conv_then_group_norm_relu(y, self.conv2, self.bn3)
+        y = self.conv3(y)
         return y + (x if self.downsample is None else self.downsample(x))
 
 
@@ -95,12 +98,12 @@ class HourglassNet(nn.Module):
         """x [N,S,S] or [N,1,S,S] -> ([scores [N,num_outputs,S/4,S/4]] per stack, [latent] per stack)."""
         if x.dim() == 3:
             x = x.unsqueeze(1)
-        x = self.layer1(group_norm_relu(self.conv1(x), self.bn1))
+        x = self.layer1(conv_then_group_norm_relu(x, self.conv1, self.bn1))
         x = self.layer3(self.layer2(F.max_pool2d(x, 2, stride=2)))
         out, latents = [], []
         for i in range(self.num_stacks):
             y, latent = self.hg[i](x)
-            y = group_norm_relu(self.fc[i][0](self.res[i](y)), self.fc[i][1])   # fc = Conv-GN-ReLU (keys unchanged)
+            y = conv_then_group_norm_relu(self.res[i](y), self.fc[i][0], self.fc[i][1])   # fc = Conv-GN-ReLU (keys unchanged)
             score = self.score[i](y)
             out.append(score)
             latents.append(latent)

@@ -133,6 +133,8 @@ class MultiviewConsistencyLoss(nn.Module):
         self.loss_func = nn.MSELoss()
 
     def forward(self, camera_poses, joints, hm_weight=None):
+        if hm_weight is None and ops.mv_consistency_supported(camera_poses, joints):
+            return ops.MultiviewConsistency.apply(camera_poses, joints)      # one launch per direction
         R = camera_poses[:, :, None, 0:3, 0:3]
         t = camera_poses[:, :, None, 0:3, 3].unsqueeze(-1)
         canonical = torch.matmul(R, joints.unsqueeze(-1)) + t                  # [B,V,J,3,1]

@@ -376,48 +376,70 @@ def group_norm_relu_supported(x, num_groups):
 
 
 class GroupNormReLU(torch.autograd.Function):
-    """relu(group_norm(x, G, weight, bias, eps)) on channels-last activations
-    (network/hourglass.py:28-31), one kernel per direction."""
+    """relu(group_norm(x + pre_bias, G, weight, bias, eps)) on channels-last activations
+    (network/hourglass.py:28-31), one kernel per direction.  `pre_bias` [C] (optional) is the bias of the
+    convolution that produced x: the convolution is then run WITHOUT its bias, and this op's backward returns
+    the bias gradient with dx (two launches and one reduction less per convolution)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, num_groups, eps):
+    def forward(ctx, x, weight, bias, num_groups, eps, pre_bias=None):
         N, C, H, W = x.shape
         weight, bias = weight.contiguous(), bias.contiguous()
+        pre = None if pre_bias is None else pre_bias.contiguous()
         with _on(x.device):
             y = torch.empty_like(x, memory_format=torch.channels_last)
             mean = torch.empty((N, num_groups), dtype=torch.float32, device=x.device)
             rstd = torch.empty((N, num_groups), dtype=torch.float32, device=x.device)
-            _lib.check(_lib.lib().shr_group_norm_relu_fwd(_ptr(x), _ptr(weight), _ptr(bias), N, C, H * W, num_groups,
-                                                          float(eps), _ptr(y), _ptr(mean), _ptr(rstd), _stream()),
-                       "shr_group_norm_relu_fwd")
-        ctx.save_for_backward(x, weight, bias, mean, rstd)
+            _lib.check(_lib.lib().shr_group_norm_relu_fwd(_ptr(x), _ptr(pre), _ptr(weight), _ptr(bias), N, C, H * W,
+                                                          num_groups, float(eps), _ptr(y), _ptr(mean), _ptr(rstd),
+                                                          _stream()), "shr_group_norm_relu_fwd")
+        ctx.save_for_backward(x, weight, bias, mean, rstd, pre)
         ctx.num_groups = num_groups
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, bias, mean, rstd = ctx.saved_tensors
+        x, weight, bias, mean, rstd, pre = ctx.saved_tensors
         N, C, H, W = x.shape
         dy = dy.contiguous(memory_format=torch.channels_last)
+        k = 2 if pre is None else 3
         with _on(x.device):
             dx = torch.empty_like(x, memory_format=torch.channels_last)
-            part = torch.empty((2, N, C), dtype=torch.float32, device=x.device)     # per-sample partials (workspace)
-            dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
-            _lib.check(_lib.lib().shr_group_norm_relu_bwd(_ptr(x), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(mean),
-                                                          _ptr(rstd), N, C, H * W, ctx.num_groups, _ptr(dx),
-                                                          _ptr(part[0]), _ptr(part[1]), _ptr(dgb[0]), _ptr(dgb[1]),
+            part = torch.empty((k, N, C), dtype=torch.float32, device=x.device)     # per-sample partials (workspace)
+            dgb = torch.empty((k, C), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().shr_group_norm_relu_bwd(_ptr(x), _ptr(pre), _ptr(dy), _ptr(weight), _ptr(bias),
+                                                          _ptr(mean), _ptr(rstd), N, C, H * W, ctx.num_groups, _ptr(dx),
+                                                          _ptr(part[0]), _ptr(part[1]),
+                                                          _ptr(part[2]) if pre is not None else None,
+                                                          _ptr(dgb[0]), _ptr(dgb[1]),
+                                                          _ptr(dgb[2]) if pre is not None else None,
                                                           _stream()), "shr_group_norm_relu_bwd")
-        return dx, dgb[0], dgb[1], None, None
+        return dx, dgb[0], dgb[1], None, None, (dgb[2] if pre is not None else None)
 
 
 FUSED_GROUP_NORM_RELU = True    # False: always torch's group_norm + relu (A/B measurements)
 
 
-def group_norm_relu(x, gn):
-    """F.relu(gn(x)) for an nn.GroupNorm `gn`: the NHWC kernels when they apply, torch otherwise."""
+def group_norm_relu(x, gn, pre_bias=None):
+    """F.relu(gn(x + pre_bias)) for an nn.GroupNorm `gn`: the NHWC kernels when they apply, torch otherwise."""
     if FUSED_GROUP_NORM_RELU and gn.affine and group_norm_relu_supported(x, gn.num_groups):
-        return GroupNormReLU.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps)
+        return GroupNormReLU.apply(x, gn.weight, gn.bias, gn.num_groups, gn.eps, pre_bias)
+    if pre_bias is not None:
+        x = x + pre_bias.view(1, -1, 1, 1)
     return torch.nn.functional.relu(gn(x))
+
+
+def conv_then_group_norm_relu(x, conv, gn):
+    """relu(gn(conv(x))) with the convolution's bias folded into the normalisation kernel when that kernel will
+    take conv's output (NHWC fp32 on the GPU, supported channel counts): conv runs bias-free."""
+    if (FUSED_GROUP_NORM_RELU and gn.affine and conv.bias is not None and x.is_cuda and x.dtype == torch.float32
+            and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and bool(_lib.lib().shr_group_norm_relu_supported(int(conv.out_channels), int(gn.num_groups)))):
+        y = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if group_norm_relu_supported(y, gn.num_groups):
+            return GroupNormReLU.apply(y, gn.weight, gn.bias, gn.num_groups, gn.eps, conv.bias)
+        return torch.nn.functional.relu(gn(y + conv.bias.view(1, -1, 1, 1)))
+    return group_norm_relu(conv(x), gn)
 
 
 def heatmap_paint(uvd, S, sigma, inv_k, uv_scale=1.0, d_scale=1.0):
@@ -525,3 +547,51 @@ class PairLosses(torch.autograd.Function):
             full[:, :J] = g
             g = full
         return g, None, None, None, None, None, None, None, None
+
+
+class MultiviewConsistency(torch.autograd.Function):
+    """(camera_poses [B,V,4,4], joints [B,V,J,3]) -> MSELoss(median over the views, canonical points): the
+    reference's MultiviewConsistencyLoss without heat-map weights (mesh/multiview_utility.py:138-167), one launch;
+    the backward only scales the unit gradient the kernel already produced."""
+
+    @staticmethod
+    def forward(ctx, camera_poses, joints):
+        cam = camera_poses.detach().contiguous().float()
+        joints = joints.contiguous().float()
+        _check_input(cam, "camera_poses")
+        _check_input(joints, "joints")
+        B, V, J = joints.shape[0], joints.shape[1], joints.shape[2]
+        if cam.shape != (B, V, 4, 4) or joints.dim() != 4 or joints.shape[3] != 3:
+            raise RuntimeError("expected camera_poses [B,V,4,4] and joints [B,V,J,3]")
+        want = ctx.needs_input_grad[1]
+        with _on(joints.device):
+            sums = torch.empty(B, dtype=torch.float32, device=joints.device)
+            grad = torch.empty((B, V, J, 3), dtype=torch.float32, device=joints.device) if want else None
+            _lib.check(_lib.lib().shr_mv_consistency(_ptr(cam), _ptr(joints), B, V, J, _ptr(sums), _ptr(grad), _stream()),
+                       "shr_mv_consistency")
+        if want:
+            ctx.save_for_backward(grad)
+        ctx.count = float(B * V * J * 3)
+        return sums.sum() / ctx.count
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return None, grad * (g / ctx.count)
+
+
+def mv_consistency_supported(camera_poses, joints):
+    return (joints.is_cuda and camera_poses.is_cuda and joints.dim() == 4 and joints.shape[-1] == 3
+            and joints.shape[1] <= 8 and joints.shape[2] <= 64 and joints.dtype == torch.float32)
+
+
+def depth_resample(depth, sample_ratio, kernel_size, generator=None):
+    """DepthResample on [N,H,W] scaled depth: one torch.rand + one launch -> [N,1,H,W]."""
+    _check_input(depth, "depth")
+    N, H, W = depth.shape
+    with _on(depth.device):
+        uniform = torch.rand((N, H, W), dtype=torch.float32, device=depth.device, generator=generator)
+        out = torch.empty((N, 1, H, W), dtype=torch.float32, device=depth.device)
+        _lib.check(_lib.lib().shr_depth_resample(_ptr(depth), _ptr(uniform), N, H, W, float(sample_ratio),
+                                                 int(kernel_size), _ptr(out), _stream()), "shr_depth_resample")
+    return out

@@ -100,6 +100,10 @@ class DepthResample(nn.Module):
     def forward(self, dm):
         if dm.ndimension() == 3:
             dm = dm.unsqueeze(1)
+        if dm.is_cuda and dm.dtype == torch.float32 and dm.shape[1] == 1 and not (torch.is_grad_enabled() and dm.requires_grad):
+            # one torch.rand + one launch (drop-out and the fixed Gaussian fused; same draws -> same result)
+            return ops.depth_resample(dm.reshape(dm.shape[0], dm.shape[2], dm.shape[3]).contiguous(), self.sample_ratio,
+                                      self.gaussian_filter.kernel_size[0])
         dm = torch.where(torch.rand_like(dm) > self.sample_ratio, torch.ones_like(dm), dm)
         return self.gaussian_filter(dm)
 

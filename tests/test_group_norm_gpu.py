@@ -101,3 +101,53 @@ def test_soft_argmax_sharply_peaked_maps_keep_their_gradient_precision():
         assert err <= 4e-5 * max(1.0, hd.grad.abs().max().item()) + 4 * err_t, (N, J, S, err, err_t)
         worst = max(worst, err / max(1.0, hd.grad.abs().max().item()))
     assert worst < 2e-4
+
+
+@pytest.mark.parametrize("N,Cin,C,H,W,G,k", [(5, 32, 64, 16, 16, 16, 1), (3, 64, 128, 8, 8, 16, 3), (4, 1, 64, 32, 32, 4, 5)])
+def test_conv_bias_folded_into_group_norm_relu(N, Cin, C, H, W, G, k):
+    """relu(gn(conv(x))) with the convolution's bias folded into the normalisation kernel (forward: x + bias on the
+    fly; backward: the bias gradient = per-channel sum of dx, returned by the same kernel) against the plain
+    torch composition in fp64: outputs, dx, and the gradients of the conv weight, conv BIAS, gamma and beta."""
+    from spherehand_amd import ops
+    g = torch.Generator().manual_seed(N + C + k)
+    conv = torch.nn.Conv2d(Cin, C, k, padding=k // 2).cuda().to(memory_format=torch.channels_last)
+    gn = torch.nn.GroupNorm(G, C).cuda()
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(C, generator=g) * 2)
+        gn.weight.copy_(torch.randn(C, generator=g)); gn.bias.copy_(torch.randn(C, generator=g) * 0.5)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda().to(memory_format=torch.channels_last).requires_grad_(True)
+    up = torch.randn(N, C, H, W, generator=g).cuda().to(memory_format=torch.channels_last)
+    y = ops.conv_then_group_norm_relu(x, conv, gn)
+    (y * up).sum().backward()
+    got = [y.detach(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone(), gn.weight.grad.clone(),
+           gn.bias.grad.clone()]
+    cd, gd = torch.nn.Conv2d(Cin, C, k, padding=k // 2).cuda().double(), torch.nn.GroupNorm(G, C).cuda().double()
+    cd.load_state_dict({n_: v.double() for n_, v in conv.state_dict().items()})
+    gd.load_state_dict({n_: v.double() for n_, v in gn.state_dict().items()})
+    xd = x.detach().double().contiguous().requires_grad_(True)
+    yr = torch.relu(gd(cd(xd)))
+    (yr * up.double()).sum().backward()
+    ref = [yr.detach(), xd.grad, cd.weight.grad, cd.bias.grad, gd.weight.grad, gd.bias.grad]
+    for a, b, tol, name in zip(got, ref, (5e-6, 5e-5, 5e-5, 5e-5, 5e-5, 5e-5), ("y", "dx", "dW", "dbias", "dgamma", "dbeta")):
+        assert (a.double() - b).abs().max().item() <= tol * max(1.0, b.abs().max().item()), name
+
+
+def test_hourglass_gradients_with_and_without_the_fused_kernels():
+    """The whole network, backward included: fused GroupNorm+ReLU (+ folded conv biases) vs torch ops only, on the GPU."""
+    from spherehand_amd import ops
+    from spherehand_amd.hourglass import create_hourglass_network
+    torch.manual_seed(1)
+    net = create_hourglass_network(82, 1).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(6, 1, 64, 64).cuda().to(memory_format=torch.channels_last)
+    grads = []
+    for fused in (True, False):
+        ops.FUSED_GROUP_NORM_RELU = fused
+        net.zero_grad(set_to_none=True)
+        out, _ = net(x)
+        out[0].square().mean().backward()
+        grads.append({k: p.grad.clone() for k, p in net.named_parameters()})
+    ops.FUSED_GROUP_NORM_RELU = True
+    gmax = max(v.abs().max().item() for v in grads[1].values())
+    for k in grads[1]:
+        assert (grads[0][k] - grads[1][k]).abs().max().item() <= 2e-4 * gmax + 1e-7, k
+    assert any(k.endswith("conv1.bias") for k in grads[0])

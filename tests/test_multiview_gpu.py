@@ -222,3 +222,62 @@ def test_fused_render_and_compare_sphere_counts(J):
     g_ref = ops.sphere_raster_bwd(spd, (2 * e).contiguous(), owner)
     assert (sse.double() - (e.double() ** 2).sum((1, 2))).abs().max().item() <= 2e-5 * sse.abs().max().item()
     assert (grad - g_ref).abs().max().item() <= 2e-5 * g_ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("V", [3, 4, 2, 5])
+def test_mv_consistency_kernel_matches_the_torch_formulation(V):
+    """MultiviewConsistencyLoss (mesh/multiview_utility.py:138-167): the one-launch kernel (value + gradient routed
+    through torch.median's selected view) against the torch ops it replaces; the value itself is pinned to the
+    reference by g7's 'mv_consistency' term (test_engine_gpu.py)."""
+    from spherehand_amd import ops
+    from spherehand_amd.datasets import random_rotations
+    from spherehand_amd.multiview_utility import MultiviewConsistencyLoss
+    g = torch.Generator().manual_seed(V)
+    B, J = 7, 41
+    cam = torch.eye(4).repeat(B, V, 1, 1)
+    cam[:, :, :3, :3] = random_rotations(B * V, 40.0, g).view(B, V, 3, 3)
+    cam[:, :, :3, 3] = torch.randn(B, V, 3, generator=g) * 5
+    joints = torch.randn(B, V, J, 3, generator=g) * 40
+    joints[0, :, 3] = joints[0, 0:1, 3]                     # nearly tied canonical points exercise the rank rule
+    cam, joints = cam.cuda(), joints.cuda()
+
+    def torch_loss(cam, joints):
+        R = cam[:, :, None, 0:3, 0:3]
+        t = cam[:, :, None, 0:3, 3].unsqueeze(-1)
+        canonical = torch.matmul(R, joints.unsqueeze(-1)) + t
+        med, _ = torch.median(canonical, dim=1)
+        return torch.nn.functional.mse_loss(med.unsqueeze(1).expand_as(canonical), canonical)
+
+    a = joints.clone().requires_grad_(True)
+    la = MultiviewConsistencyLoss()(cam, a)
+    (la * 3.0).backward()
+    b = joints.clone().requires_grad_(True)
+    lb = torch_loss(cam, b)
+    (lb * 3.0).backward()
+    assert ops.mv_consistency_supported(cam, a)
+    assert abs(la.item() - lb.item()) <= 1e-5 * abs(lb.item())
+    assert (a.grad - b.grad).abs().max().item() <= 1e-5 * b.grad.abs().max().item() + 1e-7
+    # no-grad forward gives the same value
+    with torch.no_grad():
+        assert MultiviewConsistencyLoss()(cam, joints).item() == la.item()
+
+
+@pytest.mark.parametrize("ksize", [3, 5])
+def test_depth_resample_kernel_matches_the_module_ops(ksize):
+    """DepthResample (network/util_modules.py:10-43): drop-out to 1.0 + the fixed Gaussian in one launch, against
+    torch.where + the module's nn.Conv2d fed the same uniform draws."""
+    from spherehand_amd import ops
+    from spherehand_amd.util_modules import DepthResample
+    mod = DepthResample(0.95, ksize).cuda()
+    dm = (torch.rand(5, 48, 40, device="cuda") * 1.2).contiguous()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    out = ops.depth_resample(dm, 0.95, ksize, generator=g)
+    g.manual_seed(3)
+    u = torch.rand((5, 48, 40), device="cuda", generator=g)
+    x = torch.where(u > 0.95, torch.ones_like(dm), dm).unsqueeze(1)
+    ref = mod.gaussian_filter(x)
+    assert out.shape == ref.shape == (5, 1, 48, 40)
+    assert (out - ref).abs().max().item() <= 2e-6
+    with torch.no_grad():
+        z = mod(dm)                                           # the module takes the kernel on CUDA tensors
+    assert z.shape == (5, 1, 48, 40) and 0.0 < (z - dm.unsqueeze(1)).abs().max().item() < 1.3
