@@ -234,7 +234,7 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     R = lib.shr_data_to_model_parts(n5, S5, S5)
     ls = torch.empty(n5 * R, device=dev); gr = torch.empty(n5 * R, J, 3, device=dev)
     a = [t.data_ptr() for t in (obs, index, cen, rad, ls, gr)]
-    t_d2m = mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_partial(a[0], a[1], a[2], a[3], n5, J, S5, S5, R,
+    t_d2m = mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_partial(a[0], a[1], a[2], 3, a[3], n5, J, S5, S5, R,
                                                                                a[4], a[5], s), "d2m"), stream, 20, 3, 3)
     Rm = lib.shr_sphere_raster_mse_regions(S5, S5)
     dep = torch.empty(n5, S5, S5, device=dev); sse = torch.empty(n5 * Rm, device=dev)
@@ -262,7 +262,7 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     R = lib.shr_data_to_model_parts(n5, S, S)
     ls = torch.empty(n5 * R, device=dev); gr = torch.empty(n5 * R, J, 3, device=dev)
     a = [t.data_ptr() for t in (obs, index, cen, rad, ls, gr)]
-    t_d2m = mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_partial(a[0], a[1], a[2], a[3], n5, J, S, S, R,
+    t_d2m = mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_partial(a[0], a[1], a[2], 3, a[3], n5, J, S, S, R,
                                                                                a[4], a[5], s), "d2m"), stream, 40, 3, 3)
     sec["data_to_model_kernel_1152_crops_128x128"] = dict(us=round(t_d2m, 1), **roof(n5 * (4 * S * S + 16 * J), t_d2m))
     del ds, crit, obs

@@ -119,8 +119,9 @@ int shr_data_to_model_indexed(const float *depth, const int32_t *depth_index,
  * as fixed-point integers inside the kernel: a crop's result is bit-reproducible and does not depend on the
  * launch shape. */
 int shr_data_to_model_parts(int N, int H, int W);
+/* centre_stride: floats between consecutive centres (3, or 4 to read the rasterizer's (x, y, z, r) records in place). */
 int shr_data_to_model_partial(const float *depth, const int32_t *depth_index,
-                              const float *centres, const float *radii,
+                              const float *centres, int centre_stride, const float *radii,
                               int N, int J, int H, int W, int parts, float *loss_parts,
                               float *grad_parts, void *stream);
 
@@ -229,6 +230,17 @@ int shr_group_norm_relu_bwd(const float *x, const float *pre_bias, const float *
 int shr_mutual_project_fwd(const float *cam, const float *inv_cam, const float *joints,
                            const float *radii, int B, int V, int J, float *spheres,
                            void *stream);
+/* Assembly of MutualProjectionLoss (mesh/multiview_utility.py:98-129) and of its backward from the partial results
+ * of shr_sphere_raster_mse (sse_part [N][Rm], grad_spheres_part [N][Rm][J][4], N = B*V*V pairs) and of
+ * shr_data_to_model_partial (d2m_part [E][Rd], grad_d2m_part [E][Rd][J][3]; E = N pairs when is_mv, else the B*V
+ * same-view pairs, entry b*V+i):
+ *   loss[0] = 9 MSE + d2m_weight * 9 d2m over all pairs (is_mv), or 3 x the same over the V same-view pairs,
+ *   grad_joints[B,V,J,3] (may be NULL) = d loss / d joints (both sphere gradients weighted, added and pulled back
+ *   through the detached view transforms).  fp64 accumulation of the scalar in a fixed order: deterministic. */
+int shr_mv_loss_combine(const float *cam, const float *inv_cam, const float *sse_part,
+                        const float *grad_spheres_part, int Rm, const float *d2m_part,
+                        const float *grad_d2m_part, int Rd, int B, int V, int J, int H, int W, int is_mv,
+                        float d2m_weight, float *loss, float *grad_joints, void *stream);
 /* grad_joints[B,V,J,3] = sum_j R(b,i,j)^T grad_spheres[b,i,j,k].xyz (the view
  * transforms are constants: detached at mesh/multiview_utility.py:68). */
 int shr_mutual_project_bwd(const float *cam, const float *inv_cam, const float *grad_spheres,

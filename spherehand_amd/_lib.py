@@ -15,7 +15,7 @@ import torch  # noqa: F401  (device memory, streams: the plumbing this library s
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libspherehand_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -32,7 +32,8 @@ SIGNATURES = {
     "shr_data_to_model": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "shr_data_to_model_indexed": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "shr_data_to_model_parts": ([_i, _i, _i], _i),
-    "shr_data_to_model_partial": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
+    "shr_data_to_model_partial": ([_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
+    "shr_mv_loss_combine": ([_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
     "shr_sphere_raster_mse_regions": ([_i, _i], _i),
     "shr_pair_losses": ([_vp, ctypes.c_longlong, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "shr_mv_consistency": ([_vp, _vp, _i, _i, _i, _vp, _vp, _vp], _i),

@@ -68,8 +68,9 @@ struct D2mUnitIter {
 template <bool WANT_GRAD, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ depth_index,
-                     const float *__restrict__ centres, const float *__restrict__ radii, int J, int H, int W,
-                     int band_units, int parts, float *__restrict__ loss_sum, float *__restrict__ grad_centres) {
+                     const float *__restrict__ centres, int centre_stride, const float *__restrict__ radii, int J,
+                     int H, int W, int band_units, int parts, float *__restrict__ loss_sum,
+                     float *__restrict__ grad_centres) {
   __shared__ float4 s_c[SHR_MAX_SPHERES];                 // (cx, cy, cz, r)
   __shared__ int s_odd, s_nan;                            // non-finite sphere table / a NaN loss term
   __shared__ unsigned long long s_loss;                   // fixed-point loss sum
@@ -83,7 +84,7 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
   if (wave == 0) {
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane < J) {
-      const float *p = centres + ((size_t)n * J + lane) * 3;
+      const float *p = centres + ((size_t)n * J + lane) * centre_stride;
       c = make_float4(p[0], p[1], p[2], radii[lane]);
       s_c[lane] = c;
     }
@@ -410,26 +411,27 @@ int g_d2m_band = 0;    // 0 = by crop size (SHR_TUNE_D2M_BAND_UNITS)
 
 template <bool WANT_GRAD>
 void launch_d2m_waves(int waves, const float *depth, const int32_t *depth_index, const float *centres,
-                      const float *radii, int N, int J, int H, int W, int band_units, int parts, float *loss_sum,
+                      int centre_stride, const float *radii, int N, int J, int H, int W, int band_units, int parts, float *loss_sum,
                       float *grad_centres, hipStream_t s) {
   using namespace shr;
   const dim3 grid((unsigned)(N * parts));
   if (waves >= 16)
-    hipLaunchKernelGGL((data_to_model_kernel<WANT_GRAD, 16>), grid, dim3(1024), 0, s, depth, depth_index, centres, radii,
-                       J, H, W, band_units, parts, loss_sum, grad_centres);
+    hipLaunchKernelGGL((data_to_model_kernel<WANT_GRAD, 16>), grid, dim3(1024), 0, s, depth, depth_index, centres, centre_stride,
+                       radii, J, H, W, band_units, parts, loss_sum, grad_centres);
   else if (waves >= 8)
-    hipLaunchKernelGGL((data_to_model_kernel<WANT_GRAD, 8>), grid, dim3(512), 0, s, depth, depth_index, centres, radii,
-                       J, H, W, band_units, parts, loss_sum, grad_centres);
+    hipLaunchKernelGGL((data_to_model_kernel<WANT_GRAD, 8>), grid, dim3(512), 0, s, depth, depth_index, centres, centre_stride,
+                       radii, J, H, W, band_units, parts, loss_sum, grad_centres);
   else
-    hipLaunchKernelGGL((data_to_model_kernel<WANT_GRAD, 4>), grid, dim3(256), 0, s, depth, depth_index, centres, radii,
-                       J, H, W, band_units, parts, loss_sum, grad_centres);
+    hipLaunchKernelGGL((data_to_model_kernel<WANT_GRAD, 4>), grid, dim3(256), 0, s, depth, depth_index, centres, centre_stride,
+                       radii, J, H, W, band_units, parts, loss_sum, grad_centres);
 }
 
-int launch_d2m(const float *depth, const int32_t *depth_index, const float *centres, const float *radii, int N, int J,
-               int H, int W, int parts, float *loss_sum, float *grad_centres, void *stream) {
+int launch_d2m(const float *depth, const int32_t *depth_index, const float *centres, int centre_stride,
+               const float *radii, int N, int J, int H, int W, int parts, float *loss_sum, float *grad_centres,
+               void *stream) {
   if (N == 0) return SHR_OK;
   if (!depth || !centres || !radii || !loss_sum || N < 0 || J <= 0 || H <= 0 || W <= 0) return SHR_EINVAL;
-  if (parts != 1 && parts != 2 && parts != 4) return SHR_EINVAL;
+  if ((parts != 1 && parts != 2 && parts != 4) || (centre_stride != 3 && centre_stride != 4)) return SHR_EINVAL;
   // ring entries pack (v, u) into 16 bits each
   if (J > SHR_MAX_SPHERES || (long long)H * W > (1LL << 30) || H > 65535 || W > 65535 ||
       (long long)N * parts > 0x7fffffffLL)
@@ -447,10 +449,10 @@ int launch_d2m(const float *depth, const int32_t *depth_index, const float *cent
   if (g_d2m_band) band_units = g_d2m_band;
   if (band_units < 1) band_units = 1;
   if (grad_centres)
-    launch_d2m_waves<true>(waves, depth, depth_index, centres, radii, N, J, H, W, band_units, parts, loss_sum,
+    launch_d2m_waves<true>(waves, depth, depth_index, centres, centre_stride, radii, N, J, H, W, band_units, parts, loss_sum,
                            grad_centres, s);
   else
-    launch_d2m_waves<false>(waves, depth, depth_index, centres, radii, N, J, H, W, band_units, parts, loss_sum,
+    launch_d2m_waves<false>(waves, depth, depth_index, centres, centre_stride, radii, N, J, H, W, band_units, parts, loss_sum,
                             grad_centres, s);
   return (int)hipGetLastError();
 }
@@ -470,14 +472,14 @@ int shr::d2m_set_band_units(int units) {
 
 extern "C" int shr_data_to_model(const float *depth, const float *centres, const float *radii, int N, int J, int H,
                                  int W, float *loss_sum, float *grad_centres, void *stream) {
-  return launch_d2m(depth, nullptr, centres, radii, N, J, H, W, 1, loss_sum, grad_centres, stream);
+  return launch_d2m(depth, nullptr, centres, 3, radii, N, J, H, W, 1, loss_sum, grad_centres, stream);
 }
 
 extern "C" int shr_data_to_model_indexed(const float *depth, const int32_t *depth_index, const float *centres,
                                          const float *radii, int N, int J, int H, int W, float *loss_sum,
                                          float *grad_centres, void *stream) {
   if (!depth_index && N > 0) return SHR_EINVAL;
-  return launch_d2m(depth, depth_index, centres, radii, N, J, H, W, 1, loss_sum, grad_centres, stream);
+  return launch_d2m(depth, depth_index, centres, 3, radii, N, J, H, W, 1, loss_sum, grad_centres, stream);
 }
 
 // Large crops are split over several workgroups (on different CUs): the kernel then writes `parts` partial
@@ -488,7 +490,8 @@ extern "C" int shr_data_to_model_parts(int N, int H, int W) {
 }
 
 extern "C" int shr_data_to_model_partial(const float *depth, const int32_t *depth_index, const float *centres,
-                                         const float *radii, int N, int J, int H, int W, int parts,
+                                         int centre_stride, const float *radii, int N, int J, int H, int W, int parts,
                                          float *loss_parts, float *grad_parts, void *stream) {
-  return launch_d2m(depth, depth_index, centres, radii, N, J, H, W, parts, loss_parts, grad_parts, stream);
+  return launch_d2m(depth, depth_index, centres, centre_stride, radii, N, J, H, W, parts, loss_parts, grad_parts,
+                    stream);
 }

@@ -69,7 +69,96 @@ __global__ void mutual_project_bwd_kernel(const float *__restrict__ cam, const f
   o[0] = g[0]; o[1] = g[1]; o[2] = g[2];
 }
 
+// Assembly of MutualProjectionLoss (mesh/multiview_utility.py:98-129) from the partial results of the fused
+// render-and-compare kernel and of the data->model kernel, with its whole backward, in one call:
+//   is_mv:   loss = 9 * sum(sse) / (B V V H W) + 500 * 9 * sum(d2m) / (B V V H W)          over all V*V pairs
+//   else:    loss = 3 * sum_diag(sse) / (B H W)  + 500 * 3 * sum_diag(d2m) / (B H W)       over the V same-view pairs
+// and grad_joints[b,i,k] = sum_j R(b,i,j)^T (w_m * d sse / d centre + w_d * d d2m / d centre) -- the sphere
+// gradients of the two kernels (R partials each) weighted, added and pulled back through the view transforms
+// (constants: detached at :68; the radii are buffers).  The loss is accumulated in fp64 in a fixed order.
+// d2m_part / gd2m_part hold one entry per pair (is_mv) or per DIAGONAL pair b*V+i (else).
+__global__ void __launch_bounds__(256)
+mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ inv_cam,
+                       const float *__restrict__ sse_part, const float4 *__restrict__ gsp_part, int Rm,
+                       const float *__restrict__ d2m_part, const float *__restrict__ gd2m_part, int Rd, int B, int V,
+                       int J, int is_mv, float w_m, float w_d, float *__restrict__ loss_out,
+                       float *__restrict__ grad_joints) {
+  const long long total = (long long)B * V * J;
+  if (blockIdx.x == gridDim.x - 1) {
+    // the scalar: one workgroup, every thread a strided fp64 partial, then a fixed tree
+    __shared__ double s_m[256], s_d[256];
+    const long long N = (long long)B * V * V;
+    double am = 0.0, ad = 0.0;
+    for (long long n = threadIdx.x; n < N; n += 256) {
+      const int j = (int)(n % V), i = (int)((n / V) % V);
+      if (!is_mv && i != j) continue;
+      for (int r = 0; r < Rm; r++) am += (double)sse_part[n * Rm + r];
+      const long long e = is_mv ? n : (n / ((long long)V * V)) * V + i;
+      for (int r = 0; r < Rd; r++) ad += (double)d2m_part[e * Rd + r];
+    }
+    s_m[threadIdx.x] = am; s_d[threadIdx.x] = ad;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+      if ((int)threadIdx.x < h) { s_m[threadIdx.x] += s_m[threadIdx.x + h]; s_d[threadIdx.x] += s_d[threadIdx.x + h]; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_out[0] = (float)((double)w_m * s_m[0] + (double)w_d * s_d[0]);
+    return;
+  }
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total || !grad_joints) return;
+  const int k = (int)(idx % J);
+  const int i = (int)((idx / J) % V);
+  const int b = (int)(idx / ((long long)J * V));
+  float g[3] = {0.f, 0.f, 0.f};
+  for (int j = 0; j < V; j++) {
+    if (!is_mv && j != i) continue;
+    const long long n = ((long long)b * V + i) * V + j;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int r = 0; r < Rm; r++) {
+      const float4 a = gsp_part[(n * Rm + r) * J + k];
+      gx += a.x; gy += a.y; gz += a.z;
+    }
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    const long long e = is_mv ? n : (long long)b * V + i;
+    for (int r = 0; r < Rd; r++) {
+      const float *a = gd2m_part + ((e * Rd + r) * J + k) * 3;
+      dx += a[0]; dy += a[1]; dz += a[2];
+    }
+    const float sx = w_m * gx + w_d * dx, sy = w_m * gy + w_d * dy, sz = w_m * gz + w_d * dz;
+    float R[3][3], t[3];
+    pair_rt(cam, inv_cam, b, V, i, j, R, t);
+#pragma unroll
+    for (int c = 0; c < 3; c++) g[c] += (R[0][c] * sx + R[1][c] * sy) + R[2][c] * sz;
+  }
+  float *o = grad_joints + idx * 3;
+  o[0] = g[0]; o[1] = g[1]; o[2] = g[2];
+}
+
 }  // namespace shr
+
+extern "C" int shr_mv_loss_combine(const float *cam, const float *inv_cam, const float *sse_part,
+                                   const float *grad_spheres_part, int Rm, const float *d2m_part,
+                                   const float *grad_d2m_part, int Rd, int B, int V, int J, int H, int W, int is_mv,
+                                   float d2m_weight, float *loss, float *grad_joints, void *stream) {
+  using namespace shr;
+  if (B == 0) return SHR_OK;
+  if (!cam || !inv_cam || !sse_part || !grad_spheres_part || !d2m_part || !grad_d2m_part || !loss || B < 0 || V <= 0 ||
+      J <= 0 || H <= 0 || W <= 0 || Rm <= 0 || Rd <= 0)
+    return SHR_EINVAL;
+  if (((uintptr_t)grad_spheres_part & 15u) != 0) return SHR_EINVAL;
+  if ((long long)B * V * V * J > (1LL << 31) - 256) return SHR_ETOOLARGE;
+  // MSELoss means and the reference's x9 / x3 (mesh/multiview_utility.py:100-101, :126-127); DataToModelLoss means
+  // over the same pixel counts (mesh/render.py:142) times its x9 / x3 and the caller's 500 (:129)
+  const double px = (double)H * W;
+  const double wm = is_mv ? 9.0 / ((double)B * V * V * px) : 3.0 / ((double)B * px);
+  const double wd = (double)d2m_weight * wm;
+  const long long total = (long long)B * V * J;
+  hipLaunchKernelGGL(mv_loss_combine_kernel, dim3((unsigned)((total + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream,
+                     cam, inv_cam, sse_part, reinterpret_cast<const float4 *>(grad_spheres_part), Rm, d2m_part,
+                     grad_d2m_part, Rd, B, V, J, is_mv, (float)wm, (float)wd, loss, grad_joints);
+  return (int)hipGetLastError();
+}
 
 extern "C" int shr_mutual_project_fwd(const float *cam, const float *inv_cam, const float *joints,
                                       const float *radii, int B, int V, int J, float *spheres, void *stream) {

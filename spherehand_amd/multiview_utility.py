@@ -64,14 +64,17 @@ class MutualProjectionLoss(nn.Module):
         B, V = camera_poses.shape[0], camera_poses.shape[1]
         H, W = depth_maps.shape[-2], depth_maps.shape[-1]
         mp = self.mutual_projection
-        if self.fused and joints.is_cuda and depth_maps.is_cuda and V == 3:
-            spheres = ops.MutualProject.apply(camera_poses.detach(), inv_camera_poses.detach(), joints,
-                                              mp.radiuses.view(-1))                      # [B,V,V,J,4]
-            J = spheres.shape[3]
+        if self.fused and joints.is_cuda and depth_maps.is_cuda and V == 3 and joints.dtype == torch.float32:
+            # crop (b,i,j) compares with observed image b*V+j through an index (the reference expands the
+            # observations 3x); five launches for both terms and their whole backward (ops.MutualProjectionLossFused)
             observed = depth_maps.contiguous().float().view(B * V, H, W)
-            flat = spheres.view(B * V * V, J, 4)
-            if ops.sphere_raster_mse_supported(flat, observed, H, W):
-                return self._forward_fused(flat, observed, B, V, J, H, W, is_mv)
+            radii = mp.radiuses.view(-1)
+            if W % 4 == 0 and observed.data_ptr() % 16 == 0 and \
+                    ops._lib.lib().shr_sphere_raster_mse_regions(int(H), int(W)) > 0:
+                index, diag = self._indices(B, V, joints.device)
+                loss, projected = ops.MutualProjectionLossFused.apply(camera_poses, inv_camera_poses, joints, observed, radii,
+                                                                      index, diag, bool(is_mv), 500.0)
+                return loss, projected.view(B, V, V, H, W)
         projected_dms, projected_joints = mp(camera_poses, inv_camera_poses, joints)
         J = projected_joints.shape[3]
         pts = projected_joints.squeeze(-1)                                     # [B,V,V,J,3]
@@ -93,34 +96,16 @@ class MutualProjectionLoss(nn.Module):
         loss = model_to_data_loss + data_to_model_loss * 500
         return loss, projected_dms
 
-    def _forward_fused(self, spheres, observed, B, V, J, H, W, is_mv):
-        """Both terms without any per-pair image in HBM besides the returned projections: crop
-        (b,i,j) compares with observed image b*V + j through an index (the reference expands the
-        observations 3x), the model->data term is ONE render-and-compare launch."""
-        dev = spheres.device
+    def _indices(self, B, V, dev):
         key = (B, V, str(dev))
         if self._index_key != key:
             b = torch.arange(B, device=dev, dtype=torch.int32).view(B, 1, 1)
             j = torch.arange(V, device=dev, dtype=torch.int32).view(1, 1, V)
-            self._index = (b * V + j).expand(B, V, V).reshape(-1).contiguous()
-            diag = torch.eye(V, device=dev, dtype=torch.float32).view(1, V, V).expand(B, V, V).reshape(-1)
-            self._diag = diag.contiguous()
+            self._index = (b * V + j).expand(B, V, V).reshape(-1).contiguous()          # pair (b,i,j) -> image b*V+j
+            self._diag_index = torch.arange(B * V * V, device=dev).view(B, V, V).diagonal(dim1=1, dim2=2).reshape(-1) \
+                .contiguous()                                                           # the V same-view pairs
             self._index_key = key
-        sse, projected = ops.SphereRasterSSE.apply(spheres, observed, self._index)
-        centres = spheres[..., 0:3]
-        radii = self.data_to_model_criterion.radiuses.view(-1)
-        if is_mv:
-            # MSELoss over [B,V,V,H,W] (x9) and DataToModelLoss's mean over the same pixels (x9)
-            model_to_data_loss = sse.double().sum().float() / float(B * V * V * H * W) * 9
-            data_to_model_loss = ops.DataToModel.apply(observed, centres, radii, self._index) * 9
-        else:
-            # the three same-view pairs: three MSELoss means over [B,H,W] summed, x3
-            model_to_data_loss = (sse * self._diag).double().sum().float() / float(B * H * W) * 3
-            idx = torch.arange(B * V * V, device=dev).view(B, V, V).diagonal(dim1=1, dim2=2).reshape(-1)
-            data_to_model_loss = ops.DataToModel.apply(observed, centres[idx].contiguous(), radii,
-                                                       self._index[idx].contiguous()) * (V * 3)
-        loss = model_to_data_loss + data_to_model_loss * 500
-        return loss, projected.view(B, V, V, H, W)
+        return self._index, self._diag_index
 
 
 class MultiviewConsistencyLoss(nn.Module):

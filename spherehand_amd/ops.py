@@ -204,7 +204,7 @@ def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
     with _on(depth.device):
         loss_sum = torch.empty((N, R), dtype=torch.float32, device=depth.device)
         grad = torch.empty((N, R, J, 3), dtype=torch.float32, device=depth.device) if want_grad else None
-        _lib.check(lib.shr_data_to_model_partial(_ptr(depth), _ptr(depth_index), _ptr(centres), _ptr(radii), N, J, H, W, R,
+        _lib.check(lib.shr_data_to_model_partial(_ptr(depth), _ptr(depth_index), _ptr(centres), 3, _ptr(radii), N, J, H, W, R,
                                                  _ptr(loss_sum), _ptr(grad), _stream()), "shr_data_to_model_partial")
         if R > 1:
             loss_sum = loss_sum.sum(1)
@@ -237,6 +237,67 @@ class DataToModel(torch.autograd.Function):
     def backward(ctx, grad_out):
         (grad,) = ctx.saved_tensors
         return None, grad * (grad_out / ctx.count), None, None
+
+
+class MutualProjectionLossFused(torch.autograd.Function):
+    """(cam, inv_cam [B,V,4,4], joints [B,V,J,3], observed [B*V,H,W], radii [J], index [B*V*V] int32, is_mv) ->
+    (loss, projected depth [B*V*V,H,W]): MutualProjectionLoss (mesh/multiview_utility.py:90-130) as FIVE launches
+    -- view projection, fused render-and-compare, data->model, and the assembly kernel that weights, adds and
+    pulls both sphere gradients back to the joints (the whole backward is done in the forward: the losses are
+    plain sums) -- plus one scaling in backward.  The unfused wiring needed ~35 small torch launches around the
+    same three kernels."""
+
+    @staticmethod
+    def forward(ctx, cam, inv_cam, joints, observed, radii, index, diag_index, is_mv, d2m_weight):
+        cam, inv_cam, joints = (t.detach().contiguous().float() for t in (cam, inv_cam, joints))
+        observed, radii = observed.contiguous().float(), radii.contiguous().float()
+        for t, name in ((cam, "camera_poses"), (inv_cam, "inv_camera_poses"), (joints, "joints"), (observed, "depth_maps"),
+                        (radii, "radii")):
+            _check_input(t, name)
+        B, V, J = joints.shape[0], joints.shape[1], joints.shape[2]
+        H, W = observed.shape[-2], observed.shape[-1]
+        N = B * V * V
+        lib = _lib.lib()
+        Rm = lib.shr_sphere_raster_mse_regions(int(H), int(W))
+        dev = joints.device
+        with _on(dev):
+            spheres = torch.empty((N, J, 4), dtype=torch.float32, device=dev)
+            _lib.check(lib.shr_mutual_project_fwd(_ptr(cam), _ptr(inv_cam), _ptr(joints), _ptr(radii), B, V, J, _ptr(spheres),
+                                                  _stream()), "shr_mutual_project_fwd")
+            depth = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+            sse = torch.empty((N, Rm), dtype=torch.float32, device=dev)
+            gsp = torch.empty((N, Rm, J, 4), dtype=torch.float32, device=dev)
+            _lib.check(lib.shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), _ptr(depth),
+                                                 _ptr(sse), _ptr(gsp), _stream()), "shr_sphere_raster_mse")
+            if is_mv:
+                E, cen, cidx = N, spheres, index
+            else:                # the V same-view pairs only: their records and observed-image numbers, gathered
+                E = B * V
+                cen = spheres.index_select(0, diag_index)
+                cidx = index.index_select(0, diag_index)
+            Rd = lib.shr_data_to_model_parts(E, int(H), int(W))
+            d2m = torch.empty((E, Rd), dtype=torch.float32, device=dev)
+            gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
+            _lib.check(lib.shr_data_to_model_partial(_ptr(observed), _ptr(cidx), _ptr(cen), 4, _ptr(radii), E, J, H, W, Rd,
+                                                     _ptr(d2m), _ptr(gd2m), _stream()), "shr_data_to_model_partial")
+            loss = torch.empty(1, dtype=torch.float32, device=dev)
+            want = ctx.needs_input_grad[2]
+            gj = torch.empty((B, V, J, 3), dtype=torch.float32, device=dev) if want else None
+            _lib.check(lib.shr_mv_loss_combine(_ptr(cam), _ptr(inv_cam), _ptr(sse), _ptr(gsp), Rm, _ptr(d2m), _ptr(gd2m), Rd,
+                                               B, V, J, H, W, int(bool(is_mv)), float(d2m_weight), _ptr(loss), _ptr(gj),
+                                               _stream()), "shr_mv_loss_combine")
+        if want:
+            ctx.save_for_backward(gj)
+        ctx.mark_non_differentiable(depth)
+        ctx.set_materialize_grads(False)
+        return loss.view(()), depth
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_depth):
+        if g_loss is None:
+            return (None,) * 9
+        (gj,) = ctx.saved_tensors
+        return None, None, gj * g_loss, None, None, None, None, None, None
 
 
 class MutualProject(torch.autograd.Function):
