@@ -1,0 +1,59 @@
+"""gpurun_out/r02 (tools/collect_profiles_r02.sh) -> profiles/r02_*: python tools/summarize_r02.py"""
+import collections, csv, glob, json, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O, P = os.path.join(ROOT, "gpurun_out", "r02"), os.path.join(ROOT, "profiles")
+
+def shr_rows(src, dst, keep=lambda name: True):
+    rows = list(csv.reader(open(src)))
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(rows[0])
+        for r in rows[1:]:
+            if keep(r[0]):
+                w.writerow([r[0].split("(")[0][:120]] + r[1:])
+
+ours = lambda n: "shr::" in n or "group_norm" in n
+shr_rows(os.path.join(O, "stats_headline", "bench_kernel_stats.csv"), os.path.join(P, "r02_bench_kernel_stats.csv"))
+shr_rows(os.path.join(O, "stats", "bench_kernel_stats.csv"), os.path.join(P, "r02_secondary_kernel_stats.csv"), ours)
+for n in ("bench_line.json", "bench_line_graph.json"):
+    shutil.copy(os.path.join(O, n), os.path.join(P, "r02_" + n))
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), os.path.join(O, "pmc_fetch"),
+                       os.path.join(O, "pmc_write"), os.path.join(P, "r02_pmc_traffic.json"), "sphere_zbuf_fwd_kernel",
+                       "sphere_zbuf_bwd_kernel"], stdout=subprocess.DEVNULL)
+# SQ counters: per kernel, mean per launch over every launch of every pass that saw it
+sq = collections.defaultdict(lambda: collections.defaultdict(list))
+grid = {}
+for f in glob.glob(os.path.join(O, "sq_*", "*counter_collection.csv")) + glob.glob(os.path.join(O, "fetch_d2m*", "*counter_collection.csv")):
+    tag = os.path.basename(os.path.dirname(f))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if not ours(k) or "group_norm" in k or "soft_argmax" in k or "fk_" in k or "lbs_" in k or "paint" in k or "noise" in k:
+            continue
+        key = k.replace("void ", "") + " grid=" + r["Grid_Size"] if "Grid_Size" in r else k.replace("void ", "")
+        if tag.startswith("fetch") and "data_to_model" not in k:
+            continue
+        sq[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, cs in sorted(sq.items()):
+    m = {c: round(sum(v) / len(v), 1) for c, v in cs.items()}
+    d = {"launches_seen": max(len(v) for v in cs.values()), "counters_mean_per_launch": m}
+    if "SQ_WAVE_CYCLES" in m and m["SQ_WAVE_CYCLES"] > 0:
+        wc = m["SQ_WAVE_CYCLES"]
+        d["share_of_wave_cycles"] = {"issuing (ACTIVE_INST_ANY)": round(m.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3),
+                                     "of which VALU (ACTIVE_INST_VALU)": round(m.get("SQ_ACTIVE_INST_VALU", 0) / wc, 3),
+                                     "parked at s_waitcnt / barrier (WAIT_ANY)": round(m.get("SQ_WAIT_ANY", 0) / wc, 3),
+                                     "issue-stalled (WAIT_INST_ANY)": round(m.get("SQ_WAIT_INST_ANY", 0) / wc, 3)}
+        if m.get("SQ_WAVES"):
+            d["per_wave"] = {"VALU_instructions": round(m.get("SQ_INSTS_VALU", 0) / m["SQ_WAVES"], 1),
+                             "SALU_instructions": round(m.get("SQ_INSTS_SALU", 0) / m["SQ_WAVES"], 1),
+                             "LDS_instructions": round(m.get("SQ_INSTS_LDS", 0) / m["SQ_WAVES"], 1),
+                             "lifetime_cycles (4 x WAVE_CYCLES / WAVES)": round(4 * wc / m["SQ_WAVES"], 0)}
+    if "FETCH_SIZE" in m:
+        d["hbm_read_bytes_per_launch (2 x FETCH_SIZE KB, gfx950 half-count)"] = int(2 * m["FETCH_SIZE"] * 1024)
+    out[k] = d
+out["_note"] = ("rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes, sets A and B of tools/collect_profiles_r02.sh) on "
+                "bench.py (--no-secondary: the headline kernels at batch 256; with the secondary set: every other kernel) and on "
+                "tools/prof_d2m.py (1152 crops, S = 128 / 256).  SQ_*_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles "
+                "summed over all waves; a kernel seen at several problem sizes is split by grid size.")
+json.dump(out, open(os.path.join(P, "r02_sq_counters.json"), "w"), indent=1)
+print(json.dumps({k: v.get("share_of_wave_cycles") for k, v in out.items() if isinstance(v, dict)}, indent=1))
