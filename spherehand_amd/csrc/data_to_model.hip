@@ -15,15 +15,15 @@
 // Design (round 2; the round-1 kernel pruned per 64 points with wave-wide boxes and seeds and was
 // bound by the latency of those reductions and of one-point-per-lane dependent chains):
 //   * every WAVE is independent until the final combine.  The crop is cut into UNITS of 256
-//     consecutive pixels (one 16-byte load per lane) and BANDS of consecutive units (a few rows to a
-//     few dozen), dealt round-robin to the waves, two or more per wave: every wave carries an equal
-//     share of the hand while the points it searches together stay neighbours.  Three units' loads
-//     are in flight per wave, across band boundaries;
+//     consecutive pixels (one 16-byte load per lane) and BANDS of a few consecutive units, handed out
+//     to the waves DYNAMICALLY (an LDS counter; legal because the sums below do not depend on their
+//     order): every wave carries an equal share of the hand while the points it searches together
+//     stay neighbours.  Two units' loads are in flight per wave, across band boundaries;
 //   * a wave keeps the ~15 % foreground pixels of a unit and appends them -- lane order,
 //     ballot/mbcnt prefix -- to its own ring in LDS as 8-byte (v << 16 | u, z) entries; whenever
 //     256 entries are there (and at the end of the band) it searches them, FOUR neighbouring points
 //     per lane: a sphere's record is read once for the 256 points (uniform-address ds_read_b128 =
-//     an LDS broadcast), ~11 VALU instructions per (point, sphere), four independent chains per lane;
+//     an LDS broadcast, requested one sphere ahead), 12 VALU instructions per (point, sphere), four independent chains per lane;
 //   * the points of a search lie in a thin strip of rows [y_lo, y_hi] (first / last ring entry:
 //     256 points are ~5 rows of a hand), and | ||p - c|| - r | >= dist_y(c, strip) - r, so with
 //     lanes = spheres one ballot gives the spheres whose y extent meets the strip.  They are
@@ -33,8 +33,8 @@
 //   * the loss and the gradient are accumulated as FIXED-POINT integers (2^-20 mm / 2^-26 per
 //     unit-vector component; 64-bit LDS atomics on one table per workgroup, a lane's four points
 //     combined first when they share their owner): integer sums do not depend on their order, so
-//     the result is bit-reproducible AND (one workgroup per crop) independent of the launch shape, without any per-owner
-//     wave reduction (the round-1 ballot loop over distinct owners was a third of the kernel).
+//     the result is bit-reproducible AND (one workgroup per crop) independent of the launch shape,
+//     without any per-owner wave reduction (the round-1 ballot loop over distinct owners was a third of the kernel).
 // A non-finite sphere record or depth value sends the search through the exact index-order loop
 // (torch.min / clamp propagate NaN).  HBM: reads 4*H*W + 12*J + 4*J bytes per crop.
 

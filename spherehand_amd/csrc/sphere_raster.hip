@@ -40,12 +40,19 @@ int log2_if_pow2(int v) {
   return s;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: the flag is kept per device ordinal
+// (ops._on() may launch on a non-current device of the same process).
+constexpr int kMaxDevices = 64;
+struct AttrDone { bool dev[kMaxDevices] = {}; };
+
 template <typename K>
-hipError_t allow_big_lds(K kernel, bool *done) {
-  if (*done) return hipSuccess;
+hipError_t allow_big_lds(K kernel, AttrDone *done) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = -1;
+  if (d >= 0 && done->dev[d]) return hipSuccess;
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-  if (e == hipSuccess) *done = true;
+  if (e == hipSuccess && d >= 0) done->dev[d] = true;
   return e;
 }
 
@@ -60,7 +67,7 @@ bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 template <bool OWNER, bool VEC4, bool POW2>
 int launch_zbuf_fwd_t(const float4 *sp, int N, int J, int H, int W, float *depth, uint8_t *argmin, int rows,
                       hipStream_t s) {
-  static bool attr_done = false;
+  static AttrDone attr_done;
   auto k = sphere_zbuf_fwd_kernel<OWNER, VEC4, POW2>;
   const hipError_t e = allow_big_lds(k, &attr_done);
   if (e != hipSuccess) return (int)e;
@@ -82,7 +89,7 @@ int launch_zbuf_fwd(const float4 *sp, int N, int J, int H, int W, float *depth, 
 template <bool VEC4, bool POW2>
 int launch_zbuf_bwd_t(const float4 *sp, const float *grad, const uint8_t *argmin, int N, int J, int H, int W,
                       float4 *gs, int rows, hipStream_t s) {
-  static bool attr_done = false;
+  static AttrDone attr_done;
   auto k = sphere_zbuf_bwd_kernel<VEC4, POW2>;
   const hipError_t e = allow_big_lds(k, &attr_done);
   if (e != hipSuccess) return (int)e;
@@ -239,7 +246,7 @@ extern "C" int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, 
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = kHdrBytes + kPartBytes + (size_t)rows * (W + kRowPad) * 8;
   dim3 grid((unsigned)N, (unsigned)((H + rows - 1) / rows));
-  static bool attr_a = false, attr_b = false;
+  static AttrDone attr_a, attr_b;
   if (is_pow2(W) && is_pow2(H)) {
     auto k = sphere_zbuf_mse_kernel<true>;
     const hipError_t e = allow_big_lds(k, &attr_a);
