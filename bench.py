@@ -341,13 +341,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # test hooks (tests/test_bench_gpu.py runs two ranks on ONE GPU, where RCCL refuses duplicate devices):
+    # SHR_BENCH_DEVICE pins every rank to one device, SHR_BENCH_BACKEND=gloo swaps the process-group backend
+    if os.environ.get("SHR_BENCH_DEVICE"):
+        local_rank = int(os.environ["SHR_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SHR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         # the launcher's world size, --gpus and what RCCL actually connected must agree
         assert dist.get_world_size() == world == args.gpus, \
             "launched %d ranks (RCCL sees %d) but --gpus %d" % (world, dist.get_world_size(), args.gpus)
@@ -438,7 +446,7 @@ def main():
                                    "JointAngleDataset poses (seed 0), grad N(0,1)",
                        "crops_per_gpu": BATCH, "image": [S, S], "spheres_per_crop": J,
                        "launch": args.launch, "parallelism": "batch-sharded x%d, no data-path collective" % world,
-                       "rccl_ranks": rccl_ranks},
+                       "rccl_ranks": rccl_ranks, "backend": os.environ.get("SHR_BENCH_BACKEND", "nccl") if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,

@@ -1,0 +1,36 @@
+"""GPU: bench.py's multi-rank path end to end -- two ranks launched exactly as the driver launches them
+(`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`) on ONE MI355X (backend gloo and a
+pinned device through bench.py's test hooks: RCCL refuses two ranks on one device).  Checks the JSON contract:
+whole-job value = crops of all ranks / max-over-ranks time, weak scaling, the rank count the collective saw."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+from test_ddp_cpu import free_port
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_two_ranks_one_gpu():
+    env = dict(os.environ, SHR_BENCH_BACKEND="gloo", SHR_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "10"]
+    out = subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT, capture_output=True, text=True).stdout
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out                               # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 50 and d["warmup"] == 10 and d["scaling"] == "weak"
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["crops_per_gpu"] == 256
+    assert abs(d["value"] - 2 * 256 * 50 / (d["ms_per_step"] * 1e-3 * 50)) <= 1e-3 * d["value"]
+    assert "cpu_baseline" not in d and "secondary" not in d   # N = 1 only
+    assert 0 < d["roofline"]["frac"] < 1
+
+
+def test_bench_rejects_a_world_size_mismatch():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "nproc-per-node" in (r.stderr + r.stdout)
