@@ -58,6 +58,8 @@ int shr_device_info(char *name_host, int name_len, int *num_cu_host);
 #define SHR_TUNE_FWD_SHARES 6
 #define SHR_TUNE_BWD_SHARES 7
 #define SHR_TUNE_D2M_WAVES 8       /* waves per workgroup of the data->model kernel: 0 = by batch size, 4, 8 or 16 */
+#define SHR_TUNE_PERSISTENT 10     /* sphere rasterizer launches over more crops than the device holds: 0 = one workgroup per
+                                    * crop, 1 = persistent workgroups (default), > 1 = that many workgroups */
 #define SHR_TUNE_D2M_BAND_UNITS 9  /* 256-pixel units per band handed to a wave: 0 = by crop size */
 int shr_set_tuning(int key, int value);
 /* Self-test: adds to *mismatches (device, caller-zeroed u64) the number of fp32

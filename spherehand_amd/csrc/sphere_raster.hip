@@ -17,6 +17,7 @@ struct Tuning {
   int fwd_waves = 16;                   // waves per forward workgroup
   int fwd_shares = 0x28384858;          // work-list shares of the four wave age groups, oldest in the low byte (sum 256)
   int bwd_shares = 0x2c3a4654;
+  int persistent = 1;                   // 0: one workgroup per crop; 1: persistent workgroups when N exceeds the device; > 1: that many
 } g_tune;
 
 constexpr int kMaxLds = 160 * 1024;
@@ -64,18 +65,52 @@ int pick_waves(int ntiles) {
 
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// Workgroups along x for a launch over N crops: all of them when they are resident at once anyway; otherwise as many
+// as the device holds at a time (CUs x workgroups per CU by LDS), each looping over its crops with the next crop's
+// records prefetched (sphere_zbuf.h).  Needs a wave that is neither the list wave nor a background wave.
+int num_cus() {
+  static int cus[kMaxDevices] = {};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return 256;
+  if (cus[d] == 0) {
+    int v = 0;
+    cus[d] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && v > 0) ? v : 256;
+  }
+  return cus[d];
+}
+
+int persistent_grid(int N, int regions, size_t lds, int nwaves) {
+  if (g_tune.persistent == 0 || nwaves <= kBgWaves + 1) return N;
+  const int per_cu = (int)(kMaxLds / (lds ? lds : 1)) > 0 ? (int)(kMaxLds / lds) : 1;
+  long long cap = (long long)num_cus() * per_cu / (regions > 0 ? regions : 1);
+  if (cap < 1) cap = 1;
+  if (g_tune.persistent > 1) return N > g_tune.persistent ? g_tune.persistent : N;   // tests / experiments: explicit count
+  // measured (MI355X, 128x128, tools/exp_persist.py): nothing to win at 4.5 crops per CU (1152), forward -2 % at 9
+  // (2304), forward -8 % / backward -3 % at 36 (9216): the hardware already overlaps a workgroup's exit with the next
+  // one's dispatch, what is saved is the records' first read
+  return N >= 4 * cap ? (int)cap : N;
+}
+
+template <bool OWNER, bool VEC4, bool POW2, bool PERSIST>
+int launch_zbuf_fwd_p(const float4 *sp, int N, int J, int H, int W, float *depth, uint8_t *argmin, int rows, size_t lds,
+                      dim3 grid, hipStream_t s) {
+  static AttrDone attr_done;
+  auto k = sphere_zbuf_fwd_kernel<OWNER, VEC4, POW2, PERSIST>;
+  const hipError_t e = allow_big_lds(k, &attr_done);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k, grid, dim3(64 * g_tune.fwd_waves), lds, s, sp, N, J, H, W, depth, argmin, rows,
+                     log2_if_pow2(W / 4), g_tune.fwd_shares);
+  return (int)hipGetLastError();
+}
+
 template <bool OWNER, bool VEC4, bool POW2>
 int launch_zbuf_fwd_t(const float4 *sp, int N, int J, int H, int W, float *depth, uint8_t *argmin, int rows,
                       hipStream_t s) {
-  static AttrDone attr_done;
-  auto k = sphere_zbuf_fwd_kernel<OWNER, VEC4, POW2>;
-  const hipError_t e = allow_big_lds(k, &attr_done);
-  if (e != hipSuccess) return (int)e;
   const size_t lds = kHdrBytes + (size_t)(rows + kPadRows) * (W + kRowPad) * (OWNER ? 8 : 4);
-  dim3 grid((unsigned)N, (unsigned)((H + rows - 1) / rows)), block(64 * g_tune.fwd_waves);
-  hipLaunchKernelGGL(k, grid, block, lds, s, sp, J, H, W, depth, argmin, rows, log2_if_pow2(W / 4),
-                     g_tune.fwd_shares);
-  return (int)hipGetLastError();
+  const int regions = (H + rows - 1) / rows;
+  dim3 grid((unsigned)persistent_grid(N, regions, lds, g_tune.fwd_waves), (unsigned)regions);
+  return (int)grid.x < N ? launch_zbuf_fwd_p<OWNER, VEC4, POW2, true>(sp, N, J, H, W, depth, argmin, rows, lds, grid, s)
+                         : launch_zbuf_fwd_p<OWNER, VEC4, POW2, false>(sp, N, J, H, W, depth, argmin, rows, lds, grid, s);
 }
 
 template <bool OWNER, bool VEC4>
@@ -86,17 +121,25 @@ int launch_zbuf_fwd(const float4 *sp, int N, int J, int H, int W, float *depth, 
              : launch_zbuf_fwd_t<OWNER, VEC4, false>(sp, N, J, H, W, depth, argmin, rows, s);
 }
 
+template <bool VEC4, bool POW2, bool PERSIST>
+int launch_zbuf_bwd_p(const float4 *sp, const float *grad, const uint8_t *argmin, int N, int J, int H, int W, float4 *gs,
+                      int rows, size_t lds, int gridx, hipStream_t s) {
+  static AttrDone attr_done;
+  auto k = sphere_zbuf_bwd_kernel<VEC4, POW2, PERSIST>;
+  const hipError_t e = allow_big_lds(k, &attr_done);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k, dim3((unsigned)gridx), dim3(64 * kZWaves), lds, s, sp, grad, argmin, N, J, H, W, gs, rows,
+                     log2_if_pow2(W / 4), g_tune.bwd_shares);
+  return (int)hipGetLastError();
+}
+
 template <bool VEC4, bool POW2>
 int launch_zbuf_bwd_t(const float4 *sp, const float *grad, const uint8_t *argmin, int N, int J, int H, int W,
                       float4 *gs, int rows, hipStream_t s) {
-  static AttrDone attr_done;
-  auto k = sphere_zbuf_bwd_kernel<VEC4, POW2>;
-  const hipError_t e = allow_big_lds(k, &attr_done);
-  if (e != hipSuccess) return (int)e;
   const size_t lds = kHdrBytes + kPartBytes + (size_t)(rows + kPadRows) * (W + kRowPad) * 5;
-  hipLaunchKernelGGL(k, dim3((unsigned)N), dim3(64 * kZWaves), lds, s, sp, grad, argmin, J, H, W, gs, rows,
-                     log2_if_pow2(W / 4), g_tune.bwd_shares);
-  return (int)hipGetLastError();
+  const int gridx = persistent_grid(N, 1, lds, kZWaves);
+  return gridx < N ? launch_zbuf_bwd_p<VEC4, POW2, true>(sp, grad, argmin, N, J, H, W, gs, rows, lds, gridx, s)
+                   : launch_zbuf_bwd_p<VEC4, POW2, false>(sp, grad, argmin, N, J, H, W, gs, rows, lds, gridx, s);
 }
 
 template <bool VEC4>
@@ -118,6 +161,7 @@ extern "C" int shr_set_tuning(int key, int value) {
       if (value < 1 || value > 16) return SHR_EINVAL;
       g_tune.fwd_waves = value;
       return SHR_OK;
+    case SHR_TUNE_PERSISTENT: if (value < 0) return SHR_EINVAL; g_tune.persistent = value; return SHR_OK;
     case SHR_TUNE_D2M_WAVES: return d2m_set_waves(value);
     case SHR_TUNE_D2M_BAND_UNITS: return d2m_set_band_units(value);
     case SHR_TUNE_FWD_SHARES:
@@ -245,20 +289,22 @@ extern "C" int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, 
   if (rows <= 0 || (H + rows - 1) / rows > 65535) return SHR_ETOOLARGE;
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = kHdrBytes + kPartBytes + (size_t)rows * (W + kRowPad) * 8;
+  // (persistent workgroups measured no gain for this kernel -- its per-crop chain is longer and the observed image's
+  // first read follows an index load -- so it stays at one workgroup per crop and region: PERSIST = false)
   dim3 grid((unsigned)N, (unsigned)((H + rows - 1) / rows));
   static AttrDone attr_a, attr_b;
   if (is_pow2(W) && is_pow2(H)) {
-    auto k = sphere_zbuf_mse_kernel<true>;
+    auto k = sphere_zbuf_mse_kernel<true, false>;
     const hipError_t e = allow_big_lds(k, &attr_a);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), J, H, W, target,
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
                        target_index, depth, sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), rows,
                        log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares);
   } else {
-    auto k = sphere_zbuf_mse_kernel<false>;
+    auto k = sphere_zbuf_mse_kernel<false, false>;
     const hipError_t e = allow_big_lds(k, &attr_b);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), J, H, W, target,
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
                        target_index, depth, sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), rows,
                        log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares);
   }

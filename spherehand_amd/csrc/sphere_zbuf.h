@@ -53,11 +53,12 @@ constexpr int kPadRows = 0;   // rows after the region's last (none: a chunk nev
 constexpr int kBgWaves = 7;   // forward: waves that store the background rows before the first barrier
 // (storing them after the barrier instead, with smaller list shares for those waves, moves the barrier from 4.6 k
 // to 3.8 k cycles but the stores then cost the scan conversion more than that: measured 8.9 vs 8.6 us)
-// LDS header: spheres [64] float4 | work items [64] int4 | ends [64] int | flags
+// LDS header: spheres [64] float4 | work items [64] int4 | ends [64] int | flags | next crop's spheres [64] float4
 constexpr int kOffItems = 1024;
 constexpr int kOffEnds = 2048;
 constexpr int kOffFlags = 2304;
-constexpr int kHdrBytes = 2304 + 16;
+constexpr int kOffNext = 2304 + 16;       // [64] float4: the NEXT crop's records (persistent workgroups)
+constexpr int kHdrBytes = kOffNext + 1024;
 constexpr int kMaxFastWidth = 8192;  // 16-bit fields of the work items
 
 __device__ __forceinline__ uint32_t depth_key(float d) {
@@ -413,21 +414,36 @@ __device__ __forceinline__ void touched_rows(const float4 s, bool valid, const A
 // other waves fill that time with the z-buffer initialisation and then with the
 // BACKGROUND ROWS: rows no sphere's box touches (half of a hand crop) are stored straight
 // from registers before the first barrier and never pass through LDS or the decode.
-template <bool OWNER, bool VEC4, bool POW2>
+template <bool OWNER, bool VEC4, bool POW2, bool PERSIST>
 __global__ void __launch_bounds__(1024)
-sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
-                       float *__restrict__ depth, uint8_t *__restrict__ argmin, int rows_per_region,
-                       int w4_shift, int shares) {
+sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_,
+                       float *__restrict__ depth, uint8_t *__restrict__ argmin, int rows_per_region_,
+                       int w4_shift_, int shares) {
   using Key = typename KeyOf<OWNER>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
   int4 *s_items = reinterpret_cast<int4 *>(smem + kOffItems);
   int *s_ends = reinterpret_cast<int *>(smem + kOffEnds);
   int *s_flag = reinterpret_cast<int *>(smem + kOffFlags);
+  float4 *s_next = reinterpret_cast<float4 *>(smem + kOffNext);
   Key *zbuf = reinterpret_cast<Key *>(smem + kHdrBytes);
 
-  const int n = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // PERSISTENT workgroups: with more crops than the launch has workgroups (gridDim.x < N) a workgroup takes crops
+  // blockIdx.x, blockIdx.x + gridDim.x, ...  The youngest wave requests the NEXT crop's records right after the
+  // first barrier and parks them in LDS before the second one, so every crop but a workgroup's first starts with
+  // its records at hand (their first read is a 2-2.6 k-cycle round trip in front of everything else).  Worth 8 % of
+  // the forward at 36 crops per CU, nothing at 4.5 (the launcher decides: sphere_raster.hip persistent_grid).
+  const int crop_step = gridDim.x;
+  for (int n = blockIdx.x, crop_it = 0; PERSIST ? n < N : crop_it == 0; n += crop_step, ++crop_it) {
+  // Every crop starts from OPAQUE copies of the launch constants and of the thread index: otherwise the compiler
+  // hoists each crop-invariant value out of the crop loop and keeps it in a register (forward: 92 instead of 51
+  // VGPRs; the fused kernel spilled).
+  int J = J_, H = H_, W = W_, rows_per_region = rows_per_region_, w4_shift = w4_shift_, tid = threadIdx.x;
+  if (PERSIST) {
+    asm volatile("" : "+s"(J), "+s"(H), "+s"(W), "+s"(rows_per_region), "+s"(w4_shift));
+    asm volatile("" : "+v"(tid));
+  }
+  const int lane = tid & 63, wave = tid >> 6;
   const int nthr = blockDim.x, nwaves = nthr >> 6;
   const int r0 = blockIdx.y * rows_per_region;
   const int r1 = min(H, r0 + rows_per_region);
@@ -444,8 +460,9 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
   const int nbgw = min(kBgWaves, nwaves - 1);
   const bool bg_wave = nwaves == 1 || (wave_s >= 1 && wave_s <= nbgw);
   const bool valid = lane < J;
+  const bool pf_wave = wave_s == nwaves - 1 && !list_wave && !bg_wave;
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid && (list_wave || bg_wave)) sph = spheres[(size_t)n * J + lane];
+  if (valid && (list_wave || bg_wave)) sph = crop_it == 0 ? spheres[(size_t)n * J + lane] : s_next[lane];
 
   {  // background everywhere (pad rows/columns included); overlaps the read above
     const Key bg = OWNER ? (Key)(((unsigned long long)depth_key(kBackground) << 32) | SHR_ARGMIN_NONE)
@@ -535,12 +552,17 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
   if (VEC4 && bg_wave) store_background(nwaves == 1 ? 0 : wave_s - 1, nwaves == 1 ? 1 : nbgw);
   __syncthreads();
   if (!(list_wave || bg_wave)) sph = s_sph[lane];
+  const bool has_next = PERSIST && n + crop_step < N;   // (the launcher keeps a prefetch wave whenever gridDim.x < N)
+  float4 sph_next = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pf_wave && has_next && valid) sph_next = spheres[(size_t)(n + crop_step) * J + lane];
 
   if (s_flag[0]) {  // workgroup-uniform: this crop needs the general path
     const int tiles_x = (W + kTileW - 1) / kTileW;
     const int t0 = (r0 / kTileH) * tiles_x, t1 = ((r1 + kTileH - 1) / kTileH) * tiles_x;
     tile_forward<VEC4, OWNER>(sph, J, H, W, out, aout, tiles_x, t0 + wave, t1, nwaves, lane);
-    return;
+    if (pf_wave && has_next) s_next[lane] = sph_next;
+    __syncthreads();
+    continue;
   }
   if (VEC4) { ua = rfl(s_flag[2]); ub = rfl(s_flag[3]); }
 
@@ -578,6 +600,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
         },
         [](int) {});
   }
+  if (pf_wave && has_next) s_next[lane] = sph_next;   // (arrived long ago: the wave's own scan slice lies in between)
   __syncthreads();
 
   // ---- stream the touched rows out ---------------------------------------------------
@@ -614,6 +637,8 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int J, int H, int W,
       }
     }
   }
+  if (PERSIST && n + crop_step < N) __syncthreads();   // the z-buffer is re-initialised next: every wave's stream-out reads are done
+  }  // crops
 }
 
 // ---------------------------------------------------------------------------
@@ -624,25 +649,34 @@ constexpr int kPartBytes = kZWaves * SHR_MAX_SPHERES * 16;
 constexpr int kStageBatch = 4;   // backward: units (16-byte chunks per lane) requested per wait while staging
 constexpr int kSpecUnits = 2;    // ... and units per wave requested before the touched rows are known
 
-template <bool VEC4, bool POW2>
+template <bool VEC4, bool POW2, bool PERSIST>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restrict__ grad_depth,
-                       const uint8_t *__restrict__ argmin, int J, int H, int W,
-                       float4 *__restrict__ grad_spheres, int rows_per_region, int w4_shift, int shares) {
+                       const uint8_t *__restrict__ argmin, int N, int J_, int H_, int W_,
+                       float4 *__restrict__ grad_spheres, int rows_per_region_, int w4_shift_, int shares) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
   int4 *s_items = reinterpret_cast<int4 *>(smem + kOffItems);
   int *s_ends = reinterpret_cast<int *>(smem + kOffEnds);
   int *s_flag = reinterpret_cast<int *>(smem + kOffFlags);
+  float4 *s_next = reinterpret_cast<float4 *>(smem + kOffNext);
   float4 *s_part = reinterpret_cast<float4 *>(smem + kHdrBytes);
+  // PERSISTENT workgroups (gridDim.x < N: crops blockIdx.x, blockIdx.x + gridDim.x, ...): the youngest wave requests
+  // the next crop's records after the staging barrier and parks them in LDS (see the forward).
+  const int crop_step = gridDim.x;
+  for (int n = blockIdx.x, crop_it = 0; PERSIST ? n < N : crop_it == 0; n += crop_step, ++crop_it) {
+  // Every crop starts from OPAQUE copies of the launch constants and of the thread index: otherwise the compiler
+  // hoists each crop-invariant value out of the crop loop and keeps it in a register (forward: 92 instead of 51
+  // VGPRs; the fused kernel spilled).
+  int J = J_, H = H_, W = W_, rows_per_region = rows_per_region_, w4_shift = w4_shift_, tid = threadIdx.x;
+  if (PERSIST) {
+    asm volatile("" : "+s"(J), "+s"(H), "+s"(W), "+s"(rows_per_region), "+s"(w4_shift));
+    asm volatile("" : "+v"(tid));
+  }
+  const int lane = tid & 63, wave = tid >> 6;
   const int LW = W + kRowPad;
   float *gbuf = reinterpret_cast<float *>(smem + kHdrBytes + kPartBytes);
   uint8_t *obuf = smem + kHdrBytes + kPartBytes + (size_t)(rows_per_region + kPadRows) * LW * 4;
-
-  const int n = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float *gin = grad_depth + (size_t)n * H * W;
-  const uint8_t *oin = argmin + (size_t)n * H * W;
   const Axis ax = make_axis(W), ay = make_axis(H);
   const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
   typedef float v4f __attribute__((ext_vector_type(4)));
@@ -653,12 +687,22 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   // the memory queue) read the records: wave 0 builds the work list, waves 1-3 derive the touched
   // rows and request what step 2 of the staging needs, for the whole workgroup.  A young wave's
   // copy of the records arrived up to 3 k cycles later and held the barrier.
-  const float4 *rec = spheres + (size_t)n * J;
   const bool lead = wave_s < 4, p2_wave = wave_s >= 1 && wave_s < 4;
-  v4f sphv = {0.f, 0.f, 0.f, 0.f};
-  if (lead) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sphv) : "v"(rec + min(lane, J - 1)));
+  const bool pf_wave = wave_s == kZWaves - 1;
+  const float *gin = grad_depth + (size_t)n * H * W;
+  const uint8_t *oin = argmin + (size_t)n * H * W;
+  const float4 *rec = spheres + (size_t)n * J;
+  const bool has_next = PERSIST && n + crop_step < N;
+  v4f sphv = {0.f, 0.f, 0.f, 0.f}, nextv = {0.f, 0.f, 0.f, 0.f};
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
   bool have_sph = false;
+  if (crop_it == 0) {
+    if (lead) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sphv) : "v"(rec + min(lane, J - 1)));
+  } else if (lead) {
+    if (lane < J) sph = s_next[lane];
+    have_sph = true;
+    if (wave_s == 0) s_sph[lane] = sph;
+  }
   s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // 1024 = 16 waves x 64 spheres
 
   for (int r0 = 0; r0 < H; r0 += rows_per_region) {
@@ -789,6 +833,8 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
       }
     }
     __syncthreads();
+    if (pf_wave && has_next && r0 == 0)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nextv) : "v"(spheres + (size_t)(n + crop_step) * J + min(lane, J - 1)));
 
     // Static schedule: wave w walks the w-th of 16 equal-weight contiguous slices of the
     // list (which wave sums which pixels must not depend on timing); at the end of a
@@ -827,6 +873,10 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
           a0 = a1 = a2 = a3 = 0.f;
         });
   }
+  if (pf_wave && has_next) {   // (arrived long ago: the wave's own walk lies in between)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(nextv) : : "memory");
+    s_next[lane] = make_float4(nextv.x, nextv.y, nextv.z, nextv.w);
+  }
   __syncthreads();
   // combine the waves' partials in wave order; d/dr = r * sum(-g/sqrt(q))
   if (tid < J) {
@@ -839,6 +889,8 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     const v4u_t tt = {__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w)};
     asm_store16<SHR_BWD_STORE_MODE>(grad_spheres + (size_t)n * J + tid, tt);
   }
+  if (has_next) __syncthreads();   // the partials are zeroed and the staging buffers refilled next
+  }  // crops
 }
 
 // ---------------------------------------------------------------------------
@@ -859,37 +911,52 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
 // tiles like sphere_tile_bwd_kernel with the gradient formed in registers.
 constexpr int kSphereCostMse = 28;
 
-template <bool POW2>
+template <bool POW2, bool PERSIST>
 __global__ void __launch_bounds__(1024)
-sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, const float *__restrict__ target,
+sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_, const float *__restrict__ target,
                        const int *__restrict__ target_index, float *__restrict__ depth,
-                       float *__restrict__ sse_out, float4 *__restrict__ grad_out, int rows_per_region,
-                       int w4_shift, int shares_fwd, int shares_bwd) {
+                       float *__restrict__ sse_out, float4 *__restrict__ grad_out, int rows_per_region_,
+                       int w4_shift_, int shares_fwd, int shares_bwd) {
   using Key = unsigned long long;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
   int4 *s_items = reinterpret_cast<int4 *>(smem + kOffItems);
   int *s_ends = reinterpret_cast<int *>(smem + kOffEnds);
   int *s_flag = reinterpret_cast<int *>(smem + kOffFlags);
+  float4 *s_next = reinterpret_cast<float4 *>(smem + kOffNext);
   float4 *s_part = reinterpret_cast<float4 *>(smem + kHdrBytes);
   Key *zbuf = reinterpret_cast<Key *>(smem + kHdrBytes + kPartBytes);
 
-  const int n = blockIdx.x, region = blockIdx.y, nregions = gridDim.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // PERSISTENT workgroups (gridDim.x < N: crops blockIdx.x, blockIdx.x + gridDim.x, ... of this region): the youngest
+  // wave requests the next crop's records after the first barrier and parks them in LDS (see the forward).
+  const int crop_step = gridDim.x;
+  for (int n = blockIdx.x, crop_it = 0; PERSIST ? n < N : crop_it == 0; n += crop_step, ++crop_it) {
+  // Every crop starts from OPAQUE copies of the launch constants and of the thread index: otherwise the compiler
+  // hoists each crop-invariant value out of the crop loop and keeps it in a register (forward: 92 instead of 51
+  // VGPRs; the fused kernel spilled).
+  int J = J_, H = H_, W = W_, rows_per_region = rows_per_region_, w4_shift = w4_shift_, tid = threadIdx.x;
+  if (PERSIST) {
+    asm volatile("" : "+s"(J), "+s"(H), "+s"(W), "+s"(rows_per_region), "+s"(w4_shift));
+    asm volatile("" : "+v"(tid));
+  }
+  const int region = blockIdx.y, nregions = gridDim.y;
+  const int lane = tid & 63, wave = tid >> 6;
   const int r0 = region * rows_per_region;
   const int r1 = min(H, r0 + rows_per_region);
   const int rh = r1 - r0;
   const int LW = W + kRowPad;
   const Axis ax = make_axis(W), ay = make_axis(H);
   const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
-  const float *tgt = target + (size_t)(target_index ? target_index[n] : n) * H * W + (size_t)r0 * W;
-  float *out = depth ? depth + (size_t)n * H * W + (size_t)r0 * W : nullptr;
-
   const int wave_s = rfl(wave);
   const bool bg_wave = wave_s >= 1 && wave_s <= kBgWaves;
   const bool valid = lane < J;
+  const bool pf_wave = wave_s == kZWaves - 1;
+  const float *tgt = target + (size_t)(target_index ? target_index[n] : n) * H * W + (size_t)r0 * W;
+  float *out = depth ? depth + (size_t)n * H * W + (size_t)r0 * W : nullptr;
+  const bool has_next = PERSIST && n + crop_step < N;
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid && (wave_s == 0 || bg_wave)) sph = spheres[(size_t)n * J + lane];   // the others: wave 0's LDS copy, later
+  if (valid && (wave_s == 0 || bg_wave))   // the others: wave 0's LDS copy, later
+    sph = crop_it == 0 ? spheres[(size_t)n * J + lane] : s_next[lane];
   s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // 1024 = 16 waves x 64 spheres
   {  // background everywhere
     const Key bg = ((Key)depth_key(kBackground) << 32) | SHR_ARGMIN_NONE;
@@ -943,6 +1010,8 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
   }
   __syncthreads();
   if (!(wave_s == 0 || bg_wave)) sph = s_sph[lane];
+  float4 sph_next = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pf_wave && has_next && valid) sph_next = spheres[(size_t)(n + crop_step) * J + lane];
   const bool general = s_flag[0] != 0;
   ua = rfl(s_flag[2]);
   ub = rfl(s_flag[3]);
@@ -972,6 +1041,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
           }
         },
         [](int) {});
+    if (pf_wave && has_next) s_next[lane] = sph_next;
     __syncthreads();
 
     // ---- convert: error, its square, gradient image in place ---------------------------------
@@ -1103,6 +1173,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
     }
   }
 
+  if (general && pf_wave && has_next) s_next[lane] = sph_next;
   // ---- reductions: waves in order --------------------------------------------------------------
   sse = wave_sum_lane63(sse);
   __syncthreads();
@@ -1124,6 +1195,8 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int J, int H, int W, 
     t.w = t.w * s_sph[tid].w;
     grad_out[slot * J + tid] = t;
   }
+  if (has_next) __syncthreads();   // records, work list, partials and z-buffer are rewritten next
+  }  // crops
 }
 
 }  // namespace shr

@@ -218,3 +218,37 @@ def test_sqrt_rn_exhaustive():
                "shr_selftest_sqrt")
     assert int(bad.item()) == 0
     assert hi - lo > 350_000_000
+
+
+@pytest.mark.parametrize("S,wgs", [(64, 3), (128, 5), (256, 2)])
+def test_persistent_workgroups_equal_one_workgroup_per_crop(oracle, S, wgs):
+    """More crops than workgroups: a workgroup walks crops b, b + G, ... with the next crop's records prefetched.
+    Same bits as one workgroup per crop (and as the oracle), including crops that take the general path in the
+    middle of a workgroup's sequence (a NaN sphere; all spheres behind the background)."""
+    from spherehand_amd import ops
+    rs = np.random.RandomState(S)
+    n, J = 23, 41
+    sp = np.zeros((n, J, 4), np.float32)
+    sp[..., 0:2] = rs.uniform(-90, 90, (n, J, 2)); sp[..., 2] = rs.uniform(-40, 40, (n, J)); sp[..., 3] = rs.uniform(8, 24, (n, J))
+    sp[4, 7, 0] = np.nan                      # general path
+    sp[9, :, 2] = 150.0                       # no sphere in front of the background: general path
+    sp[10:12, :, 0] = 1e4                     # nothing on screen
+    d_sp = torch.from_numpy(sp).cuda()
+    g = torch.from_numpy(rs.standard_normal((n, S, S)).astype(np.float32)).cuda()
+    res = {}
+    for mode in (0, wgs):
+        ops.set_tuning(ops.TUNE_PERSISTENT, mode)
+        d, o = ops.sphere_raster_fwd(d_sp, S, S, want_argmin=True)
+        d2 = ops.sphere_raster_fwd(d_sp, S, S)
+        gs = ops.sphere_raster_bwd(d_sp, g, o)
+        tgt = torch.full((5, S, S), 100.0, device="cuda"); tgt[:, S // 4:3 * S // 4, S // 4:3 * S // 4] = -5.0
+        tidx = (torch.arange(n, device="cuda", dtype=torch.int32) % 5).contiguous()
+        fd, fsse, fgrad = ops.sphere_raster_mse(d_sp, tgt, tidx)                       # fused render-and-compare
+        res[mode] = [t.cpu().numpy() for t in (d, o, d2, gs, fd, fsse, fgrad)]
+    ops.set_tuning(ops.TUNE_PERSISTENT, 1)
+    for a, b in zip(res[0], res[wgs]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    ref = oracle.sphere_raster_fwd(sp, S, S, want_argmin=False)
+    ok = ~np.isnan(ref)                                  # (a NaN's payload is not part of the contract)
+    assert np.array_equal(np.isnan(res[wgs][0]), ~ok)
+    assert np.array_equal(res[wgs][0][ok].view(np.uint32), ref[ok].view(np.uint32))
