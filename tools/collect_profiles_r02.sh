@@ -26,6 +26,9 @@ for S in 128 256; do
 done
 timeout 300 python bench.py > "$O/bench_line.json" 2> "$O/bench_line.err"
 timeout 300 python bench.py --launch graph --no-secondary --no-cpu-baseline > "$O/bench_line_graph.json" 2>> "$O/bench_line.err"
+# summarise on the box and drop the raw counter / trace CSVs (gpurun merges at most 64 MiB back)
+python tools/summarize_r02.py gpurun_out/r02_profiles > "$O/summarize.log" 2>&1
+find "$O" -name "*counter_collection.csv" -delete; find "$O" -name "*kernel_trace.csv" -delete
 find "$O" -name "*kernel_stats.csv" | head -3
 tail -1 "$O/bench_line.json" | cut -c1-200
 du -sh "$O"

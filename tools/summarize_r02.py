@@ -1,7 +1,9 @@
 """gpurun_out/r02 (tools/collect_profiles_r02.sh) -> profiles/r02_*: python tools/summarize_r02.py"""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-O, P = os.path.join(ROOT, "gpurun_out", "r02"), os.path.join(ROOT, "profiles")
+O = os.path.join(ROOT, "gpurun_out", "r02")
+P = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles")
+os.makedirs(P, exist_ok=True)
 
 def shr_rows(src, dst, keep=lambda name: True):
     rows = list(csv.reader(open(src)))
