@@ -3,6 +3,9 @@ import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from spherehand_amd import _lib
+if os.environ.get("SHR_LIB"):          # an experiment build of the library (SHR_HIPCC_EXTRA=-D... python -m spherehand_amd.build)
+    _lib.SO_PATH = os.environ["SHR_LIB"]
 import bench
 from spherehand_amd import ops
 dev = torch.device("cuda:0")
@@ -20,13 +23,13 @@ def t_us(fn, reps=600):
         best = min(best, e0.elapsed_time(e1) / reps * 1e3)
     return best
 depth, owner = ops.sphere_raster_fwd(spheres, 128, 128, want_argmin=True)
-from spherehand_amd import _lib
 L = _lib.lib()
 st = torch.cuda.current_stream().cuda_stream
 gs = torch.empty(256, 41, 4, device=dev)
 def pack(a): return a[0] | a[1] << 8 | a[2] << 16 | a[3] << 24
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-cands = [(88, 72, 56, 40), (84, 70, 58, 44), (90, 74, 58, 34), (86, 72, 58, 40), (92, 72, 54, 38), (88, 76, 54, 38),
+cands = [(64, 64, 64, 64), (72, 68, 60, 56), (56, 60, 68, 72), (48, 56, 72, 80), (60, 56, 72, 68), (76, 60, 64, 56), (80, 64, 60, 52),
+         (88, 72, 56, 40), (84, 70, 58, 44), (90, 74, 58, 34), (86, 72, 58, 40), (92, 72, 54, 38), (88, 76, 54, 38),
          (84, 74, 58, 40), (80, 72, 60, 44), (88, 68, 58, 42), (92, 76, 56, 32), (86, 70, 56, 44), (82, 70, 60, 44),
          (88, 72, 60, 36), (84, 72, 56, 44), (90, 70, 56, 40), (86, 74, 56, 40)]
 for c in cands:
