@@ -42,9 +42,8 @@ class HeatmapEstimationNetwork(nn.Module):
 
     def _augment(self, dms):
         n = dms.shape[0]
-        ones = torch.ones(n, device=dms.device)
         if self.resize_dm is None or not self.training or torch.rand(1).item() < 0.5:
-            return dms, ones, ones
+            return dms, None, None          # unit scales: nothing to undo on the way out
         scale = torch.rand(n, device=dms.device) * 0.2 + 0.75
         u_scale = scale + torch.rand_like(scale) * 0.1 - 0.05
         v_scale = scale + torch.rand_like(scale) * 0.1 - 0.05
@@ -54,8 +53,10 @@ class HeatmapEstimationNetwork(nn.Module):
         return [o[:, :self.num_joints] for o in outputs], [o[:, self.num_joints:] for o in outputs]
 
     def _real_result(self, outputs, uv_hms, d_hms, u_scale, v_scale, B, V):
-        inv = torch.stack([1.0 / u_scale, 1.0 / v_scale, torch.ones_like(u_scale)], dim=-1).unsqueeze(1)
-        xyz = [self.xyz_recover.from_output(o) * inv for o in outputs]
+        xyz = [self.xyz_recover.from_output(o) for o in outputs]
+        if u_scale is not None:
+            inv = torch.stack([1.0 / u_scale, 1.0 / v_scale, torch.ones_like(u_scale)], dim=-1).unsqueeze(1)
+            xyz = [p * inv for p in xyz]
         shape5 = lambda h: h.reshape(B, V, self.num_joints, h.shape[-2], h.shape[-1])   # noqa: E731
         return {'real_uv_hms': [shape5(h) for h in uv_hms], 'real_d_hms': [shape5(h) for h in d_hms],
                 'real_xyz': [p.reshape(B, V, self.num_joints, 3) for p in xyz]}
@@ -113,56 +114,113 @@ class MultiTaskLoss(nn.Module):
             self.register_buffer('_bone_max', bl.max_length.reshape(-1).clone(), persistent=False)
         self.domain_loss = nn.MSELoss()
         self.heatmap_size = heatmap_size
+        self._weight_cache = (None, None)
         self.weights = {'synt_hm': 1e3, 'synt_pt': 1e-1, 'mv_consistency': 1e-3, 'mv_projection': 1,
                         'temporal_smooth': 1.0, 'prior': 1e-2, 'hm_mean': 1e-2, 'domain': 0.0,
                         'collision': 1.0, 'bone_length': 1.0}
 
     def forward(self, result, synt_target=None, real_target=None):
-        w, terms, projected_dms = self.weights, {}, []
+        w, projected_dms = self.weights, []
+        entries = []            # (term, weight, its value per hourglass stack); weighed and summed in one go below
         mse = self.synthesized_loss
         if mse is not None and synt_target is not None:
-            terms['synt_uv'] = sum(w['synt_hm'] * mse(h, synt_target['uv_hms']) for h in result['synt_uv_hms'])
+            entries.append(('synt_uv', w['synt_hm'], [mse(h, synt_target['uv_hms']) for h in result['synt_uv_hms']]))
             target_z = synt_target['xyz_pts'][:, :, 2]
-            terms['synt_d'] = sum(w['synt_pt'] * mse(xyz[:, :, 2], target_z) for xyz in result['synt_xyz'])
+            entries.append(('synt_d', w['synt_pt'], [mse(xyz[:, :, 2], target_z) for xyz in result['synt_xyz']]))
         is_mv = False if real_target is None else real_target.get('is_mv', True)
         if self.mv_projection_loss is not None and real_target is not None:
-            terms['mv_projection'] = 0
+            values = []
             for xyz in result['real_xyz']:
                 loss, dm = self.mv_projection_loss(real_target['camera_poses'], real_target['inv_camera_poses'], xyz,
                                                    real_target['real_dms'], is_mv)
-                terms['mv_projection'] = terms['mv_projection'] + loss * w['mv_projection']
+                values.append(loss)
                 projected_dms.append(dm)
+            entries.append(('mv_projection', w['mv_projection'], values))
         if self.mv_consistency_loss is not None and real_target is not None:
-            wc = w['mv_consistency'] if is_mv else 0
-            terms['mv_consistency'] = sum(wc * self.mv_consistency_loss(real_target['camera_poses'], xyz, None)
-                                          for xyz in result['real_xyz'])
+            entries.append(('mv_consistency', w['mv_consistency'] if is_mv else 0,
+                            [self.mv_consistency_loss(real_target['camera_poses'], xyz, None)
+                             for xyz in result['real_xyz']]))
         if real_target is not None:
             # like the reference this term needs the MSE criterion of the synthetic switch (:235)
-            terms['uv_hm_mean'] = sum(w['hm_mean'] * mse(h, torch.zeros_like(h)) for h in result['real_uv_hms'])
+            # MSELoss(h, zeros_like(h)) = mean(h^2): the same value without the zero image and the subtraction
+            entries.append(('uv_hm_mean', w['hm_mean'], [h.square().mean() for h in result['real_uv_hms']]))
         real_xyz = result.get('real_xyz', [])
         if self.prior_loss is not None:
-            terms['pose_prior'] = sum(w['prior'] * self.prior_loss.prior_loss(xyz / 100.0) for xyz in real_xyz)
+            entries.append(('pose_prior', w['prior'], [self.prior_loss.prior_loss(xyz / 100.0) for xyz in real_xyz]))
         if self.temporal_smooth_loss is not None:
-            terms['temporal_smooth'] = sum(w['temporal_smooth'] * self.temporal_smooth_loss(xyz) for xyz in real_xyz)
+            entries.append(('temporal_smooth', w['temporal_smooth'],
+                            [self.temporal_smooth_loss(xyz) for xyz in real_xyz]))
         cc, bc = self.collision_criterion, self.bone_length_criterion
         if cc is not None and bc is not None and real_xyz and real_xyz[0].is_cuda and real_xyz[0].dtype == torch.float32:
             # both hinge losses and their gradients in one launch (same indexing as the modules: the first 41
             # points of joints.view(B, -1, 3))
             pairs = [ops.PairLosses.apply(xyz.reshape(xyz.shape[0], -1, 3), 41, 11, 6, float(cc.min_sq_dist),
                                           self._bone_a, self._bone_b, self._bone_min, self._bone_max) for xyz in real_xyz]
-            terms['collision'] = sum(w['collision'] * p[0] for p in pairs)
-            terms['bone_length'] = sum(w['bone_length'] * p[1] for p in pairs)
+            entries.append(('collision', w['collision'], [p[0] for p in pairs]))
+            entries.append(('bone_length', w['bone_length'], [p[1] for p in pairs]))
         else:
             if cc is not None:
-                terms['collision'] = sum(w['collision'] * cc(xyz) for xyz in real_xyz)
+                entries.append(('collision', w['collision'], [cc(xyz) for xyz in real_xyz]))
             if bc is not None:
-                terms['bone_length'] = sum(w['bone_length'] * bc(xyz) for xyz in real_xyz)
+                entries.append(('bone_length', w['bone_length'], [bc(xyz) for xyz in real_xyz]))
         if 'batch_synt_fea' in result and 'batch_real_fea' in result:
-            terms['domain_loss'] = sum(
-                w['domain'] * self.domain_loss(s.mean(dim=(0, 2, 3)), r.mean(dim=(0, 2, 3)))
-                for s, r in zip(result['batch_synt_fea'], result['batch_real_fea']))
-        return terms, projected_dms
+            if w['domain'] == 0.0:
+                # the reference's weight is 0 (create_network...:180): the term is reported as 0 and has no gradient;
+                # evaluating the two feature means and their MSE for it cost ~16 launches per step
+                entries.append(('domain_loss', 0.0, None))
+            else:
+                entries.append(('domain_loss', w['domain'],
+                                [self.domain_loss(s.mean(dim=(0, 2, 3)), r.mean(dim=(0, 2, 3)))
+                                 for s, r in zip(result['batch_synt_fea'], result['batch_real_fea'])]))
+        return self._weigh(entries), projected_dms
+
+    def _weigh(self, entries):
+        """term = sum over the stacks of weight * value (the reference's sums at :196-262), evaluated for all terms
+        at once: one stack, one multiply by the cached weight vector, one row sum -- instead of a multiply and an add
+        per term and stack (and as many again in the backward).  Returns a LossTerms dict whose `.stacked` is the [K]
+        tensor the values are views of."""
+        live = [(name, wt, vals) for name, wt, vals in entries if vals]
+        depth = {len(vals) for _, _, vals in live}
+        if not live or len(depth) != 1:         # no tensors, or ragged stacks: term by term
+            return LossTerms((name, sum(wt * v for v in vals) if vals else 0) for name, wt, vals in entries)
+        S, ref = depth.pop(), live[0][2][0]
+        zero = None
+        rows, weights = [], []
+        for name, wt, vals in entries:
+            if not vals:                        # reported as 0: a row of zeros with weight 0
+                zero = ref.new_zeros(()) if zero is None else zero
+                vals = [zero] * S
+                wt = 0.0
+            rows.extend(v.reshape(()) for v in vals)
+            weights.append(float(wt))
+        key = (tuple(weights), ref.device, ref.dtype)
+        if self._weight_cache[0] != key:
+            self._weight_cache = (key, torch.tensor(weights, device=ref.device, dtype=ref.dtype).unsqueeze(1))
+        stacked = (torch.stack(rows).view(len(entries), S) * self._weight_cache[1]).sum(dim=1)
+        terms = LossTerms(zip((name for name, _, _ in entries), stacked.unbind(0)))
+        terms.stacked = stacked
+        return terms
 
 
-def combine_loss(loss_terms):
-    return sum(loss_terms.values())
+class LossTerms(dict):
+    """The loss terms by name; `.stacked` (when set) is the [K] tensor holding them in order, so the total and the
+    running averages need no second stack."""
+    stacked = None
+
+
+def stack_terms(loss_terms):
+    """The terms as one [K] tensor (python numbers become constants): one launch feeds both the total loss and the
+    running averages."""
+    stacked = getattr(loss_terms, 'stacked', None)
+    if stacked is not None and stacked.numel() == len(loss_terms):
+        return stacked
+    vals = list(loss_terms.values())
+    ref = next((v for v in vals if torch.is_tensor(v)), None)
+    if ref is None:
+        return torch.tensor([float(v) for v in vals])
+    return torch.stack([v.reshape(()).to(ref.dtype) if torch.is_tensor(v) else ref.new_tensor(float(v)) for v in vals])
+
+
+def combine_loss(loss_terms, stacked=None):
+    """Sum of the terms (network/engine.py: sum_loss_terms); `stacked` = stack_terms(loss_terms) if already made."""
+    return (stack_terms(loss_terms) if stacked is None else stacked).sum()

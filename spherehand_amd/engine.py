@@ -24,7 +24,7 @@ import torch
 import torch.distributed as dist
 import torch.utils.data as data
 
-from .criterion import HeatmapEstimationNetwork, MultiTaskLoss, average_joint_error, combine_loss
+from .criterion import HeatmapEstimationNetwork, MultiTaskLoss, average_joint_error, combine_loss, stack_terms
 from .hand_model import load_mesh
 from .joint_angle import JointAngleDataset
 from .pose_denoiser import default_pose_denoiser
@@ -52,22 +52,37 @@ class Constant:
 
 
 class RunningAverage:
-    """Mean of per-step dicts of 0-dim tensors, kept on the device."""
+    """Mean of per-step dicts of 0-dim tensors, kept on the device as ONE [K] tensor (one launch per step; the
+    reference converts every term to a python float every step: a device sync each, network/engine.py:40)."""
 
     def __init__(self):
-        self.num, self.sum = 0, None
+        self.num, self.keys, self.total = 0, None, None
 
-    def append(self, terms):
-        vals = {k: (v.detach() if torch.is_tensor(v) else torch.as_tensor(float(v))) for k, v in terms.items()}
-        if self.sum is None:
-            self.sum = {k: v.clone().float() for k, v in vals.items()}
+    def append(self, terms, stacked=None):
+        """`stacked` = criterion.stack_terms(terms) if the caller already has it."""
+        if stacked is None:
+            from .criterion import stack_terms
+            stacked = stack_terms(terms)
+        stacked = stacked.detach().float()
+        if self.total is None or list(terms) != self.keys:
+            if self.total is not None:          # the set of terms changed (e.g. another epoch type): fold by name
+                old = dict(zip(self.keys, self.total.unbind(0)))
+                keys = list(dict.fromkeys(self.keys + list(terms)))
+                new = dict(zip(terms, stacked.unbind(0)))
+                zero = stacked.new_zeros(())
+                self.total = torch.stack([old.get(k, zero) + new.get(k, zero).to(self.total.device) for k in keys])
+                self.keys = keys
+            else:
+                self.keys, self.total = list(terms), stacked.clone()
         else:
-            for k, v in vals.items():
-                self.sum[k] = self.sum[k] + v.to(self.sum[k].device)
+            self.total = self.total + stacked.to(self.total.device)
         self.num += 1
 
     def means(self):
-        return {} if self.sum is None else {k: float(v) / self.num for k, v in self.sum.items()}
+        if self.total is None:
+            return {}
+        vals = (self.total.double() / self.num).tolist()      # one device -> host copy
+        return dict(zip(self.keys, vals))
 
     def __str__(self):
         return ' '.join('{}: {:.4f}'.format(k, v) for k, v in self.means().items())
@@ -279,8 +294,10 @@ class Engine:
                         gt_joints[:, 0].unsqueeze(1), self.pose_denoiser(est[:, 0]).unsqueeze(1))
             else:
                 metrics['avg_joint_error'] = average_joint_error(gt_joints, est)
+        stacked = stack_terms(loss_terms)           # one launch: the total loss below and the running averages share it
+        self._last_stacked = stacked.detach()
         if train:
-            combine_loss(loss_terms).backward()
+            combine_loss(loss_terms, stacked).backward()
             self.optimizer.step()
         return loss_terms, metrics, result, projected
 
@@ -307,7 +324,7 @@ class Engine:
             pose = next(pose_it) if pose_it is not None else None
             with torch.set_grad_enabled(train):
                 terms, metrics, _, _ = self.step(real, pose, train, is_mv=(it < 1500) if with_synt else True)
-            losses.append(terms)
+            losses.append(terms, self._last_stacked)
             if metrics:
                 metrics_avg.append(metrics)
             if it % self.log_every == 0:
