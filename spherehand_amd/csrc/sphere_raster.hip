@@ -17,6 +17,8 @@ struct Tuning {
   int fwd_waves = 16;                   // waves per forward workgroup
   int fwd_shares = 0x28384858;          // work-list shares of the four wave age groups, oldest in the low byte (sum 256)
   int bwd_shares = 0x2c3a4654;
+  int lds_pad = 0;                      // experiments: extra dynamic LDS per zbuf workgroup (forces one workgroup per CU)
+  int fwd_zbuf_bytes = 0;               // forward z-buffer bytes per workgroup; 0 = by launch size (launch_zbuf_fwd_t)
   int persistent = 1;                   // 0: one workgroup per crop; 1: persistent workgroups when N exceeds the device; > 1: that many
 } g_tune;
 
@@ -82,6 +84,9 @@ int num_cus() {
 int persistent_grid(int N, int regions, size_t lds, int nwaves) {
   if (g_tune.persistent == 0 || nwaves <= kBgWaves + 1) return N;
   const int per_cu = (int)(kMaxLds / (lds ? lds : 1)) > 0 ? (int)(kMaxLds / lds) : 1;
+  // two resident workgroups per CU already overlap one crop's prologue with another's scan: persistent workgroups
+  // measured slower there (depth-only forward at 9216 crops: 5.5 vs 4.2 us per 256 crops, tools/exp_twocu.py)
+  if (per_cu >= 2 && g_tune.persistent == 1) return N;
   long long cap = (long long)num_cus() * per_cu / (regions > 0 ? regions : 1);
   if (cap < 1) cap = 1;
   if (g_tune.persistent > 1) return N > g_tune.persistent ? g_tune.persistent : N;   // tests / experiments: explicit count
@@ -93,24 +98,39 @@ int persistent_grid(int N, int regions, size_t lds, int nwaves) {
 
 template <bool OWNER, bool VEC4, bool POW2, bool PERSIST>
 int launch_zbuf_fwd_p(const float4 *sp, int N, int J, int H, int W, float *depth, uint8_t *argmin, int rows, size_t lds,
-                      dim3 grid, hipStream_t s) {
+                      int zcells, dim3 grid, hipStream_t s) {
   static AttrDone attr_done;
   auto k = sphere_zbuf_fwd_kernel<OWNER, VEC4, POW2, PERSIST>;
   const hipError_t e = allow_big_lds(k, &attr_done);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k, grid, dim3(64 * g_tune.fwd_waves), lds, s, sp, N, J, H, W, depth, argmin, rows,
-                     log2_if_pow2(W / 4), g_tune.fwd_shares);
+                     log2_if_pow2(W / 4), g_tune.fwd_shares, zcells);
   return (int)hipGetLastError();
 }
 
 template <bool OWNER, bool VEC4, bool POW2>
 int launch_zbuf_fwd_t(const float4 *sp, int N, int J, int H, int W, float *depth, uint8_t *argmin, int rows,
                       hipStream_t s) {
-  const size_t lds = kHdrBytes + (size_t)(rows + kPadRows) * (W + kRowPad) * (OWNER ? 8 : 4);
+  // LDS per workgroup.  `full` holds any touched box of a region in one pass (pick_rows sized the regions for it).
+  // With at least two workgroups per CU in the launch a workgroup gets HALF of the CU's LDS instead: two resident
+  // workgroups overlap each other's prologue, scan conversion and stream-out (depth-only forward at 9216 crops:
+  // 5.9 -> 4.2 us per 256 crops, tools/exp_twocu.py); a hand crop's box (~63 x 62 px of 128 x 128) fits it in one
+  // pass, a larger one takes two.
+  const size_t key = OWNER ? 8 : 4;
   const int regions = (H + rows - 1) / rows;
+  const size_t pitch = (size_t)max_box_pitch(W);
+  const size_t full = kHdrBytes + (size_t)rows * pitch * key, least = kHdrBytes + 8 * pitch * key, half = kMaxLds / 2;
+  size_t lds = full;
+  if (g_tune.fwd_zbuf_bytes > 0) lds = kHdrBytes + (size_t)g_tune.fwd_zbuf_bytes;
+  else if (full > half && (long long)N * regions >= 2LL * num_cus()) lds = half;
+  if (lds < least) lds = least;
+  if (lds > full) lds = full;
+  const int zcells = (int)((lds - kHdrBytes) / key);
+  if (lds + g_tune.lds_pad <= (size_t)kMaxLds) lds += g_tune.lds_pad;
   dim3 grid((unsigned)persistent_grid(N, regions, lds, g_tune.fwd_waves), (unsigned)regions);
-  return (int)grid.x < N ? launch_zbuf_fwd_p<OWNER, VEC4, POW2, true>(sp, N, J, H, W, depth, argmin, rows, lds, grid, s)
-                         : launch_zbuf_fwd_p<OWNER, VEC4, POW2, false>(sp, N, J, H, W, depth, argmin, rows, lds, grid, s);
+  return (int)grid.x < N
+             ? launch_zbuf_fwd_p<OWNER, VEC4, POW2, true>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, s)
+             : launch_zbuf_fwd_p<OWNER, VEC4, POW2, false>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, s);
 }
 
 template <bool OWNER, bool VEC4>
@@ -161,6 +181,8 @@ extern "C" int shr_set_tuning(int key, int value) {
       if (value < 1 || value > 16) return SHR_EINVAL;
       g_tune.fwd_waves = value;
       return SHR_OK;
+    case 99: g_tune.lds_pad = value; return SHR_OK;
+    case SHR_TUNE_FWD_ZBUF_BYTES: if (value < 0) return SHR_EINVAL; g_tune.fwd_zbuf_bytes = value; return SHR_OK;
     case SHR_TUNE_PERSISTENT: if (value < 0) return SHR_EINVAL; g_tune.persistent = value; return SHR_OK;
     case SHR_TUNE_D2M_WAVES: return d2m_set_waves(value);
     case SHR_TUNE_D2M_BAND_UNITS: return d2m_set_band_units(value);
@@ -198,7 +220,7 @@ extern "C" int shr_sphere_raster_fwd(const float *spheres, int N, int J, int H, 
   hipStream_t s = (hipStream_t)stream;
   const float4 *sp = reinterpret_cast<const float4 *>(spheres);
 
-  const long long row_bytes = (long long)(W + kRowPad) * (argmin ? 8 : 4);
+  const long long row_bytes = (long long)max_box_pitch(W) * (argmin ? 8 : 4);   // the widest pitch a touched box can get
   // Measured (MI355X, 128x128): one whole-crop workgroup per CU beats two 80-KB half-crop
   // workgroups at every batch size (N = 256: 8.8 vs 10.7 us; N = 9216: 6.1 vs 6.6 us per 256
   // crops): a half-crop workgroup repeats the prologue and splits the spheres that straddle

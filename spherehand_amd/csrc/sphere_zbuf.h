@@ -53,11 +53,11 @@ constexpr int kPadRows = 0;   // rows after the region's last (none: a chunk nev
 constexpr int kBgWaves = 7;   // forward: waves that store the background rows before the first barrier
 // (storing them after the barrier instead, with smaller list shares for those waves, moves the barrier from 4.6 k
 // to 3.8 k cycles but the stores then cost the scan conversion more than that: measured 8.9 vs 8.6 us)
-// LDS header: spheres [64] float4 | work items [64] int4 | ends [64] int | flags | next crop's spheres [64] float4
+// LDS header: spheres [64] float4 | work items [64] int4 | ends [64] int | flags [16] | next crop's spheres [64] float4
 constexpr int kOffItems = 1024;
 constexpr int kOffEnds = 2048;
 constexpr int kOffFlags = 2304;
-constexpr int kOffNext = 2304 + 16;       // [64] float4: the NEXT crop's records (persistent workgroups)
+constexpr int kOffNext = 2304 + 64;       // [64] float4: the NEXT crop's records (persistent workgroups)
 constexpr int kHdrBytes = kOffNext + 1024;
 constexpr int kMaxFastWidth = 8192;  // 16-bit fields of the work items
 
@@ -230,6 +230,7 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
                                    readlane_f(w.sph.w, j));
       const int u0 = geom & 0xffff, v0 = (int)((unsigned)geom >> 16);
       const int v1 = rows & 0xffff, inv15 = (int)((unsigned)rows >> 16), ph = (inv15 << 6) >> 15;   // ph = 64 / pw
+      const int v1c = min(v1, r1 - 1);   // (r1 may cut the list's boxes: the forward's z-buffer can end above the region's last row)
       const int pw = cols & 0xff, ncx = (cols >> 8) & 0xff, u1 = (int)((unsigned)cols >> 16);
       const float rr = s.w * s.w;
       // lane -> (lx, ly) inside a chunk: ly = lane / pw = (lane * ceil(2^15 / pw)) >> 15, exact for lane < 64
@@ -259,7 +260,7 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
           } else {
             // clipped by the region's last row: "row <= v1" as ONE comparison of coordinates
             // (half a pixel of margin; the limit of a lane outside the packing is -huge)
-            const float ylim = packed ? axis_coord_t<true>(ay, v1) + 0.5f * ay.mul : -3.0e38f;
+            const float ylim = packed ? axis_coord_t<true>(ay, v1c) + 0.5f * ay.mul : -3.0e38f;
             for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell) {
               const float ygb = yg + dyg;
               body(j, s, cell, cell + dcell, dx, cav, yg, ygb, yg <= ylim, ygb <= ylim, c + 1 < c_end, std::true_type());
@@ -268,10 +269,11 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
         } else {
           for (; c < c_end; c += 2, v += 2 * ph, cell += 2 * dcell)
             body(j, s, cell, cell + dcell, dx, cav, axis_coord_t<POW2>(ay, v), axis_coord_t<POW2>(ay, v + ph),
-                 packed && v <= v1, packed && v + ph <= v1, c + 1 < c_end, std::true_type());
+                 packed && v <= v1c, packed && v + ph <= v1c, c + 1 < c_end, std::true_type());
         }
       } else {   // a box wider than a wave: pw = 64, ph = 1, chunk = (row c / ncx, segment c % ncx)
-        for (; c < c_end; ++c) {
+        const int c_end_w = min(c_end, (v1c - v0 + 1) * ncx);
+        for (; c < c_end_w; ++c) {
           const int g = rfl((int)(((float)c + 0.5f) / (float)ncx));
           const int u = u0 + ((c - g * ncx) << 6) + lane, v = v0 + g;
           const float dx = axis_coord_t<POW2>(ax, u) - s.x;
@@ -405,9 +407,57 @@ __device__ __forceinline__ void touched_rows(const float4 s, bool valid, const A
   if (bad != 0ull || low == 0ull) { cv0 = r0; cv1 = r1 - 1; }
 }
 
+// The same for rows AND columns: the pixel box [cv0, cv1] x [cu0, cu1] that holds every pixel a sphere
+// of the crop can touch inside rows [r0, r1) -- the only part of the region that needs a z-buffer.  The
+// per-sphere ranges are sphere_item's (same function, same inputs).  One transposed four-component wave
+// minimum (v0, -v1, u0, -u1) instead of four reductions.
+__device__ __forceinline__ void touched_box(const float4 s, bool valid, const Axis &ax, const Axis &ay, float kx,
+                                            float ky, int W, int r0, int r1, int lane, int &cv0, int &cv1, int &cu0,
+                                            int &cu1) {
+  const bool tame = sphere_is_tame(s);
+  const unsigned long long bad = __ballot(valid && !(tame && fabsf(s.z) < 1e30f));
+  const unsigned long long low = __ballot(valid && s.z <= kBackground);
+  int v0 = r0, v1 = r1 - 1, u0 = 0, u1 = W - 1;
+  if (tame) {
+    const float ar = fabsf(s.w);
+    axis_box(s.x, ar, kx, ax.half, (float)W + 2.f, 0, W - 1, u0, u1);
+    axis_box(s.y, ar, ky, ay.half, (float)r1 + 2.f, r0, r1 - 1, v0, v1);
+  }
+  const bool on = valid && v1 >= v0 && u1 >= u0;   // (pixel numbers are < 2^24: exact in fp32)
+  const float m = wave_min4_transposed(on ? (float)v0 : 1e9f, on ? -(float)v1 : 1e9f, on ? (float)u0 : 1e9f,
+                                       on ? -(float)u1 : 1e9f, lane);
+  cv0 = (int)readlane_f(m, 12);
+  cv1 = -(int)readlane_f(m, 13);
+  cu0 = (int)readlane_f(m, 14);
+  cu1 = -(int)readlane_f(m, 15);
+  if (cv1 < cv0) { cv0 = r1; cv1 = r0 - 1; cu0 = 0; cu1 = -1; }
+  if (bad != 0ull || low == 0ull) { cv0 = r0; cv1 = r1 - 1; cu0 = 0; cu1 = W - 1; }
+}
+
+// Row pitch (cells) of a z-buffer over a box `bw` columns wide (bw % 4 == 0): kRowPad cells of padding, and never
+// within 8 cells of a multiple of 32 -- the rows of a chunk would start in (nearly) the same LDS banks.
+__host__ __device__ __forceinline__ int box_pitch(int bw) {
+  const int p = bw + kRowPad;
+  return (p & 31) < 8 ? p + 8 : p;
+}
+// the widest pitch any box of a W-pixel row can get
+__host__ __device__ __forceinline__ int max_box_pitch(int W) { return ((W + 3) & ~3) + kRowPad + 8; }
+
 // ---------------------------------------------------------------------------
-// Forward.  grid = (N, nregions), block = 64 * nwaves (<= 1024), dynamic LDS = kHdrBytes +
-// (rows_per_region + kPadRows) * (W + kRowPad) * sizeof(key).
+// Forward.  grid = (N or fewer, nregions), block = 64 * nwaves (<= 1024), dynamic LDS = kHdrBytes +
+// zcells * sizeof(key).
+//
+// The z-buffer covers only the TOUCHED BOX of the region -- the rows and columns some sphere's pixel box
+// reaches (a hand crop: ~63 x 62 of 128 x 128 pixels) -- at a row pitch that follows the box's width.
+// Everything outside it is background whatever the depths: whole background rows are stored straight from
+// registers before the first barrier, the background columns of the touched rows are filled in by the
+// stream-out.  A box of more than `zcells` cells is rasterized in PASSES over row bands (the work list is
+// rebuilt clipped to each band), so that any crop is exact at any LDS budget: the launcher gives a
+// workgroup half of the CU's LDS when the launch has at least two workgroups per CU -- two resident
+// workgroups overlap each other's prologue (record read, work list, background stores), issue-bound scan
+// conversion and stream-out, which one workgroup per CU runs strictly one after the other (5.9 -> 4.2 us
+// per 256 crops for the depth-only forward at 9216 crops, tools/exp_twocu.py) -- and the whole of it
+// otherwise (one pass for any 128 x 128 box).
 //
 // Schedule of one workgroup (in-kernel clock64, batch 256 = one crop per CU): the sphere
 // read takes ~2 k cycles to arrive and wave 0 needs ~1.5 k more for the work list; the
@@ -418,7 +468,7 @@ template <bool OWNER, bool VEC4, bool POW2, bool PERSIST>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_,
                        float *__restrict__ depth, uint8_t *__restrict__ argmin, int rows_per_region_,
-                       int w4_shift_, int shares) {
+                       int w4_shift_, int shares, int zcells_) {
   using Key = typename KeyOf<OWNER>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
@@ -439,8 +489,9 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   // hoists each crop-invariant value out of the crop loop and keeps it in a register (forward: 92 instead of 51
   // VGPRs; the fused kernel spilled).
   int J = J_, H = H_, W = W_, rows_per_region = rows_per_region_, w4_shift = w4_shift_, tid = threadIdx.x;
+  int zcells = zcells_;
   if (PERSIST) {
-    asm volatile("" : "+s"(J), "+s"(H), "+s"(W), "+s"(rows_per_region), "+s"(w4_shift));
+    asm volatile("" : "+s"(J), "+s"(H), "+s"(W), "+s"(rows_per_region), "+s"(w4_shift), "+s"(zcells));
     asm volatile("" : "+v"(tid));
   }
   const int lane = tid & 63, wave = tid >> 6;
@@ -448,12 +499,11 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   const int r0 = blockIdx.y * rows_per_region;
   const int r1 = min(H, r0 + rows_per_region);
   const int rh = r1 - r0;
-  const int LW = W + kRowPad;
   const Axis ax = make_axis(W), ay = make_axis(H);
   const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
 
   // the waves that need the crop's records before the first barrier (wave 0: work list; the
-  // background waves: touched rows) read them from memory, lane j = sphere j; the others take
+  // background waves: touched box) read them from memory, lane j = sphere j; the others take
   // wave 0's LDS copy after the barrier (their requests would only lengthen the memory queue)
   const int wave_s = rfl(wave);
   const bool list_wave = wave_s == 0;
@@ -464,11 +514,10 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
   if (valid && (list_wave || bg_wave)) sph = crop_it == 0 ? spheres[(size_t)n * J + lane] : s_next[lane];
 
-  {  // background everywhere (pad rows/columns included); overlaps the read above
-    const Key bg = OWNER ? (Key)(((unsigned long long)depth_key(kBackground) << 32) | SHR_ARGMIN_NONE)
-                         : (Key)depth_key(kBackground);
+  const Key bg = OWNER ? (Key)(((unsigned long long)depth_key(kBackground) << 32) | SHR_ARGMIN_NONE)
+                       : (Key)depth_key(kBackground);
+  auto init_zbuf = [&](int ncell) {   // background everywhere
     constexpr int per16 = 16 / sizeof(Key);
-    const int ncell = (rh + kPadRows) * LW;
     const int nvec = ncell / per16;
     if (OWNER) {
       const ulonglong2 v = make_ulonglong2(bg, bg);
@@ -478,13 +527,14 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
       for (int i = tid; i < nvec; i += nthr) reinterpret_cast<uint4 *>(zbuf)[i] = v;
     }
     for (int i = nvec * per16 + tid; i < ncell; i += nthr) zbuf[i] = bg;
-  }
+  };
+  // (the box is not known yet: every cell a one-pass box of this region can use; overlaps the read above)
+  init_zbuf(min(zcells, rh * max_box_pitch(W)));
 
-  int cv0 = r0, cv1 = r1 - 1;
   // Waves 1..kBgWaves store the background rows while wave 0 builds the list: they are the
   // first to finish the z-buffer initialisation (the SIMD arbitration favours old waves) and
   // a wave issues a wave-wide store every ~55 cycles, so ~6 stores apiece fit in wave 0's
-  // shadow.  The other waves learn the touched rows after the barrier.
+  // shadow.  The other waves learn the touched box after the barrier.
 
   if (list_wave) {
     s_sph[lane] = sph;
@@ -513,13 +563,18 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   uchar4 *aout4 = OWNER ? reinterpret_cast<uchar4 *>(aout + (size_t)r0 * W) : nullptr;
   // units [0, ua) and [ub, nunits) lie entirely in background rows, [ua, ub) is touched
   int ua = 0, ub = nunits;
-  if (VEC4 && bg_wave) {
-    touched_rows(sph, valid, ay, ky, r0, r1, cv0, cv1);
-    if (cv1 < cv0) ua = ub = nunits;
-    else { ua = ((cv0 - r0) * w4) >> 6; ub = min(nunits, ((cv1 - r0 + 1) * w4 + 63) >> 6); }
-    ua = rfl(ua);
-    ub = rfl(ub);
-    if (wave_s == (nwaves == 1 ? 0 : 1) && lane == 0) { s_flag[2] = ua; s_flag[3] = ub; }   // for the other waves
+  int4 bx = make_int4(0, 0, 0, 0);
+  if (bg_wave) {
+    int cv0, cv1, cu0, cu1;
+    touched_box(sph, valid, ax, ay, kx, ky, W, r0, r1, lane, cv0, cv1, cu0, cu1);
+    if (VEC4) {
+      if (cv1 < cv0) ua = ub = nunits;
+      else { ua = ((cv0 - r0) * w4) >> 6; ub = min(nunits, ((cv1 - r0 + 1) * w4 + 63) >> 6); }
+      ua = rfl(ua);
+      ub = rfl(ub);
+    }
+    // (the publishing wave keeps the box; see below)
+    bx = make_int4(cv0, cv1, cu0, cu1);
   }
   // ---- background rows: stored by the waves that wait for the work list ---------------
   const float4 bgd = make_float4(kBackground, kBackground, kBackground, kBackground);
@@ -550,93 +605,130 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     }
   };
   if (VEC4 && bg_wave) store_background(nwaves == 1 ? 0 : wave_s - 1, nwaves == 1 ? 1 : nbgw);
+  if (wave_s == (nwaves == 1 ? 0 : 1) && lane == 0) {
+    // Everything the other waves derive from the box, computed ONCE (the stores above drain meanwhile): sixteen
+    // waves repeating this scalar arithmetic -- a division among it -- after the barrier cost 2 k cycles per crop.
+    const int cv0 = bx.x, cv1 = bx.y;
+    const int cu0 = bx.z & ~3;                                          // 16-byte chunks lie inside or outside the box
+    const int bw = bx.w >= cu0 ? ((bx.w | 3) - cu0 + 1) : 4;
+    const int pitch = box_pitch(bw);
+    // the touched part of the region in 16-byte chunks (VEC4) / pixels (otherwise): what the stream-out writes
+    const int row_len = VEC4 ? w4 : W;
+    const int out_lo = VEC4 ? ua << 6 : 0, out_hi = VEC4 ? min(ub << 6, nchunk) : rh * W;
+    // Rows [cv0, pe) of the box fit the z-buffer; a box with more rows than that (possible only at the small
+    // budget of two workgroups per CU, or when a test squeezes it) leaves rows [pe, cv1] -- from a tile boundary
+    // on -- to the general tile code, which writes whole rows itself: no second pass, no loop around the scan.
+    const int split = (cv0 + zcells / pitch) & ~(kTileH - 1);           // (zcells / pitch >= 8: the launcher's budget)
+    const bool over = split <= cv1;
+    s_flag[2] = out_lo;
+    s_flag[3] = over ? min(out_hi, (split - r0) * row_len) : out_hi;
+    s_flag[4] = cv0; s_flag[5] = over ? split : cv1 + 1; s_flag[6] = cu0; s_flag[7] = bw;
+    s_flag[8] = pitch;
+    s_flag[9] = over ? split : r1;                                      // the scan conversion's clip row
+    // tile rows: from the split to the end of the touched units (rows below the box inside them are background,
+    // which the tile code reproduces), on tile boundaries
+    s_flag[10] = over ? split : r1;
+    s_flag[11] = over ? min(r1, (r0 + (out_hi + row_len - 1) / row_len + kTileH - 1) & ~(kTileH - 1)) : r1;
+  }
   __syncthreads();
   if (!(list_wave || bg_wave)) sph = s_sph[lane];
   const bool has_next = PERSIST && n + crop_step < N;   // (the launcher keeps a prefetch wave whenever gridDim.x < N)
   float4 sph_next = make_float4(0.f, 0.f, 0.f, 0.f);
   if (pf_wave && has_next && valid) sph_next = spheres[(size_t)(n + crop_step) * J + lane];
 
-  if (s_flag[0]) {  // workgroup-uniform: this crop needs the general path
-    const int tiles_x = (W + kTileW - 1) / kTileW;
-    const int t0 = (r0 / kTileH) * tiles_x, t1 = ((r1 + kTileH - 1) / kTileH) * tiles_x;
-    tile_forward<VEC4, OWNER>(sph, J, H, W, out, aout, tiles_x, t0 + wave, t1, nwaves, lane);
-    if (pf_wave && has_next) s_next[lane] = sph_next;
+  const bool general = s_flag[0] != 0;   // workgroup-uniform: the whole region takes the tile code
+  int tile_lo = r0, tile_hi = r1;        // rows for the tile code
+  if (!general) {
+    const int out_lo = rfl(s_flag[2]), out_hi = rfl(s_flag[3]);
+    const int p0 = rfl(s_flag[4]), pe = rfl(s_flag[5]), cu0 = rfl(s_flag[6]), bw = rfl(s_flag[7]);
+    const int pitch = rfl(s_flag[8]), clip = rfl(s_flag[9]);
+    tile_lo = rfl(s_flag[10]);
+    tile_hi = rfl(s_flag[11]);
+
+    // ---- scan-convert the chunk list ---------------------------------------------------
+    // A chunk may reach below its sphere's box (rows that are real pixels, or lie beyond the
+    // z-buffer's last row): the hit test is exact for ANY pixel and fails there, nothing is written.
+    {
+      WaveList wl;
+      wl.sph = sph;
+      wl.item = s_items[lane];
+      wl.end = s_ends[lane];
+      Key *zb = zbuf - (p0 * pitch + cu0);   // cell of pixel (v, u) = zb[v * pitch + u]
+      walk_my_slice<POW2, kSphereCostFwd, true>(
+          wl, J, s_flag[1], wave, nwaves, shares, lane, ax, ay, 0, clip, pitch,
+          [&](int j, const float4 s, int cell_a, int cell_b, float, float ca, float yga, float ygb, bool ok_a,
+              bool ok_b, bool has_b, auto row_test) {
+            const float dya = yga - s.y, dyb = ygb - s.y;
+            float qa = ca - dya * dya, qb = ca - dyb * dyb;
+            if (decltype(row_test)::value) { qa = ok_a ? qa : -1.f; qb = ok_b ? qb : -1.f; }
+            auto put = [&](Key *cell, float d) {
+              if (OWNER)
+                atomicMin(reinterpret_cast<unsigned long long *>(cell),
+                          ((unsigned long long)depth_key(d) << 32) | (unsigned)j);
+              else
+                atomicMin(reinterpret_cast<unsigned int *>(cell), depth_key(d));
+            };
+            if (has_b) {  // wave-uniform; branch-free up to the atomics: both roots in flight together
+              const bool ha = qa > kHitMin, hb = qb > kHitMin;
+              // (the root of a non-hit lane's q may be NaN: never stored)
+              const float da = s.z - sqrt_rn(qa), db = s.z - sqrt_rn(qb);
+              if (ha) put(zb + cell_a, da);
+              if (hb) put(zb + cell_b, db);
+            } else if (qa > kHitMin) {
+              put(zb + cell_a, s.z - sqrt_rn(qa));
+            }
+          },
+          [](int) {});
+    }
+    if (pf_wave && has_next) s_next[lane] = sph_next;   // (arrived long ago: the wave's own scan slice lies in between)
     __syncthreads();
-    continue;
-  }
-  if (VEC4) { ua = rfl(s_flag[2]); ub = rfl(s_flag[3]); }
 
-  // ---- scan-convert the patch list -------------------------------------------------
-  // A patch may overhang the box, the image's right edge or the region's last row:
-  // the hit test is exact for ANY pixel, overhanging lanes land in LDS padding.
-  {
-    WaveList wl;
-    wl.sph = sph;
-    wl.item = s_items[lane];
-    wl.end = s_ends[lane];
-    walk_my_slice<POW2, kSphereCostFwd, true>(
-        wl, J, s_flag[1], wave, nwaves, shares, lane, ax, ay, r0, r1, LW,
-        [&](int j, const float4 s, int cell_a, int cell_b, float, float ca, float yga, float ygb, bool ok_a,
-            bool ok_b, bool has_b, auto row_test) {
-          const float dya = yga - s.y, dyb = ygb - s.y;
-          float qa = ca - dya * dya, qb = ca - dyb * dyb;
-          if (decltype(row_test)::value) { qa = ok_a ? qa : -1.f; qb = ok_b ? qb : -1.f; }
-          auto put = [&](Key *cell, float d) {
-            if (OWNER)
-              atomicMin(reinterpret_cast<unsigned long long *>(cell),
-                        ((unsigned long long)depth_key(d) << 32) | (unsigned)j);
-            else
-              atomicMin(reinterpret_cast<unsigned int *>(cell), depth_key(d));
-          };
-          if (has_b) {  // wave-uniform; branch-free up to the atomics: both roots in flight together
-            const bool ha = qa > kHitMin, hb = qb > kHitMin;
-            // (the root of a non-hit lane's q may be NaN: never stored)
-            const float da = s.z - sqrt_rn(qa), db = s.z - sqrt_rn(qb);
-            if (ha) put(zbuf + cell_a, da);
-            if (hb) put(zbuf + cell_b, db);
-          } else if (qa > kHitMin) {
-            put(zbuf + cell_a, s.z - sqrt_rn(qa));
+    // ---- stream the touched rows out: [out_lo, out_hi) of the region's chunks / pixels -------
+    const Key *zrow = zbuf - (p0 - r0) * pitch - cu0;   // cell of region pixel (v, x) = zrow[v * pitch + x]
+    const unsigned box_h = pe > p0 ? (unsigned)(pe - p0) : 0u;
+    if (VEC4) {
+      for (int c = out_lo + tid; c < out_hi; c += nthr) {
+        int v, x;
+        if (POW2 || w4_shift >= 0) { v = c >> w4_shift; x = (c & (w4 - 1)) << 2; }
+        else { v = c / w4; x = (c - v * w4) << 2; }
+        float4 o = bgd;
+        uchar4 a = bga;
+        if ((unsigned)(v + r0 - p0) < box_h && (unsigned)(x - cu0) < (unsigned)bw) {
+          const Key *cell = zrow + v * pitch + x;
+          if (OWNER) {
+            const ulonglong2 k01 = reinterpret_cast<const ulonglong2 *>(cell)[0];
+            const ulonglong2 k23 = reinterpret_cast<const ulonglong2 *>(cell)[1];
+            o = make_float4(key_depth((uint32_t)(k01.x >> 32)), key_depth((uint32_t)(k01.y >> 32)),
+                            key_depth((uint32_t)(k23.x >> 32)), key_depth((uint32_t)(k23.y >> 32)));
+            a = make_uchar4((uint8_t)k01.x, (uint8_t)k01.y, (uint8_t)k23.x, (uint8_t)k23.y);
+          } else {
+            const uint4 k = *reinterpret_cast<const uint4 *>(cell);
+            o = make_float4(key_depth(k.x), key_depth(k.y), key_depth(k.z), key_depth(k.w));
           }
-        },
-        [](int) {});
-  }
-  if (pf_wave && has_next) s_next[lane] = sph_next;   // (arrived long ago: the wave's own scan slice lies in between)
-  __syncthreads();
-
-  // ---- stream the touched rows out ---------------------------------------------------
-  if (VEC4) {
-    for (int u = ua + wave_s; u < ub; u += nwaves) {
-      const int c = (u << 6) + lane;
-      if (c >= nchunk) continue;
-      int v, x;
-      if (POW2 || w4_shift >= 0) { v = c >> w4_shift; x = (c & (w4 - 1)) << 2; }
-      else { v = c / w4; x = (c - v * w4) << 2; }
-      const Key *cell = zbuf + v * LW + x;
-      float4 o;
-      if (OWNER) {
-        const ulonglong2 k01 = reinterpret_cast<const ulonglong2 *>(cell)[0];
-        const ulonglong2 k23 = reinterpret_cast<const ulonglong2 *>(cell)[1];
-        o = make_float4(key_depth((uint32_t)(k01.x >> 32)), key_depth((uint32_t)(k01.y >> 32)),
-                        key_depth((uint32_t)(k23.x >> 32)), key_depth((uint32_t)(k23.y >> 32)));
-        late_store(aout4 + c, make_uchar4((uint8_t)k01.x, (uint8_t)k01.y, (uint8_t)k23.x, (uint8_t)k23.y));
-      } else {
-        const uint4 k = *reinterpret_cast<const uint4 *>(cell);
-        o = make_float4(key_depth(k.x), key_depth(k.y), key_depth(k.z), key_depth(k.w));
+        }
+        if (OWNER) late_store(aout4 + c, a);
+        late_store(out4 + c, o);
       }
-      late_store(out4 + c, o);
-    }
-  } else {
-    for (int p = tid; p < rh * W; p += nthr) {
-      const int v = p / W, u = p - v * W;
-      const Key k = zbuf[v * LW + u];
-      if (OWNER) {
-        out[(size_t)(r0 + v) * W + u] = key_depth((uint32_t)((unsigned long long)k >> 32));
-        aout[(size_t)(r0 + v) * W + u] = (uint8_t)k;
-      } else {
-        out[(size_t)(r0 + v) * W + u] = key_depth((uint32_t)k);
+    } else {
+      for (int p = out_lo + tid; p < out_hi; p += nthr) {
+        const int v = p / W, u = p - v * W;
+        Key k = bg;
+        if ((unsigned)(v + r0 - p0) < box_h && (unsigned)(u - cu0) < (unsigned)bw) k = zrow[v * pitch + u];
+        if (OWNER) {
+          out[(size_t)(r0 + v) * W + u] = key_depth((uint32_t)((unsigned long long)k >> 32));
+          aout[(size_t)(r0 + v) * W + u] = (uint8_t)k;
+        } else {
+          out[(size_t)(r0 + v) * W + u] = key_depth((uint32_t)k);
+        }
       }
     }
   }
+  if (tile_lo < tile_hi) {   // workgroup-uniform: a crop on the general path, or the rows its z-buffer could not hold
+    const int tiles_x = (W + kTileW - 1) / kTileW;
+    const int t0 = (tile_lo / kTileH) * tiles_x, t1 = ((tile_hi + kTileH - 1) / kTileH) * tiles_x;
+    tile_forward<VEC4, OWNER>(sph, J, H, W, out, aout, tiles_x, t0 + wave, t1, nwaves, lane);
+  }
+  if (general && pf_wave && has_next) s_next[lane] = sph_next;
   if (PERSIST && n + crop_step < N) __syncthreads();   // the z-buffer is re-initialised next: every wave's stream-out reads are done
   }  // crops
 }

@@ -13,11 +13,12 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["zbuf", "general", "zbuf-small-lds", "zbuf-4-waves"])
+@pytest.fixture(scope="module", params=["zbuf", "general", "zbuf-small-lds", "zbuf-4-waves", "zbuf-bands"])
 def ops(request):
     """Every test runs on the fast LDS z-buffer kernels, on the general tile
     kernels, on the z-buffer kernels squeezed into 16 KB of LDS (many row regions
-    per crop) and with 4-wave forward workgroups."""
+    per crop), with 4-wave forward workgroups, and with a 12-KB forward z-buffer
+    (a crop's touched box is rasterized in several passes over row bands)."""
     from spherehand_amd import ops as o
     assert torch.cuda.is_available()
     o.set_tuning(o.TUNE_FORCE_GENERAL, 1 if request.param == "general" else 0)
@@ -26,7 +27,9 @@ def ops(request):
     o.set_tuning(o.TUNE_FWD_OWNER_LDS_BYTES, 24 * 1024 if small else 0)
     o.set_tuning(o.TUNE_BWD_LDS_BYTES, 16 * 1024 if small else 128 * 1024)
     o.set_tuning(o.TUNE_FWD_WAVES, 4 if request.param == "zbuf-4-waves" else 16)
+    o.set_tuning(o.TUNE_FWD_ZBUF_BYTES, 12 * 1024 if request.param == "zbuf-bands" else 0)
     yield o
+    o.set_tuning(o.TUNE_FWD_ZBUF_BYTES, 0)
     o.set_tuning(o.TUNE_FWD_WAVES, 16)
     o.set_tuning(o.TUNE_FORCE_GENERAL, 0)
     o.set_tuning(o.TUNE_FWD_LDS_BYTES, 80 * 1024)
@@ -236,8 +239,9 @@ def test_persistent_workgroups_equal_one_workgroup_per_crop(oracle, S, wgs):
     d_sp = torch.from_numpy(sp).cuda()
     g = torch.from_numpy(rs.standard_normal((n, S, S)).astype(np.float32)).cuda()
     res = {}
-    for mode in (0, wgs):
-        ops.set_tuning(ops.TUNE_PERSISTENT, mode)
+    for mode in (0, wgs, -wgs):
+        ops.set_tuning(ops.TUNE_PERSISTENT, abs(mode))
+        ops.set_tuning(ops.TUNE_FWD_ZBUF_BYTES, 20 * 1024 if mode < 0 else 0)   # < 0: ... and the forward in row bands
         d, o = ops.sphere_raster_fwd(d_sp, S, S, want_argmin=True)
         d2 = ops.sphere_raster_fwd(d_sp, S, S)
         gs = ops.sphere_raster_bwd(d_sp, g, o)
@@ -246,8 +250,10 @@ def test_persistent_workgroups_equal_one_workgroup_per_crop(oracle, S, wgs):
         fd, fsse, fgrad = ops.sphere_raster_mse(d_sp, tgt, tidx)                       # fused render-and-compare
         res[mode] = [t.cpu().numpy() for t in (d, o, d2, gs, fd, fsse, fgrad)]
     ops.set_tuning(ops.TUNE_PERSISTENT, 1)
-    for a, b in zip(res[0], res[wgs]):
-        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    ops.set_tuning(ops.TUNE_FWD_ZBUF_BYTES, 0)
+    for other in (wgs, -wgs):
+        for a, b in zip(res[0], res[other]):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
     ref = oracle.sphere_raster_fwd(sp, S, S, want_argmin=False)
     ok = ~np.isnan(ref)                                  # (a NaN's payload is not part of the contract)
     assert np.array_equal(np.isnan(res[wgs][0]), ~ok)

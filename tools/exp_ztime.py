@@ -12,12 +12,14 @@ spheres, grad = bench.make_inputs(0, dev)
 N, J, S = 256, 41, 128
 depth = torch.empty(N, S, S, device=dev)
 owner = torch.empty(N, S, S, device=dev, dtype=torch.uint8)
-tbuf = torch.zeros(N * 16 * 8, dtype=torch.int64, device=dev)
+tbuf = torch.zeros(N * 16 * 8 + N, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(50):
     lib.exp_zfwd_t_launch(spheres.data_ptr(), N, J, S, S, depth.data_ptr(), owner.data_ptr(), 128, SHARES, tbuf.data_ptr(), st)
 torch.cuda.synchronize()
-t = tbuf.cpu().numpy().reshape(N, 16, 8).astype(np.float64)
+npass = tbuf.cpu().numpy()[N * 128:]
+print('passes*1000 + rows_fit per crop (first 12):', npass[:12].tolist(), 'max passes', int(npass.max() // 1000))
+t = tbuf.cpu().numpy()[:N * 128].reshape(N, 16, 8).astype(np.float64)
 base = t[:, :, 0].min()
 print("clock64 ticks are 100 MHz (10 ns) on gfx9 s_memtime? checking span:", (t[:, :, 6].max() - base))
 names = ["T1 spheres+list (wave0)", "T2 init done", "T3 after barrier1", "T4 raster done", "T5 after barrier2", "T6 end"]

@@ -30,6 +30,8 @@ def sphere_case():
     ops.set_tuning(ops.TUNE_FWD_OWNER_LDS_BYTES, 24 * 1024 if mode == 2 else 0)
     ops.set_tuning(ops.TUNE_BWD_LDS_BYTES, 16 * 1024 if mode == 2 else 128 * 1024)
     ops.set_tuning(ops.TUNE_FWD_WAVES, 4 if mode == 3 else 16)
+    zb = int(rs.choice([0, 0, 6, 20, 48, 80])) * 1024                           # forward z-buffer: several row bands per box
+    ops.set_tuning(ops.TUNE_FWD_ZBUF_BYTES, zb)
     d, a = ops.sphere_raster_fwd(dev(sp), H, W, want_argmin=True)
     od, oa = oracle.sphere_raster_fwd(sp, H, W)
     if not np.isfinite(sp).all() or np.abs(sp).max() > 1e20:
@@ -38,7 +40,7 @@ def sphere_case():
         ok = np.array_equal(np.isnan(dn), np.isnan(od)) and np.array_equal(bits(dn)[~np.isnan(od)], bits(od)[~np.isnan(od)])
         if not ok:
             fails += 1
-            print("SPHERE (non-finite) MISMATCH", dict(N=N, J=J, H=H, W=W, mode=mode))
+            print("SPHERE (non-finite) MISMATCH", dict(N=N, J=J, H=H, W=W, mode=mode, zb=zb))
         return
     ok = np.array_equal(bits(d.cpu().numpy()), bits(od)) and np.array_equal(a.cpu().numpy(), oa)
     gd = rs.standard_normal((N, H, W)).astype(np.float32)
@@ -57,7 +59,7 @@ def sphere_case():
         ok = ok and bool(np.abs(gsp.cpu().numpy() - og2).max() <= 2e-5 * np.abs(og2).max() + 1e-3)
     if not ok:
         fails += 1
-        print("SPHERE MISMATCH", dict(N=N, J=J, H=H, W=W, scale=scale, mode=mode))
+        print("SPHERE MISMATCH", dict(N=N, J=J, H=H, W=W, scale=scale, mode=mode, zb=zb))
 
 def tri_case():
     global fails
