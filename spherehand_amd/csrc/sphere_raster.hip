@@ -15,7 +15,7 @@ struct Tuning {
   int bwd_lds_bytes = 128 * 1024;       // backward staging (grad f32 + owner u8)
   int force_general = 0;                // 1: always the tile kernels (tests)
   int fwd_waves = 16;                   // waves per forward workgroup
-  int fwd_shares = 0x28384858;          // work-list shares of the four wave age groups, oldest in the low byte (sum 256)
+  int fwd_shares = 0x24344464;          // work-list shares of the four wave age groups, oldest in the low byte (sum 256)
   int bwd_shares = 0x2c3a4654;
   int lds_pad = 0;                      // experiments: extra dynamic LDS per zbuf workgroup (forces one workgroup per CU)
   int fwd_zbuf_bytes = 0;               // forward z-buffer bytes per workgroup; 0 = by launch size (launch_zbuf_fwd_t)

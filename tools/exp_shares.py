@@ -32,6 +32,8 @@ cands = [(64, 64, 64, 64), (72, 68, 60, 56), (56, 60, 68, 72), (48, 56, 72, 80),
          (88, 72, 56, 40), (84, 70, 58, 44), (90, 74, 58, 34), (86, 72, 58, 40), (92, 72, 54, 38), (88, 76, 54, 38),
          (84, 74, 58, 40), (80, 72, 60, 44), (88, 68, 58, 42), (92, 76, 56, 32), (86, 70, 56, 44), (82, 70, 60, 44),
          (88, 72, 60, 36), (84, 72, 56, 44), (90, 70, 56, 40), (86, 74, 56, 40)]
+if os.environ.get("CANDS"):   # e.g. CANDS="100:72:50:34,96:72:52:36"
+    cands = [tuple(int(v) for v in c.split(":")) for c in os.environ["CANDS"].split(",")]
 for c in cands:
     if which == "fwd":
         ops.set_tuning(ops.TUNE_FWD_SHARES, pack(c))

@@ -18,7 +18,7 @@ for _ in range(50):
     lib.exp_zfwd_t_launch(spheres.data_ptr(), N, J, S, S, depth.data_ptr(), owner.data_ptr(), 128, SHARES, tbuf.data_ptr(), st)
 torch.cuda.synchronize()
 npass = tbuf.cpu().numpy()[N * 128:]
-print('passes*1000 + rows_fit per crop (first 12):', npass[:12].tolist(), 'max passes', int(npass.max() // 1000))
+print('box rows*1000 + columns per crop (first 12):', npass[:12].tolist(), ' mean rows %.1f columns %.1f' % ((npass // 1000).mean(), (npass % 1000).mean()))
 t = tbuf.cpu().numpy()[:N * 128].reshape(N, 16, 8).astype(np.float64)
 base = t[:, :, 0].min()
 print("clock64 ticks are 100 MHz (10 ns) on gfx9 s_memtime? checking span:", (t[:, :, 6].max() - base))
