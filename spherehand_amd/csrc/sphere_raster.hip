@@ -18,6 +18,7 @@ struct Tuning {
   int fwd_shares = 0x24344464;          // work-list shares of the four wave age groups, oldest in the low byte (sum 256)
   int bwd_shares = 0x2c3a4654;
   int lds_pad = 0;                      // experiments: extra dynamic LDS per zbuf workgroup (forces one workgroup per CU)
+  int bwd_waves = 0;                    // waves per backward workgroup: 0 = by launch size, 8 or 16
   int fwd_zbuf_bytes = 0;               // forward z-buffer bytes per workgroup; 0 = by launch size (launch_zbuf_fwd_t)
   int persistent = 1;                   // 0: one workgroup per crop; 1: persistent workgroups when N exceeds the device; > 1: that many
 } g_tune;
@@ -141,14 +142,14 @@ int launch_zbuf_fwd(const float4 *sp, int N, int J, int H, int W, float *depth, 
              : launch_zbuf_fwd_t<OWNER, VEC4, false>(sp, N, J, H, W, depth, argmin, rows, s);
 }
 
-template <bool VEC4, bool POW2, bool PERSIST>
+template <bool VEC4, bool POW2, bool PERSIST, int NW>
 int launch_zbuf_bwd_p(const float4 *sp, const float *grad, const uint8_t *argmin, int N, int J, int H, int W, float4 *gs,
                       int rows, size_t lds, int gridx, hipStream_t s) {
   static AttrDone attr_done;
-  auto k = sphere_zbuf_bwd_kernel<VEC4, POW2, PERSIST>;
+  auto k = sphere_zbuf_bwd_kernel<VEC4, POW2, PERSIST, NW>;
   const hipError_t e = allow_big_lds(k, &attr_done);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(k, dim3((unsigned)gridx), dim3(64 * kZWaves), lds, s, sp, grad, argmin, N, J, H, W, gs, rows,
+  hipLaunchKernelGGL(k, dim3((unsigned)gridx), dim3(64 * NW), lds, s, sp, grad, argmin, N, J, H, W, gs, rows,
                      log2_if_pow2(W / 4), g_tune.bwd_shares);
   return (int)hipGetLastError();
 }
@@ -156,10 +157,24 @@ int launch_zbuf_bwd_p(const float4 *sp, const float *grad, const uint8_t *argmin
 template <bool VEC4, bool POW2>
 int launch_zbuf_bwd_t(const float4 *sp, const float *grad, const uint8_t *argmin, int N, int J, int H, int W,
                       float4 *gs, int rows, hipStream_t s) {
-  const size_t lds = kHdrBytes + kPartBytes + (size_t)(rows + kPadRows) * (W + kRowPad) * 5;
-  const int gridx = persistent_grid(N, 1, lds, kZWaves);
-  return gridx < N ? launch_zbuf_bwd_p<VEC4, POW2, true>(sp, grad, argmin, N, J, H, W, gs, rows, lds, gridx, s)
-                   : launch_zbuf_bwd_p<VEC4, POW2, false>(sp, grad, argmin, N, J, H, W, gs, rows, lds, gridx, s);
+  // `rows` = the rows of a crop the staging buffers hold at the full budget (pick_rows).  With at least two
+  // workgroups per CU in the launch a workgroup gets half of the CU's LDS and 8 waves instead (two resident
+  // workgroups overlap one crop's staging with the other's walk): the touched rows of 9 hand crops of 10 still
+  // fit in one pass, the others take two.
+  const size_t row_bytes = (size_t)(W + kRowPad) * 5, fixed = kHdrBytes + kPartBytes, half = kMaxLds / 2;
+  size_t lds = fixed + (size_t)rows * row_bytes;
+  int waves = g_tune.bwd_waves;
+  if (waves == 0) waves = (lds > half && (long long)N >= 2LL * num_cus() && half >= fixed + 8 * row_bytes) ? 8 : 16;
+  if (waves == 8 && lds > half && half >= fixed + 8 * row_bytes) {
+    rows = (int)((half - fixed) / row_bytes) & ~7;
+    lds = fixed + (size_t)rows * row_bytes;
+  }
+  const int gridx = persistent_grid(N, 1, lds, kZWaves);   // (any backward workgroup has a prefetch wave to spare)
+  if (waves == 8)
+    return gridx < N ? launch_zbuf_bwd_p<VEC4, POW2, true, 8>(sp, grad, argmin, N, J, H, W, gs, rows, lds, gridx, s)
+                     : launch_zbuf_bwd_p<VEC4, POW2, false, 8>(sp, grad, argmin, N, J, H, W, gs, rows, lds, gridx, s);
+  return gridx < N ? launch_zbuf_bwd_p<VEC4, POW2, true, 16>(sp, grad, argmin, N, J, H, W, gs, rows, lds, gridx, s)
+                   : launch_zbuf_bwd_p<VEC4, POW2, false, 16>(sp, grad, argmin, N, J, H, W, gs, rows, lds, gridx, s);
 }
 
 template <bool VEC4>
@@ -182,6 +197,7 @@ extern "C" int shr_set_tuning(int key, int value) {
       g_tune.fwd_waves = value;
       return SHR_OK;
     case 99: g_tune.lds_pad = value; return SHR_OK;
+    case SHR_TUNE_BWD_WAVES: if (value != 0 && value != 8 && value != 16) return SHR_EINVAL; g_tune.bwd_waves = value; return SHR_OK;
     case SHR_TUNE_FWD_ZBUF_BYTES: if (value < 0) return SHR_EINVAL; g_tune.fwd_zbuf_bytes = value; return SHR_OK;
     case SHR_TUNE_PERSISTENT: if (value < 0) return SHR_EINVAL; g_tune.persistent = value; return SHR_OK;
     case SHR_TUNE_D2M_WAVES: return d2m_set_waves(value);

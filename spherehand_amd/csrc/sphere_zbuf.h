@@ -734,18 +734,30 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
 }
 
 // ---------------------------------------------------------------------------
-// Backward with the forward's owner map.  grid = (N), block = 1024, dynamic LDS =
-// kHdrBytes + 16*64*16 (wave x sphere partial sums) + (rows + kPadRows) * (W +
-// kRowPad) * (4 + 1).
+// Backward with the forward's owner map.  grid = (N or fewer), block = 64 * NW (NW = 16, or 8 when two
+// workgroups share a CU), dynamic LDS = kHdrBytes + 16*64*16 (wave x sphere partial sums) + rows * (W +
+// kRowPad) * (4 + 1), `rows` = the rows of the crop the staging buffers hold.
+//
+// Only the TOUCHED ROWS [cv0, cv1] of the crop are staged and walked, from row cv0 on: a crop whose touched rows
+// exceed the buffers is done in passes of `rows` rows (the work list is rebuilt clipped to each pass, the
+// partial sums carry over).  With at least two workgroups per CU in the launch the launcher gives a workgroup
+// half of the CU's LDS (88 rows of a 128-wide crop: one pass for 9 hand crops of 10) and 8 waves, so that two
+// resident workgroups overlap one crop's staging (HBM latency) with the other's walk (VALU issue).
 constexpr int kPartBytes = kZWaves * SHR_MAX_SPHERES * 16;
 constexpr int kStageBatch = 4;   // backward: units (16-byte chunks per lane) requested per wait while staging
 constexpr int kSpecUnits = 2;    // ... and units per wave requested before the touched rows are known
+// The speculative units land in v[96:105], registers the compiler does not allocate (the kernel is limited to the
+// 96 below them): a request whose destination is an asm OUTPUT counts as available at once, and the compiler did
+// copy such registers -- before the data was there -- as soon as the path from the request to its wait branched.
+constexpr int kBwdVgprs = 96;
 
-template <bool VEC4, bool POW2, bool PERSIST>
-__global__ void __launch_bounds__(1024)
+template <bool VEC4, bool POW2, bool PERSIST, int NW>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_num_vgpr(kBwdVgprs)))
 sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restrict__ grad_depth,
                        const uint8_t *__restrict__ argmin, int N, int J_, int H_, int W_,
-                       float4 *__restrict__ grad_spheres, int rows_per_region_, int w4_shift_, int shares) {
+                       float4 *__restrict__ grad_spheres, int rows_, int w4_shift_, int shares) {
+  static_assert(NW == 8 || NW == 16, "waves per workgroup");
+  constexpr int NT = 64 * NW, NW_SHIFT = NW == 16 ? 4 : 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
   int4 *s_items = reinterpret_cast<int4 *>(smem + kOffItems);
@@ -760,118 +772,130 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   // Every crop starts from OPAQUE copies of the launch constants and of the thread index: otherwise the compiler
   // hoists each crop-invariant value out of the crop loop and keeps it in a register (forward: 92 instead of 51
   // VGPRs; the fused kernel spilled).
-  int J = J_, H = H_, W = W_, rows_per_region = rows_per_region_, w4_shift = w4_shift_, tid = threadIdx.x;
+  int J = J_, H = H_, W = W_, rows = rows_, w4_shift = w4_shift_, tid = threadIdx.x;
   if (PERSIST) {
-    asm volatile("" : "+s"(J), "+s"(H), "+s"(W), "+s"(rows_per_region), "+s"(w4_shift));
+    asm volatile("" : "+s"(J), "+s"(H), "+s"(W), "+s"(rows), "+s"(w4_shift));
     asm volatile("" : "+v"(tid));
   }
   const int lane = tid & 63, wave = tid >> 6;
   const int LW = W + kRowPad;
   float *gbuf = reinterpret_cast<float *>(smem + kHdrBytes + kPartBytes);
-  uint8_t *obuf = smem + kHdrBytes + kPartBytes + (size_t)(rows_per_region + kPadRows) * LW * 4;
+  uint8_t *obuf = smem + kHdrBytes + kPartBytes + (size_t)(rows + kPadRows) * LW * 4;
   const Axis ax = make_axis(W), ay = make_axis(H);
   const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
   typedef float v4f __attribute__((ext_vector_type(4)));
   const int wave_s = rfl(wave);
-  // Every wave requests the crop's records (lane j = sphere j) with an explicit instruction so
-  // that the staging requests below can be queued behind it and awaited separately.
-  // The four OLDEST waves (one per SIMD: the arbitration serves them first, their requests head
-  // the memory queue) read the records: wave 0 builds the work list, waves 1-3 derive the touched
-  // rows and request what step 2 of the staging needs, for the whole workgroup.  A young wave's
-  // copy of the records arrived up to 3 k cycles later and held the barrier.
-  const bool lead = wave_s < 4, p2_wave = wave_s >= 1 && wave_s < 4;
-  const bool pf_wave = wave_s == kZWaves - 1;
+  // The four OLDEST waves (one per SIMD: the arbitration serves them first, their requests head the memory
+  // queue) read the crop's records (lane j = sphere j), with an explicit instruction so that the staging requests
+  // below can be queued behind it and awaited separately: wave 0 builds the work list, all four derive the
+  // touched rows.  A young wave's copy of the records arrived up to 3 k cycles later and held the barrier.
+  const bool lead = wave_s < 4;
+  const bool pf_wave = wave_s == NW - 1;
   const float *gin = grad_depth + (size_t)n * H * W;
   const uint8_t *oin = argmin + (size_t)n * H * W;
   const float4 *rec = spheres + (size_t)n * J;
   const bool has_next = PERSIST && n + crop_step < N;
-  v4f sphv = {0.f, 0.f, 0.f, 0.f}, nextv = {0.f, 0.f, 0.f, 0.f};
+  // (the records land in v[110:113], the next crop's in v[106:109]: registers outside the compiler's, see kBwdVgprs)
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
   bool have_sph = false;
   if (crop_it == 0) {
-    if (lead) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sphv) : "v"(rec + min(lane, J - 1)));
+    if (lead)
+      asm volatile("global_load_dwordx4 v[110:113], %0, off" : : "v"(rec + min(lane, J - 1)) : "v110", "v111", "v112", "v113", "memory");
   } else if (lead) {
     if (lane < J) sph = s_next[lane];
     have_sph = true;
-    if (wave_s == 0) s_sph[lane] = sph;
   }
-  s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // 1024 = 16 waves x 64 spheres
+  for (int i = tid; i < kZWaves * SHR_MAX_SPHERES; i += NT) s_part[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // [wave][sphere]
 
-  for (int r0 = 0; r0 < H; r0 += rows_per_region) {
-    const int r1 = min(H, r0 + rows_per_region), rh = r1 - r0;
-    if (r0 > 0) __syncthreads();  // the previous region's walk is done
+  // ---- stage grad_depth + owner map ------------------------------------------------------
+  // Reading is the bandwidth-bound part (82 KB per 128x128 crop arrive in ~8 k cycles when all CUs read), and
+  // only the rows some sphere's box touches are ever looked at (half of a hand crop).  Those rows are known once
+  // the records have arrived, so the staging is split: the central half of the crop is requested at once,
+  // SPECULATIVELY, by all waves (units = 64 consecutive 16-byte chunks of the crop, unit u belongs to wave u mod
+  // NW); what the touched rows need beyond it is requested when the records are in.
+  const int w4 = W >> 2;
+  const int nchunk = H * w4;
+  const int nunits = (nchunk + 63) >> 6;
+  const float4 *gin4 = reinterpret_cast<const float4 *>(gin);
+  const uchar4 *oin4 = reinterpret_cast<const uchar4 *>(oin);
+  int uc0 = nunits >> 2;                                          // the speculative units: the central [uc0, uc1)
+  int uc1 = min(nunits - uc0, uc0 + NW * kSpecUnits);
+  const int k1 = (max(uc0 - wave_s, 0) + NW - 1) >> NW_SHIFT;     // this wave's first central unit is wave + NW k1
+  static_assert(kSpecUnits == 2, "two speculative units per wave: v[96:99] + v104, v[100:103] + v105");
+  if (VEC4) {
+    // (an absent unit re-reads the records: the count of requests in flight stays fixed)
+    const int u0 = wave_s + (k1 << NW_SHIFT), u1 = wave_s + ((k1 + 1) << NW_SHIFT);
+    const int c0 = min((u0 << 6) + lane, nchunk - 1), c1 = min((u1 << 6) + lane, nchunk - 1);
+    const void *pg0 = u0 < uc1 ? static_cast<const void *>(gin4 + c0) : static_cast<const void *>(rec);
+    const void *po0 = u0 < uc1 ? static_cast<const void *>(oin4 + c0) : static_cast<const void *>(rec);
+    const void *pg1 = u1 < uc1 ? static_cast<const void *>(gin4 + c1) : static_cast<const void *>(rec);
+    const void *po1 = u1 < uc1 ? static_cast<const void *>(oin4 + c1) : static_cast<const void *>(rec);
+    asm volatile("global_load_dwordx4 v[96:99], %0, off\n\tglobal_load_dword v104, %1, off\n\t"
+                 "global_load_dwordx4 v[100:103], %2, off\n\tglobal_load_dword v105, %3, off"
+                 : : "v"(pg0), "v"(po0), "v"(pg1), "v"(po1)
+                 : "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "memory");
+  }
+  // owner padding = "nobody": the walk may overhang the image edge
+  for (int i = tid; i < rows * kRowPad; i += NT) obuf[(i / kRowPad) * LW + W + (i % kRowPad)] = SHR_ARGMIN_NONE;
+  if (lead) {
+    if (!have_sph) {
+      float4 t;
+      if (VEC4)
+        asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, v110\n\tv_mov_b32 %1, v111\n\tv_mov_b32 %2, v112\n\tv_mov_b32 %3, v113"
+                     : "=v"(t.x), "=v"(t.y), "=v"(t.z), "=v"(t.w) : "n"(2 * kSpecUnits) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v110\n\tv_mov_b32 %1, v111\n\tv_mov_b32 %2, v112\n\tv_mov_b32 %3, v113"
+                     : "=v"(t.x), "=v"(t.y), "=v"(t.z), "=v"(t.w) : : "memory");
+      if (lane < J) sph = t;
+    }
+    int t0, t1;
+    touched_rows(sph, lane < J, ay, ky, 0, H, t0, t1);
+    if (wave_s == 0) {
+      s_sph[lane] = sph;
+      if (lane == 0) { s_flag[2] = t0; s_flag[3] = t1; }
+    }
+  }
+  __syncthreads();   // the touched rows are known to every wave (the others arrive here straight from their requests)
+  const int cv0 = rfl(s_flag[2]), cv1 = rfl(s_flag[3]);
 
-    // ---- stage grad_depth + owner map --------------------------------------------------
-    // Reading is the bandwidth-bound part (82 KB per 128x128 crop arrive in ~8 k cycles when
-    // all CUs read), and only the rows some sphere's box touches are ever looked at (half of
-    // a hand crop).  Those rows are known once the records have arrived, so the staging is
-    // split: the central half of the region is requested at once, speculatively, by all waves
-    // (units = 64 consecutive 16-byte chunks, unit u belongs to wave u mod 16); what the
-    // touched rows need beyond it is requested by waves 1-3 as soon as THEIR records are in.
-    const int w4 = W >> 2;
-    const int nchunk = rh * w4;
-    const int nunits = (nchunk + 63) >> 6;
-    const float4 *gin4 = reinterpret_cast<const float4 *>(gin + (size_t)r0 * W);
-    const uchar4 *oin4 = reinterpret_cast<const uchar4 *>(oin + (size_t)r0 * W);
-    const int uc0 = nunits >> 2;                                          // step 1 covers the central units [uc0, uc1)
-    const int uc1 = min(nunits - uc0, uc0 + kZWaves * kSpecUnits);
-    const int k1 = (max(uc0 - wave_s, 0) + kZWaves - 1) >> 4;  // this wave's first central unit is wave + 16 k1
-    v4f g1[kSpecUnits];
-    uint32_t o1[kSpecUnits];
-    auto put_unit = [&](int u, const v4f g, uint32_t o) {
-      const int c = (u << 6) + lane;
-      if (c < nchunk) {
-        int v, x;
-        if (POW2 || w4_shift >= 0) { v = c >> w4_shift; x = (c & (w4 - 1)) << 2; }
-        else { v = c / w4; x = (c - v * w4) << 2; }
-        *reinterpret_cast<v4f *>(gbuf + v * LW + x) = g;
-        *reinterpret_cast<uint32_t *>(obuf + v * LW + x) = o;
-      }
-    };
-    if (VEC4) {
-#pragma unroll
-      for (int b = 0; b < kSpecUnits; b++) {
-        // (an absent unit re-reads the records: the count of requests in flight stays fixed)
-        const int u = wave_s + ((k1 + b) << 4);
-        const int c = min((u << 6) + lane, nchunk - 1);
-        const void *pg = u < uc1 ? static_cast<const void *>(gin4 + c) : static_cast<const void *>(rec);
-        const void *po = u < uc1 ? static_cast<const void *>(oin4 + c) : static_cast<const void *>(rec);
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(g1[b]) : "v"(pg));
-        asm volatile("global_load_dword %0, %1, off" : "=v"(o1[b]) : "v"(po));
-      }
-    }
-    // owner padding = "nobody": the walk may overhang the image edge / region end
-    for (int i = tid; i < rh * kRowPad; i += 1024) obuf[(i / kRowPad) * LW + W + (i % kRowPad)] = SHR_ARGMIN_NONE;
-    for (int i = tid; i < kPadRows * LW; i += 1024) obuf[rh * LW + i] = SHR_ARGMIN_NONE;
-    if (lead && !have_sph) {
-      if (VEC4) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(sphv) : "n"(2 * kSpecUnits) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(sphv) : : "memory");
-      if (lane < J) sph = make_float4(sphv.x, sphv.y, sphv.z, sphv.w);
-      have_sph = true;
-      if (wave_s == 0) s_sph[lane] = sph;
-    }
+  // Passes over the touched rows (one, unless they exceed the staging buffers).  The first pass's list and
+  // staging stand in front of the loop: the registers of the speculative requests must not become loop-carried
+  // values (the compiler would copy them at the loop's entry, before the data has landed).
+  auto build_list = [&](int r0, int r1) {
     if (wave_s == 0) {
       bool too_big;   // excluded by the launcher (W <= kMaxFastWidth)
       const int total = build_work_list<kSphereCostBwd>(sph, lane < J, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
       if (lane == 0) s_flag[1] = total;
     }
-    if (VEC4) {
-      int ua = nunits, ub = nunits;
-      if (p2_wave) {
-        int cv0, cv1;
-        touched_rows(sph, lane < J, ay, ky, r0, r1, cv0, cv1);
-        if (cv1 >= cv0) { ua = ((cv0 - r0) * w4) >> 6; ub = min(nunits, ((cv1 - r0 + 1) * w4 + 63) >> 6); }
-        ua = rfl(ua);
-        ub = rfl(ub);
+  };
+  auto stage = [&](int r0, int r1, auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const int rh = r1 - r0;
+    auto put_unit = [&](int u, const v4f g, uint32_t o) {
+      const int c = (u << 6) + lane;
+      int v, x;
+      if (POW2 || w4_shift >= 0) { v = c >> w4_shift; x = (c & (w4 - 1)) << 2; }
+      else { v = c / w4; x = (c - v * w4) << 2; }
+      if (c < nchunk && (unsigned)(v - r0) < (unsigned)rh) {   // (a unit may straddle the pass's first or last row)
+        *reinterpret_cast<v4f *>(gbuf + (v - r0) * LW + x) = g;
+        *reinterpret_cast<uint32_t *>(obuf + (v - r0) * LW + x) = o;
       }
-      // step 2: the touched units outside step 1's, [ua, min(ub, uc0)) and [max(ua, uc1), ub), dealt to waves 1-3
-      const int n_lo = max(0, min(ub, uc0) - ua), hi0 = max(ua, uc1), n_out = n_lo + max(0, ub - hi0);
-      bool spec_stored = false;
-      for (int t0 = wave_s - 1; p2_wave && t0 < n_out; t0 += 3 * kStageBatch) {
-        // The requests and their wait are ONE asm statement: the compiler treats an asm
-        // result as available at once and may copy it before a separate wait.  A slot
-        // without a unit re-reads the records (no control flow around the statement).
-        static_assert(kStageBatch == 4, "the staging statement below names four slots");
+    };
+    if (VEC4) {
+      // the pass's units [ua, ub); those outside the speculative range (first pass only), [ua, min(ub, uc0)) and
+      // [max(ua, uc1), ub), are dealt to the waves now
+      const int ua = (r0 * w4) >> 6, ub = min(nunits, (r1 * w4 + 63) >> 6);
+      const int s0 = FIRST ? uc0 : 0, s1 = FIRST ? uc1 : 0;
+      const int n_lo = max(0, min(ub, s0) - ua), hi0 = max(ua, s1), n_out = n_lo + max(0, ub - hi0);
+      // A batch = kStageBatch units per wave; its requests and their wait are ONE asm statement: the compiler
+      // treats an asm result as available at once and may copy it before a separate wait.  A slot without a unit
+      // re-reads the records (no control flow around the statement).  The first pass's first batch is
+      // unconditional and also lands the speculative units: their registers go from the requests above to that
+      // statement in a straight line (on a branchy path the compiler copies them -- before the data is there).
+      static_assert(kStageBatch == 4, "the staging statements below name four slots");
+      static_assert(kSpecUnits == 2, "... and tie two speculative units");
+      auto batch = [&](int t0, auto with_spec_tag) {
+        constexpr bool first_batch = decltype(with_spec_tag)::value;
         v4f g2[kStageBatch];
         uint32_t o2[kStageBatch];
         bool ok[kStageBatch];
@@ -879,68 +903,88 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
         int us[kStageBatch];
 #pragma unroll
         for (int b = 0; b < kStageBatch; b++) {
-          const int t = t0 + 3 * b;
+          const int t = t0 + NW * b;
           ok[b] = t < n_out;                                                  // wave-uniform
           const int u = us[b] = t < n_lo ? ua + t : hi0 + (t - n_lo);
           const int c = min(max((u << 6) + lane, 0), nchunk - 1);
           pg[b] = ok[b] ? static_cast<const void *>(gin4 + c) : static_cast<const void *>(rec);
           po[b] = ok[b] ? static_cast<const void *>(oin4 + c) : static_cast<const void *>(rec);
         }
-        asm volatile(
-            "global_load_dwordx4 %0, %12, off\n\tglobal_load_dword %4, %16, off\n\t"
-            "global_load_dwordx4 %1, %13, off\n\tglobal_load_dword %5, %17, off\n\t"
-            "global_load_dwordx4 %2, %14, off\n\tglobal_load_dword %6, %18, off\n\t"
-            "global_load_dwordx4 %3, %15, off\n\tglobal_load_dword %7, %19, off\n\t"
-            "s_waitcnt vmcnt(0)"
-            : "=&v"(g2[0]), "=&v"(g2[1]), "=&v"(g2[2]), "=&v"(g2[3]), "=&v"(o2[0]), "=&v"(o2[1]), "=&v"(o2[2]),
-              "=&v"(o2[3]), "+v"(g1[0]), "+v"(g1[1]), "+v"(o1[0]), "+v"(o1[1])   // the speculative batch lands here too
-            : "v"(pg[0]), "v"(pg[1]), "v"(pg[2]), "v"(pg[3]), "v"(po[0]), "v"(po[1]), "v"(po[2]), "v"(po[3])
-            : "memory");
-        static_assert(kSpecUnits == 2, "the statement above ties two speculative units");
-        if (!spec_stored) {
-#pragma unroll
-          for (int b = 0; b < kSpecUnits; b++) {
-            const int u = wave_s + ((k1 + b) << 4);
-            if (u < uc1) put_unit(u, g1[b], o1[b]);
-          }
-          spec_stored = true;
+        if (FIRST && first_batch) {
+          float4 sa, sb;       // the two speculative units, fetched from their registers once everything has landed
+          uint32_t soa, sob;
+          asm volatile(
+              "global_load_dwordx4 %0, %18, off\n\tglobal_load_dword %4, %22, off\n\t"
+              "global_load_dwordx4 %1, %19, off\n\tglobal_load_dword %5, %23, off\n\t"
+              "global_load_dwordx4 %2, %20, off\n\tglobal_load_dword %6, %24, off\n\t"
+              "global_load_dwordx4 %3, %21, off\n\tglobal_load_dword %7, %25, off\n\t"
+              "s_waitcnt vmcnt(0)\n\t"      // ... the speculative units have landed too: fetch them
+              "v_mov_b32 %8, v96\n\tv_mov_b32 %9, v97\n\tv_mov_b32 %10, v98\n\tv_mov_b32 %11, v99\n\t"
+              "v_mov_b32 %12, v100\n\tv_mov_b32 %13, v101\n\tv_mov_b32 %14, v102\n\tv_mov_b32 %15, v103\n\t"
+              "v_mov_b32 %16, v104\n\tv_mov_b32 %17, v105"
+              : "=&v"(g2[0]), "=&v"(g2[1]), "=&v"(g2[2]), "=&v"(g2[3]), "=&v"(o2[0]), "=&v"(o2[1]), "=&v"(o2[2]),
+                "=&v"(o2[3]), "=&v"(sa.x), "=&v"(sa.y), "=&v"(sa.z), "=&v"(sa.w), "=&v"(sb.x), "=&v"(sb.y),
+                "=&v"(sb.z), "=&v"(sb.w), "=&v"(soa), "=&v"(sob)
+              : "v"(pg[0]), "v"(pg[1]), "v"(pg[2]), "v"(pg[3]), "v"(po[0]), "v"(po[1]), "v"(po[2]), "v"(po[3])
+              : "memory");
+          const int u0 = wave_s + (k1 << NW_SHIFT), u1 = wave_s + ((k1 + 1) << NW_SHIFT);
+          if (u0 < uc1) put_unit(u0, v4f{sa.x, sa.y, sa.z, sa.w}, soa);
+          if (u1 < uc1) put_unit(u1, v4f{sb.x, sb.y, sb.z, sb.w}, sob);
+        } else {
+          asm volatile(
+              "global_load_dwordx4 %0, %8, off\n\tglobal_load_dword %4, %12, off\n\t"
+              "global_load_dwordx4 %1, %9, off\n\tglobal_load_dword %5, %13, off\n\t"
+              "global_load_dwordx4 %2, %10, off\n\tglobal_load_dword %6, %14, off\n\t"
+              "global_load_dwordx4 %3, %11, off\n\tglobal_load_dword %7, %15, off\n\t"
+              "s_waitcnt vmcnt(0)"
+              : "=&v"(g2[0]), "=&v"(g2[1]), "=&v"(g2[2]), "=&v"(g2[3]), "=&v"(o2[0]), "=&v"(o2[1]), "=&v"(o2[2]),
+                "=&v"(o2[3])
+              : "v"(pg[0]), "v"(pg[1]), "v"(pg[2]), "v"(pg[3]), "v"(po[0]), "v"(po[1]), "v"(po[2]), "v"(po[3])
+              : "memory");
         }
 #pragma unroll
         for (int b = 0; b < kStageBatch; b++)
           if (ok[b]) put_unit(us[b], g2[b], o2[b]);
+      };
+      int t0 = wave_s;
+      if (FIRST) {
+        batch(t0, std::true_type());
+        t0 += NW * kStageBatch;
       }
-      if (!spec_stored) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(g1[0]), "+v"(g1[1]), "+v"(o1[0]), "+v"(o1[1]) : : "memory");
-#pragma unroll
-        for (int b = 0; b < kSpecUnits; b++) {
-          const int u = wave_s + ((k1 + b) << 4);
-          if (u < uc1) put_unit(u, g1[b], o1[b]);
-        }
-      }
+      for (; t0 < n_out; t0 += NW * kStageBatch) batch(t0, std::false_type());
     } else {
-      for (int p = tid; p < rh * W; p += 1024) {
+      for (int p = tid; p < rh * W; p += NT) {
         const int v = p / W, u = p - v * W;
         gbuf[v * LW + u] = gin[(size_t)(r0 + v) * W + u];
         obuf[v * LW + u] = oin[(size_t)(r0 + v) * W + u];
       }
     }
+  };
+  if (cv1 >= cv0) {
+    build_list(cv0, min(cv0 + rows, cv1 + 1));
+    stage(cv0, min(cv0 + rows, cv1 + 1), std::true_type());
+  } else if (VEC4) {   // no touched row at all: the speculative requests still have to land before their registers are reused
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+  }
+  if (pf_wave && has_next)   // the next crop's records (its own staging requests have landed: nothing queues behind them)
+    asm volatile("global_load_dwordx4 v[106:109], %0, off" : : "v"(spheres + (size_t)(n + crop_step) * J + min(lane, J - 1))
+                 : "v106", "v107", "v108", "v109", "memory");
+  for (int r0 = cv0; r0 <= cv1;) {
+    const int r1 = min(r0 + rows, cv1 + 1), rh = r1 - r0;
     __syncthreads();
-    if (pf_wave && has_next && r0 == 0)
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nextv) : "v"(spheres + (size_t)(n + crop_step) * J + min(lane, J - 1)));
 
-    // Static schedule: wave w walks the w-th of 16 equal-weight contiguous slices of the
-    // list (which wave sums which pixels must not depend on timing); at the end of a
-    // run on a sphere its register partials are reduced with one DPP wave sum per
-    // component into the wave's private LDS slot.
+    // Static schedule: wave w walks the w-th contiguous slice of the list (which wave sums which pixels must
+    // not depend on timing); at the end of a run on a sphere its register partials are reduced with one
+    // transposed wave sum into the wave's private LDS slot.
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const int cell_max = (rh + kPadRows) * LW - 1;
+    const int cell_max = rh * LW - 1;
     const WaveList wl = load_wave_list(s_sph, s_items, s_ends, lane);
     walk_my_slice<POW2, kSphereCostBwd, false>(
-        wl, J, s_flag[1], wave, kZWaves, shares, lane, ax, ay, r0, r1, LW,
+        wl, J, s_flag[1], wave, NW, shares, lane, ax, ay, r0, r1, LW,
         [&](int j, const float4 s, int cell_a, int cell_b, float dx, float ca, float yga, float ygb, bool ok_a,
             bool ok_b, bool has_b, auto) {
           auto take = [&](int cell, float yg, bool ok) {
-            // lanes without a pixel may point past the region: clamped, and never counted.  Most
+            // lanes without a pixel may point past the pass: clamped, and never counted.  Most
             // chunks own nothing: only the owner byte is looked at, dy and q are formed for owned
             // pixels (a branch-free form with all four LDS reads in flight measured slower)
             cell = min(cell, cell_max);
@@ -959,21 +1003,29 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
         },
         [&](int j) {
           // (the slot belongs to this wave: ds_add_f32 in program order, no read-back to wait for;
-          // a crop of several row regions visits a sphere once per region)
+          // a crop of several passes visits a sphere once per pass)
           const float t = wave_sum4_transposed(a0, a1, a2, a3, lane);
           if (lane >= 60) atomicAdd(reinterpret_cast<float *>(s_part + wave * SHR_MAX_SPHERES + j) + (lane & 3), t);
           a0 = a1 = a2 = a3 = 0.f;
         });
+    r0 += rows;
+    if (r0 <= cv1) {
+      __syncthreads();  // this pass's walk is done: list and buffers are rewritten
+      build_list(r0, min(r0 + rows, cv1 + 1));
+      stage(r0, min(r0 + rows, cv1 + 1), std::false_type());
+    }
   }
   if (pf_wave && has_next) {   // (arrived long ago: the wave's own walk lies in between)
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(nextv) : : "memory");
-    s_next[lane] = make_float4(nextv.x, nextv.y, nextv.z, nextv.w);
+    float4 t;
+    asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v106\n\tv_mov_b32 %1, v107\n\tv_mov_b32 %2, v108\n\tv_mov_b32 %3, v109"
+                 : "=v"(t.x), "=v"(t.y), "=v"(t.z), "=v"(t.w) : : "memory");
+    s_next[lane] = t;
   }
   __syncthreads();
   // combine the waves' partials in wave order; d/dr = r * sum(-g/sqrt(q))
   if (tid < J) {
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int w = 0; w < kZWaves; w++) {
+    for (int w = 0; w < NW; w++) {
       const float4 a = s_part[w * SHR_MAX_SPHERES + tid];
       t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
     }

@@ -32,6 +32,7 @@ def sphere_case():
     ops.set_tuning(ops.TUNE_FWD_WAVES, 4 if mode == 3 else 16)
     zb = int(rs.choice([0, 0, 6, 20, 48, 80])) * 1024                           # forward z-buffer: several row bands per box
     ops.set_tuning(ops.TUNE_FWD_ZBUF_BYTES, zb)
+    ops.set_tuning(ops.TUNE_BWD_WAVES, int(rs.choice([0, 8, 16])))
     d, a = ops.sphere_raster_fwd(dev(sp), H, W, want_argmin=True)
     od, oa = oracle.sphere_raster_fwd(sp, H, W)
     if not np.isfinite(sp).all() or np.abs(sp).max() > 1e20:
@@ -43,23 +44,32 @@ def sphere_case():
             print("SPHERE (non-finite) MISMATCH", dict(N=N, J=J, H=H, W=W, mode=mode, zb=zb))
         return
     ok = np.array_equal(bits(d.cpu().numpy()), bits(od)) and np.array_equal(a.cpu().numpy(), oa)
+    why = [] if ok else ['fwd depth %d px, owner %d px' % (int((bits(d.cpu().numpy()) != bits(od)).sum()), int((a.cpu().numpy() != oa).sum()))]
     gd = rs.standard_normal((N, H, W)).astype(np.float32)
     og = oracle.sphere_raster_bwd(sp, gd)
     for owner in (a, None):
         gs = ops.sphere_raster_bwd(dev(sp), dev(gd), owner).cpu().numpy()
-        ok = ok and bool(np.abs(gs - og).max() <= 1e-5 * np.abs(og).max() + 2e-4)
+        okb = bool(np.abs(gs - og).max() <= 1e-5 * np.abs(og).max() + 2e-4)
+        if not okb: why.append('bwd(%s) err %.3g of %.3g' % ('owner map' if owner is not None else 'recomputed', np.abs(gs - og).max(), np.abs(og).max()))
+        ok = ok and okb
     tgt = rs.uniform(-50, 100, (N, H, W)).astype(np.float32)
     if ops.sphere_raster_mse_supported(dev(sp), dev(tgt), H, W):
         dep, sse, gsp = ops.sphere_raster_mse(dev(sp), dev(tgt))
         e = (od.astype(np.float64) - tgt)
-        ok = ok and np.array_equal(bits(dep.cpu().numpy()), bits(od))
         ref_sse = (e * e).reshape(N, -1).sum(1)
-        ok = ok and bool(np.abs(sse.double().cpu().numpy() - ref_sse).max() <= 1e-5 * ref_sse.max() + 1e-3)
         og2 = oracle.sphere_raster_bwd(sp, (2 * (od - tgt)).astype(np.float32))
-        ok = ok and bool(np.abs(gsp.cpu().numpy() - og2).max() <= 2e-5 * np.abs(og2).max() + 1e-3)
+        checks = {'fused depth': np.array_equal(bits(dep.cpu().numpy()), bits(od)),
+                  'fused sse err %.3g of %.3g' % (np.abs(sse.double().cpu().numpy() - ref_sse).max(), ref_sse.max()):
+                      bool(np.abs(sse.double().cpu().numpy() - ref_sse).max() <= 1e-5 * ref_sse.max() + 1e-3),
+                  'fused grad err %.3g of %.3g' % (np.abs(gsp.cpu().numpy() - og2).max(), np.abs(og2).max()):
+                      bool(np.abs(gsp.cpu().numpy() - og2).max() <= 2e-5 * np.abs(og2).max() + 1e-3)}
+        why += [k for k, v in checks.items() if not v]
+        ok = ok and all(checks.values())
     if not ok:
         fails += 1
-        print("SPHERE MISMATCH", dict(N=N, J=J, H=H, W=W, scale=scale, mode=mode, zb=zb))
+        print("SPHERE MISMATCH", dict(N=N, J=J, H=H, W=W, scale=scale, mode=mode, zb=zb), why)
+        if os.environ.get("FUZZ_DUMP"):
+            np.savez(os.environ["FUZZ_DUMP"], sp=sp, gd=gd, tgt=tgt, H=H, W=W, mode=mode, zb=zb)
 
 def tri_case():
     global fails
