@@ -73,18 +73,35 @@ template <bool KEEP_SQ>
 __device__ __forceinline__ void tile_min(unsigned long long mask, int J, const float4 sph,
                                          const TileGeom &g, float best[4], int owner[4],
                                          float bsq[4]) {
-  // A culled sphere is a miss (= 100) for every pixel of the tile; only if all J
-  // spheres are candidates can a pixel's minimum exceed 100.
-  const bool all_cand = (__popcll(mask) == J);
+  // torch.min over the J maps keeps the FIRST index at the minimum, so the maps are merged in index order: a
+  // candidate's map is its hit depth or the background (a miss), a culled sphere's is the background at every
+  // pixel of the tile -- the lowest culled index c0 takes its turn between the candidates below and above it.
+  // (Only then is a hit at exactly 100.0 attributed as the reference does: it owns the pixel -- and gets its
+  // gradient -- iff no lower index holds 100 there.)
+  const unsigned long long all = J >= 64 ? ~0ull : ((1ull << J) - 1ull);
+  const unsigned long long culled = ~mask & all;
+  const int c0 = culled ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(culled)) : J;
+  bool pending = culled != 0ull;   // wave-uniform
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    best[k] = all_cand ? __builtin_inff() : kBackground;
+    best[k] = __builtin_inff();
     owner[k] = SHR_ARGMIN_NONE;
     if (KEEP_SQ) bsq[k] = 1.0f;
   }
+  auto miss = [&](int k) {
+    if (kBackground < best[k]) {   // (a NaN minimum stays)
+      best[k] = kBackground;
+      owner[k] = SHR_ARGMIN_NONE;
+    }
+  };
   while (mask) {
     const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
     mask &= mask - 1;
+    if (pending && j > c0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) miss(k);
+      pending = false;
+    }
     const float sx = readlane_f(sph.x, j), sy = readlane_f(sph.y, j);
     const float sz = readlane_f(sph.z, j), sr = readlane_f(sph.w, j);
     const float rr = sr * sr;
@@ -104,13 +121,14 @@ __device__ __forceinline__ void tile_min(unsigned long long mask, int J, const f
           owner[k] = j;
           if (KEEP_SQ) bsq[k] = sq;
         }
-      } else if (all_cand) {
-        if (kBackground < best[k]) {
-          best[k] = kBackground;
-          owner[k] = SHR_ARGMIN_NONE;
-        }
+      } else {
+        miss(k);
       }
     }
+  }
+  if (pending) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) miss(k);
   }
 }
 

@@ -68,6 +68,17 @@ __device__ __forceinline__ uint32_t depth_key(float d) {
 __device__ __forceinline__ float key_depth(uint32_t k) {
   return __uint_as_float(k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu));
 }
+// 64-bit cells (depth key << 32 | owner).  The BACKGROUND cell sits one depth key below 100 with an all-ones low
+// word: every hit in front of the background beats it (its depth key is smaller, or equal with a low word < 2^32 - 1),
+// and a hit at EXACTLY 100.0 does not -- torch.min keeps the first index at the minimum, and on the fast path
+// that is sphere 0's map, which holds the background there (the fast path requires z0 <= 100: sphere 0's own hits
+// are then all in front of it).  The owner byte of a background cell reads 255 = SHR_ARGMIN_NONE.
+__device__ __forceinline__ unsigned long long background_cell() {
+  return ((unsigned long long)(depth_key(kBackground) - 1u) << 32) | 0xFFFFFFFFull;
+}
+__device__ __forceinline__ float cell_depth(unsigned long long k) {   // (the background's key is one short of 100)
+  return key_depth((uint32_t)(k >> 32) - (uint32_t)((int32_t)(uint32_t)k >> 31));
+}
 
 // Correctly rounded sqrt for a normal, positive, finite fp32 argument (here
 // q > 0.01): the hardware estimate (v_sqrt_f32, <= 1 ulp) corrected by the exact
@@ -514,8 +525,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
   if (valid && (list_wave || bg_wave)) sph = crop_it == 0 ? spheres[(size_t)n * J + lane] : s_next[lane];
 
-  const Key bg = OWNER ? (Key)(((unsigned long long)depth_key(kBackground) << 32) | SHR_ARGMIN_NONE)
-                       : (Key)depth_key(kBackground);
+  const Key bg = OWNER ? (Key)background_cell() : (Key)depth_key(kBackground);
   auto init_zbuf = [&](int ncell) {   // background everywhere
     constexpr int per16 = 16 / sizeof(Key);
     const int nvec = ncell / per16;
@@ -538,15 +548,16 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
 
   if (list_wave) {
     s_sph[lane] = sph;
-    // general path unless every sphere is tame and at least one has z <= 100: a pixel's
-    // minimum can exceed the background only where ALL J spheres hit it, and there the
-    // sphere with z <= 100 contributes z - sqrt(q) < 100, so min(100, hits) is exact.
+    // general path unless every sphere is tame and sphere 0 has z <= 100: sphere 0's map is then the
+    // background wherever it does not hit and in front of it (z - sqrt(q) < 100) where it does, so a
+    // pixel's minimum never exceeds the background -- min(100, hits) is exact -- and no later sphere
+    // whose hit lands on exactly 100.0 is the first index at the minimum (background_cell()).
     const unsigned long long bad = __ballot(valid && !(sphere_is_tame(sph) && fabsf(sph.z) < 1e30f));
     const unsigned long long low = __ballot(valid && sph.z <= kBackground);
     bool too_big;   // excluded by the launcher (W <= kMaxFastWidth, H <= 32768)
     const int total = build_work_list<kSphereCostFwd>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
     if (lane == 0) {
-      s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
+      s_flag[0] = (bad != 0ull) || ((low & 1ull) == 0ull) || too_big;
       s_flag[1] = total;
     }
   }
@@ -698,8 +709,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
           if (OWNER) {
             const ulonglong2 k01 = reinterpret_cast<const ulonglong2 *>(cell)[0];
             const ulonglong2 k23 = reinterpret_cast<const ulonglong2 *>(cell)[1];
-            o = make_float4(key_depth((uint32_t)(k01.x >> 32)), key_depth((uint32_t)(k01.y >> 32)),
-                            key_depth((uint32_t)(k23.x >> 32)), key_depth((uint32_t)(k23.y >> 32)));
+            o = make_float4(cell_depth(k01.x), cell_depth(k01.y), cell_depth(k23.x), cell_depth(k23.y));
             a = make_uchar4((uint8_t)k01.x, (uint8_t)k01.y, (uint8_t)k23.x, (uint8_t)k23.y);
           } else {
             const uint4 k = *reinterpret_cast<const uint4 *>(cell);
@@ -715,7 +725,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
         Key k = bg;
         if ((unsigned)(v + r0 - p0) < box_h && (unsigned)(u - cu0) < (unsigned)bw) k = zrow[v * pitch + u];
         if (OWNER) {
-          out[(size_t)(r0 + v) * W + u] = key_depth((uint32_t)((unsigned long long)k >> 32));
+          out[(size_t)(r0 + v) * W + u] = cell_depth((unsigned long long)k);
           aout[(size_t)(r0 + v) * W + u] = (uint8_t)k;
         } else {
           out[(size_t)(r0 + v) * W + u] = key_depth((uint32_t)k);
@@ -1103,7 +1113,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     sph = crop_it == 0 ? spheres[(size_t)n * J + lane] : s_next[lane];
   s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // 1024 = 16 waves x 64 spheres
   {  // background everywhere
-    const Key bg = ((Key)depth_key(kBackground) << 32) | SHR_ARGMIN_NONE;
+    const Key bg = (Key)background_cell();
     const int nvec = (rh * LW) >> 1;
     const ulonglong2 v = make_ulonglong2(bg, bg);
     for (int i = tid; i < nvec; i += 1024) reinterpret_cast<ulonglong2 *>(zbuf)[i] = v;
@@ -1148,7 +1158,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     bool too_big;
     const int total = build_work_list<kSphereCostMse>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
     if (lane == 0) {
-      s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
+      s_flag[0] = (bad != 0ull) || ((low & 1ull) == 0ull) || too_big;
       s_flag[1] = total;
     }
   }
@@ -1202,8 +1212,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
       else { v = c / w4; x = (c - v * w4) << 2; }
       ulonglong2 *cell = reinterpret_cast<ulonglong2 *>(zbuf + v * LW + x);
       ulonglong2 k01 = cell[0], k23 = cell[1];
-      const float4 d = make_float4(key_depth((uint32_t)(k01.x >> 32)), key_depth((uint32_t)(k01.y >> 32)),
-                                   key_depth((uint32_t)(k23.x >> 32)), key_depth((uint32_t)(k23.y >> 32)));
+      const float4 d = make_float4(cell_depth(k01.x), cell_depth(k01.y), cell_depth(k23.x), cell_depth(k23.y));
       if (out) stream_store(out4 + c, d);
       const float e0 = d.x - t.x, e1 = d.y - t.y, e2 = d.z - t.z, e3 = d.w - t.w;
       sse += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);

@@ -160,6 +160,44 @@ def test_every_sphere_a_candidate_everywhere(ops, oracle):
     assert np.array_equal(a.cpu().numpy(), oa)
 
 
+def test_hit_at_exactly_the_background_depth(ops, oracle):
+    """torch.min keeps the FIRST index at the minimum (reference mesh/render.py:89): a sphere whose hit lands on
+    exactly 100.0 owns the pixel -- and receives its gradient -- only if no lower index holds 100 there, i.e. if
+    every lower-index sphere hits the pixel behind the background.  (Found by tools/fuzz.py: the z-buffer used to
+    let any such hit win the tie against the background.)"""
+    S = 64
+    px = lambda i: (i - S / 2) * 300.0 / S                    # pixel-centre coordinates: exact in fp32
+    tie = lambda u, v: [px(u), px(v), 102.0, 2.0]             # covers ONE pixel, at depth 102 - sqrt(4) = 100.0
+    far = [1e4, 1e4, 0.0, 1.0]                                # off screen
+    front = lambda u, v, r=30.0: [px(u), px(v), 20.0, r]      # an ordinary sphere in front
+    sp = np.array([
+        [tie(40, 40), front(10, 10), far],                    # sphere 0 itself: owns the pixel (general path: z0 > 100)
+        [front(10, 10), tie(40, 40), far],                    # sphere 0 misses the pixel: its background comes first
+        [[px(40), px(40), 105.0, 3.0], tie(40, 40), front(10, 10)],   # sphere 0 hits it at 102: sphere 1's 100 wins
+        [front(10, 10), tie(40, 40), tie(40, 40)],            # two such hits, behind sphere 0's background
+        [front(40, 40), tie(40, 40), far],                    # sphere 0 in front there
+        [far, tie(40, 40), front(10, 10)],                    # sphere 0 off screen
+    ], np.float32)
+    d, a = ops.sphere_raster_fwd(dev(sp), S, S, want_argmin=True)
+    od, oa = oracle.sphere_raster_fwd(sp, S, S)
+    assert od[0, 40, 40] == 100.0 and oa[0, 40, 40] == 0 and oa[1, 40, 40] == 255 and oa[2, 40, 40] == 1
+    assert oa[3, 40, 40] == 255 and oa[4, 40, 40] == 0 and oa[5, 40, 40] == 255
+    assert np.array_equal(bits(d.cpu().numpy()), bits(od))
+    assert np.array_equal(a.cpu().numpy(), oa)
+    gd = np.random.RandomState(3).standard_normal((len(sp), S, S)).astype(np.float32)
+    gd[:, 40, 40] = 1000.0                                    # the tie pixel's gradient must go where the reference sends it
+    og = oracle.sphere_raster_bwd(sp, gd)
+    tol = 1e-5 * np.abs(og).max() + 1e-4
+    assert np.abs(ops.sphere_raster_bwd(dev(sp), dev(gd), a).cpu().numpy() - og).max() <= tol
+    assert np.abs(ops.sphere_raster_bwd(dev(sp), dev(gd)).cpu().numpy() - og).max() <= tol      # owners recomputed
+    tgt = np.full((len(sp), S, S), 100.0, np.float32); tgt[:, 40, 40] = -400.0
+    if ops.sphere_raster_mse_supported(dev(sp), dev(tgt), S, S):
+        dep, sse, gsp = ops.sphere_raster_mse(dev(sp), dev(tgt))
+        assert np.array_equal(bits(dep.cpu().numpy()), bits(od))
+        og2 = oracle.sphere_raster_bwd(sp, (2 * (od - tgt)).astype(np.float32))
+        assert np.abs(gsp.cpu().numpy() - og2).max() <= 2e-5 * np.abs(og2).max() + 1e-3
+
+
 def test_nan_inf(ops, oracle):
     sp = np.array([[[0, 0, 10, 20], [np.nan, 0, 0, 5]],
                    [[0, 0, np.nan, 20], [50, 50, 0, 5]],

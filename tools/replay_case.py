@@ -31,3 +31,16 @@ for w in (0, 8, 16):
 ops.sphere_raster_bwd(dev(sp), dev(gd), None); torch.cuda.synchronize()
 fused("after backward (recomputed owners)")
 print("spheres of crop with the error:", sp[np.unravel_index(np.abs(ops.sphere_raster_mse(dev(sp), dev(tgt))[2].cpu().numpy() - og2).argmax(), og2.shape)[0]][:, :].round(1)[:6])
+n, j = np.unravel_index(np.abs(ops.sphere_raster_mse(dev(sp), dev(tgt))[2].cpu().numpy() - og2).argmax(), og2.shape)[:2]
+ops.set_tuning(ops.TUNE_FWD_ZBUF_BYTES, 0); ops.set_tuning(ops.TUNE_BWD_WAVES, 0)
+dep, sse, gsp = ops.sphere_raster_mse(dev(sp), dev(tgt))
+d, a = ops.sphere_raster_fwd(dev(sp), H, W, want_argmin=True)
+g_img = (2 * (od - tgt)).astype(np.float32)
+gs = ops.sphere_raster_bwd(dev(sp), dev(g_img), a).cpu().numpy()
+print("crop", n, "sphere", j, sp[n, j])
+print("oracle ", og2[n, j]); print("fused  ", gsp.cpu().numpy()[n, j]); print("unfused", gs[n, j])
+own = np.argwhere(oa[n] == j); print("owned pixels (oracle):", own.tolist(), " gpu owner map agrees:", np.array_equal(a.cpu().numpy(), oa))
+diff = np.abs(gsp.cpu().numpy() - og2); bad = np.argwhere(diff > 2e-5 * np.abs(og2).max() + 1e-3)
+print("all (crop, sphere, component) beyond the bar:", bad.tolist())
+for (nn, jj) in sorted({(int(b[0]), int(b[1])) for b in bad}):
+    print(" sphere", jj, sp[nn, jj], "owned px", np.argwhere(oa[nn] == jj).tolist()[:8], "oracle", og2[nn, jj], "fused", gsp.cpu().numpy()[nn, jj])
