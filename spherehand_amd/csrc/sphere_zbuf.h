@@ -899,11 +899,11 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
       const int n_lo = max(0, min(ub, s0) - ua), hi0 = max(ua, s1), n_out = n_lo + max(0, ub - hi0);
       // A batch = kStageBatch units per wave; its requests and their wait are ONE asm statement: the compiler
       // treats an asm result as available at once and may copy it before a separate wait.  A slot without a unit
-      // re-reads the records (no control flow around the statement).  The first pass's first batch is
-      // unconditional and also lands the speculative units: their registers go from the requests above to that
-      // statement in a straight line (on a branchy path the compiler copies them -- before the data is there).
+      // re-reads the records (no control flow around the statement).  The first pass's first batch also lands
+      // the speculative units (registers outside the compiler's, kBwdVgprs) and fetches them.
       static_assert(kStageBatch == 4, "the staging statements below name four slots");
       static_assert(kSpecUnits == 2, "... and tie two speculative units");
+      constexpr int DW = NW - 1;   // the units are dealt to waves 1 .. NW-1
       auto batch = [&](int t0, auto with_spec_tag) {
         constexpr bool first_batch = decltype(with_spec_tag)::value;
         v4f g2[kStageBatch];
@@ -913,7 +913,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
         int us[kStageBatch];
 #pragma unroll
         for (int b = 0; b < kStageBatch; b++) {
-          const int t = t0 + NW * b;
+          const int t = t0 + DW * b;
           ok[b] = t < n_out;                                                  // wave-uniform
           const int u = us[b] = t < n_lo ? ua + t : hi0 + (t - n_lo);
           const int c = min(max((u << 6) + lane, 0), nchunk - 1);
@@ -923,6 +923,16 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
         if (FIRST && first_batch) {
           float4 sa, sb;       // the two speculative units, fetched from their registers once everything has landed
           uint32_t soa, sob;
+          if (!ok[0]) {        // no unit for this wave (wave-uniform): only the speculative ones to land
+            asm volatile(
+                "s_waitcnt vmcnt(0)\n\t"
+                "v_mov_b32 %0, v96\n\tv_mov_b32 %1, v97\n\tv_mov_b32 %2, v98\n\tv_mov_b32 %3, v99\n\t"
+                "v_mov_b32 %4, v100\n\tv_mov_b32 %5, v101\n\tv_mov_b32 %6, v102\n\tv_mov_b32 %7, v103\n\t"
+                "v_mov_b32 %8, v104\n\tv_mov_b32 %9, v105"
+                : "=&v"(sa.x), "=&v"(sa.y), "=&v"(sa.z), "=&v"(sa.w), "=&v"(sb.x), "=&v"(sb.y), "=&v"(sb.z),
+                  "=&v"(sb.w), "=&v"(soa), "=&v"(sob)
+                : : "memory");
+          } else
           asm volatile(
               "global_load_dwordx4 %0, %18, off\n\tglobal_load_dword %4, %22, off\n\t"
               "global_load_dwordx4 %1, %19, off\n\tglobal_load_dword %5, %23, off\n\t"
@@ -956,12 +966,12 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
         for (int b = 0; b < kStageBatch; b++)
           if (ok[b]) put_unit(us[b], g2[b], o2[b]);
       };
-      int t0 = wave_s;
+      int t0 = wave_s == 0 ? n_out : wave_s - 1;   // (wave 0 builds the list: its requests would go out last)
       if (FIRST) {
         batch(t0, std::true_type());
-        t0 += NW * kStageBatch;
+        t0 += DW * kStageBatch;
       }
-      for (; t0 < n_out; t0 += NW * kStageBatch) batch(t0, std::false_type());
+      for (; t0 < n_out; t0 += DW * kStageBatch) batch(t0, std::false_type());
     } else {
       for (int p = tid; p < rh * W; p += NT) {
         const int v = p / W, u = p - v * W;

@@ -25,9 +25,9 @@ with torch.cuda.stream(stream):
         lib.shr_sphere_raster_fwd(p[0], n, J, S, S, p[1], p[2], stream.cuda_stream)
         reps = max(4, 4000 // n)
         row = []
-        for waves in (16, 8, 0):
-            ops.set_tuning(ops.TUNE_BWD_WAVES, waves)
+        for waves in ((16,) if os.environ.get("SHR_LIB") else (16, 8, 0)):
+            if not os.environ.get("SHR_LIB"): ops.set_tuning(ops.TUNE_BWD_WAVES, waves)
             b = bench.mean_launch_us(lambda s: lib.shr_sphere_raster_bwd(p[0], p[3], p[2], n, J, S, S, p[4], s), stream, reps, 3, 3)
             row.append(b * 256 / n)
-        ops.set_tuning(ops.TUNE_BWD_WAVES, 0)
-        print("N=%5d  backward per 256 crops: 16 waves %.3f us, 8 waves %.3f us, default %.3f us" % (n, row[0], row[1], row[2]), flush=True)
+        if not os.environ.get("SHR_LIB"): ops.set_tuning(ops.TUNE_BWD_WAVES, 0)
+        print("N=%5d  backward per 256 crops:" % n, " ".join("%.3f" % r for r in row), "(16 waves, 8 waves, default)", flush=True)
