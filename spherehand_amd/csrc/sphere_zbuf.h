@@ -68,16 +68,28 @@ __device__ __forceinline__ uint32_t depth_key(float d) {
 __device__ __forceinline__ float key_depth(uint32_t k) {
   return __uint_as_float(k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu));
 }
-// 64-bit cells (depth key << 32 | owner).  The BACKGROUND cell sits one depth key below 100 with an all-ones low
-// word: every hit in front of the background beats it (its depth key is smaller, or equal with a low word < 2^32 - 1),
-// and a hit at EXACTLY 100.0 does not -- torch.min keeps the first index at the minimum, and on the fast path
-// that is sphere 0's map, which holds the background there (the fast path requires z0 <= 100: sphere 0's own hits
-// are then all in front of it).  The owner byte of a background cell reads 255 = SHR_ARGMIN_NONE.
+// 64-bit cells (depth key << 32 | owner): ds_min_u64 keeps the nearest hit and, among equal depths, the lowest sphere
+// index; the background cell is (key(100) << 32 | 0xFFFFFFFF).  One case needs a second look when a cell is decoded:
+// a hit at EXACTLY 100.0 beats the background cell, but torch.min keeps the first index at the minimum, and the
+// maps of the spheres that miss the pixel hold 100 there as well -- sphere j owns the pixel (and receives its
+// gradient) only if every lower-index sphere hits it BEHIND the background.  Such a cell is recognisable (depth key
+// of 100 with a sphere index), it practically never occurs (tools/fuzz.py found one in ~40 k crops), and
+// tie_owner() then evaluates the lower spheres directly.
 __device__ __forceinline__ unsigned long long background_cell() {
-  return ((unsigned long long)(depth_key(kBackground) - 1u) << 32) | 0xFFFFFFFFull;
+  return ((unsigned long long)depth_key(kBackground) << 32) | 0xFFFFFFFFull;
 }
-__device__ __forceinline__ float cell_depth(unsigned long long k) {   // (the background's key is one short of 100)
-  return key_depth((uint32_t)(k >> 32) - (uint32_t)((int32_t)(uint32_t)k >> 31));
+__device__ __forceinline__ bool is_background_tie(unsigned long long k) {
+  return (uint32_t)(k >> 32) == depth_key(kBackground) && (uint32_t)k < (uint32_t)SHR_MAX_SPHERES;
+}
+// the owner of a pixel whose cell holds (100.0, j): j if spheres 0 .. j-1 all hit it deeper than 100, else nobody
+__device__ __forceinline__ uint32_t tie_owner(const float4 *s_sph, uint32_t j, float xg, float yg) {
+  for (uint32_t i = 0; i < j; i++) {
+    const float4 s = s_sph[i];
+    const float dx = xg - s.x, dy = yg - s.y;
+    const float q = (s.w * s.w - dx * dx) - dy * dy;
+    if (q <= kHitMin || !(s.z - sqrtf(q) > kBackground)) return SHR_ARGMIN_NONE;
+  }
+  return j;
 }
 
 // Correctly rounded sqrt for a normal, positive, finite fp32 argument (here
@@ -148,6 +160,9 @@ __device__ __forceinline__ float rfl(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// The axes' 300 / size are IEEE divisions the compiler sinks to their first use -- behind the first barrier, where all
+// sixteen waves evaluate them on the critical path.  pin_axes() fixes the place: after the first requests are out.
+__device__ __forceinline__ void pin_axes(Axis &ax, Axis &ay) { asm volatile("" : "+v"(ax.mul), "+v"(ay.mul)); }
 
 // The work list is the sequence of chunks, sphere after sphere, on a weight axis where a
 // chunk is 2^kChunkShift long and starting a sphere (broadcasts, lane layout, column terms)
@@ -475,7 +490,7 @@ __host__ __device__ __forceinline__ int max_box_pitch(int W) { return ((W + 3) &
 // other waves fill that time with the z-buffer initialisation and then with the
 // BACKGROUND ROWS: rows no sphere's box touches (half of a hand crop) are stored straight
 // from registers before the first barrier and never pass through LDS or the decode.
-template <bool OWNER, bool VEC4, bool POW2, bool PERSIST>
+template <bool OWNER, bool VEC4, bool POW2, bool PERSIST, bool BOX>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_,
                        float *__restrict__ depth, uint8_t *__restrict__ argmin, int rows_per_region_,
@@ -510,7 +525,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   const int r0 = blockIdx.y * rows_per_region;
   const int r1 = min(H, r0 + rows_per_region);
   const int rh = r1 - r0;
-  const Axis ax = make_axis(W), ay = make_axis(H);
+  Axis ax = make_axis(W), ay = make_axis(H);
   const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
 
   // the waves that need the crop's records before the first barrier (wave 0: work list; the
@@ -539,7 +554,8 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     for (int i = nvec * per16 + tid; i < ncell; i += nthr) zbuf[i] = bg;
   };
   // (the box is not known yet: every cell a one-pass box of this region can use; overlaps the read above)
-  init_zbuf(min(zcells, rh * max_box_pitch(W)));
+  init_zbuf(BOX ? min(zcells, rh * max_box_pitch(W)) : rh * (W + kRowPad));
+  pin_axes(ax, ay);
 
   // Waves 1..kBgWaves store the background rows while wave 0 builds the list: they are the
   // first to finish the z-buffer initialisation (the SIMD arbitration favours old waves) and
@@ -548,16 +564,16 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
 
   if (list_wave) {
     s_sph[lane] = sph;
-    // general path unless every sphere is tame and sphere 0 has z <= 100: sphere 0's map is then the
-    // background wherever it does not hit and in front of it (z - sqrt(q) < 100) where it does, so a
-    // pixel's minimum never exceeds the background -- min(100, hits) is exact -- and no later sphere
-    // whose hit lands on exactly 100.0 is the first index at the minimum (background_cell()).
+    // general path unless every sphere is tame and at least one has z <= 100: a pixel's
+    // minimum can exceed the background only where ALL J spheres hit it, and there the
+    // sphere with z <= 100 contributes z - sqrt(q) < 100, so min(100, hits) is exact
+    // (a hit at exactly 100.0: background_cell() / tie_owner()).
     const unsigned long long bad = __ballot(valid && !(sphere_is_tame(sph) && fabsf(sph.z) < 1e30f));
     const unsigned long long low = __ballot(valid && sph.z <= kBackground);
     bool too_big;   // excluded by the launcher (W <= kMaxFastWidth, H <= 32768)
     const int total = build_work_list<kSphereCostFwd>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
     if (lane == 0) {
-      s_flag[0] = (bad != 0ull) || ((low & 1ull) == 0ull) || too_big;
+      s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
       s_flag[1] = total;
     }
   }
@@ -575,9 +591,10 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   // units [0, ua) and [ub, nunits) lie entirely in background rows, [ua, ub) is touched
   int ua = 0, ub = nunits;
   int4 bx = make_int4(0, 0, 0, 0);
-  if (bg_wave) {
-    int cv0, cv1, cu0, cu1;
-    touched_box(sph, valid, ax, ay, kx, ky, W, r0, r1, lane, cv0, cv1, cu0, cu1);
+  if (bg_wave && (BOX || VEC4)) {
+    int cv0, cv1, cu0 = 0, cu1 = W - 1;
+    if (BOX) touched_box(sph, valid, ax, ay, kx, ky, W, r0, r1, lane, cv0, cv1, cu0, cu1);
+    else touched_rows(sph, valid, ay, ky, r0, r1, cv0, cv1);
     if (VEC4) {
       if (cv1 < cv0) ua = ub = nunits;
       else { ua = ((cv0 - r0) * w4) >> 6; ub = min(nunits, ((cv1 - r0 + 1) * w4 + 63) >> 6); }
@@ -616,7 +633,9 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     }
   };
   if (VEC4 && bg_wave) store_background(nwaves == 1 ? 0 : wave_s - 1, nwaves == 1 ? 1 : nbgw);
-  if (wave_s == (nwaves == 1 ? 0 : 1) && lane == 0) {
+  if (!BOX) {
+    if (VEC4 && wave_s == (nwaves == 1 ? 0 : 1) && lane == 0) { s_flag[2] = ua; s_flag[3] = ub; }   // for the other waves
+  } else if (wave_s == (nwaves == 1 ? 0 : 1) && lane == 0) {
     // Everything the other waves derive from the box, computed ONCE (the stores above drain meanwhile): sixteen
     // waves repeating this scalar arithmetic -- a division among it -- after the barrier cost 2 k cycles per crop.
     const int cv0 = bx.x, cv1 = bx.y;
@@ -650,11 +669,16 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   const bool general = s_flag[0] != 0;   // workgroup-uniform: the whole region takes the tile code
   int tile_lo = r0, tile_hi = r1;        // rows for the tile code
   if (!general) {
-    const int out_lo = rfl(s_flag[2]), out_hi = rfl(s_flag[3]);
-    const int p0 = rfl(s_flag[4]), pe = rfl(s_flag[5]), cu0 = rfl(s_flag[6]), bw = rfl(s_flag[7]);
-    const int pitch = rfl(s_flag[8]), clip = rfl(s_flag[9]);
-    tile_lo = rfl(s_flag[10]);
-    tile_hi = rfl(s_flag[11]);
+    // (BOX = false: the z-buffer holds the whole region at the image's own pitch -- one workgroup per CU has the LDS
+    // for it, and nothing has to be derived from a box)
+    int out_lo = 0, out_hi = VEC4 ? nchunk : rh * W;
+    if (!BOX && VEC4) { out_lo = rfl(s_flag[2]) << 6; out_hi = min(rfl(s_flag[3]) << 6, nchunk); }
+    if (BOX) { out_lo = rfl(s_flag[2]); out_hi = rfl(s_flag[3]); }
+    const int p0 = BOX ? rfl(s_flag[4]) : r0, pe = BOX ? rfl(s_flag[5]) : r1;
+    const int cu0 = BOX ? rfl(s_flag[6]) : 0, bw = BOX ? rfl(s_flag[7]) : W;
+    const int pitch = BOX ? rfl(s_flag[8]) : W + kRowPad, clip = BOX ? rfl(s_flag[9]) : r1;
+    tile_lo = BOX ? rfl(s_flag[10]) : r1;
+    tile_hi = BOX ? rfl(s_flag[11]) : r1;
 
     // ---- scan-convert the chunk list ---------------------------------------------------
     // A chunk may reach below its sphere's box (rows that are real pixels, or lie beyond the
@@ -698,19 +722,30 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     const Key *zrow = zbuf - (p0 - r0) * pitch - cu0;   // cell of region pixel (v, x) = zrow[v * pitch + x]
     const unsigned box_h = pe > p0 ? (unsigned)(pe - p0) : 0u;
     if (VEC4) {
-      for (int c = out_lo + tid; c < out_hi; c += nthr) {
+      for (int cb = out_lo + (wave_s << 6); cb < out_hi; cb += nwaves << 6) {   // (a scalar loop: wave-wide stores of whole units)
+        const int c = cb + lane;
+        if (c >= out_hi) continue;
         int v, x;
         if (POW2 || w4_shift >= 0) { v = c >> w4_shift; x = (c & (w4 - 1)) << 2; }
         else { v = c / w4; x = (c - v * w4) << 2; }
         float4 o = bgd;
         uchar4 a = bga;
-        if ((unsigned)(v + r0 - p0) < box_h && (unsigned)(x - cu0) < (unsigned)bw) {
+        if (!BOX || ((unsigned)(v + r0 - p0) < box_h && (unsigned)(x - cu0) < (unsigned)bw)) {
           const Key *cell = zrow + v * pitch + x;
           if (OWNER) {
             const ulonglong2 k01 = reinterpret_cast<const ulonglong2 *>(cell)[0];
             const ulonglong2 k23 = reinterpret_cast<const ulonglong2 *>(cell)[1];
-            o = make_float4(cell_depth(k01.x), cell_depth(k01.y), cell_depth(k23.x), cell_depth(k23.y));
+            o = make_float4(key_depth((uint32_t)(k01.x >> 32)), key_depth((uint32_t)(k01.y >> 32)),
+                            key_depth((uint32_t)(k23.x >> 32)), key_depth((uint32_t)(k23.y >> 32)));
             a = make_uchar4((uint8_t)k01.x, (uint8_t)k01.y, (uint8_t)k23.x, (uint8_t)k23.y);
+            if (is_background_tie(k01.x) || is_background_tie(k01.y) || is_background_tie(k23.x) ||
+                is_background_tie(k23.y)) {   // (practically never)
+              const float yg = axis_coord_t<POW2>(ay, v + r0);
+              if (is_background_tie(k01.x)) a.x = (uint8_t)tie_owner(s_sph, (uint32_t)k01.x, axis_coord_t<POW2>(ax, x), yg);
+              if (is_background_tie(k01.y)) a.y = (uint8_t)tie_owner(s_sph, (uint32_t)k01.y, axis_coord_t<POW2>(ax, x + 1), yg);
+              if (is_background_tie(k23.x)) a.z = (uint8_t)tie_owner(s_sph, (uint32_t)k23.x, axis_coord_t<POW2>(ax, x + 2), yg);
+              if (is_background_tie(k23.y)) a.w = (uint8_t)tie_owner(s_sph, (uint32_t)k23.y, axis_coord_t<POW2>(ax, x + 3), yg);
+            }
           } else {
             const uint4 k = *reinterpret_cast<const uint4 *>(cell);
             o = make_float4(key_depth(k.x), key_depth(k.y), key_depth(k.z), key_depth(k.w));
@@ -723,10 +758,13 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
       for (int p = out_lo + tid; p < out_hi; p += nthr) {
         const int v = p / W, u = p - v * W;
         Key k = bg;
-        if ((unsigned)(v + r0 - p0) < box_h && (unsigned)(u - cu0) < (unsigned)bw) k = zrow[v * pitch + u];
+        if (!BOX || ((unsigned)(v + r0 - p0) < box_h && (unsigned)(u - cu0) < (unsigned)bw)) k = zrow[v * pitch + u];
         if (OWNER) {
-          out[(size_t)(r0 + v) * W + u] = cell_depth((unsigned long long)k);
-          aout[(size_t)(r0 + v) * W + u] = (uint8_t)k;
+          out[(size_t)(r0 + v) * W + u] = key_depth((uint32_t)((unsigned long long)k >> 32));
+          aout[(size_t)(r0 + v) * W + u] =
+              is_background_tie((unsigned long long)k)
+                  ? (uint8_t)tie_owner(s_sph, (uint32_t)k, axis_coord_t<POW2>(ax, u), axis_coord_t<POW2>(ay, v + r0))
+                  : (uint8_t)k;
         } else {
           out[(size_t)(r0 + v) * W + u] = key_depth((uint32_t)k);
         }
@@ -761,7 +799,7 @@ constexpr int kSpecUnits = 2;    // ... and units per wave requested before the 
 // copy such registers -- before the data was there -- as soon as the path from the request to its wait branched.
 constexpr int kBwdVgprs = 96;
 
-template <bool VEC4, bool POW2, bool PERSIST, int NW>
+template <bool VEC4, bool POW2, bool PERSIST, int NW, bool WHOLE>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_num_vgpr(kBwdVgprs)))
 sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restrict__ grad_depth,
                        const uint8_t *__restrict__ argmin, int N, int J_, int H_, int W_,
@@ -791,7 +829,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   const int LW = W + kRowPad;
   float *gbuf = reinterpret_cast<float *>(smem + kHdrBytes + kPartBytes);
   uint8_t *obuf = smem + kHdrBytes + kPartBytes + (size_t)(rows + kPadRows) * LW * 4;
-  const Axis ax = make_axis(W), ay = make_axis(H);
+  Axis ax = make_axis(W), ay = make_axis(H);
   const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
   typedef float v4f __attribute__((ext_vector_type(4)));
   const int wave_s = rfl(wave);
@@ -800,6 +838,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   // below can be queued behind it and awaited separately: wave 0 builds the work list, all four derive the
   // touched rows.  A young wave's copy of the records arrived up to 3 k cycles later and held the barrier.
   const bool lead = wave_s < 4;
+  int lead_v0 = 0, lead_v1 = -1;   // the touched rows, in the lead waves
   const bool pf_wave = wave_s == NW - 1;
   const float *gin = grad_depth + (size_t)n * H * W;
   const uint8_t *oin = argmin + (size_t)n * H * W;
@@ -847,6 +886,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   }
   // owner padding = "nobody": the walk may overhang the image edge
   for (int i = tid; i < rows * kRowPad; i += NT) obuf[(i / kRowPad) * LW + W + (i % kRowPad)] = SHR_ARGMIN_NONE;
+  pin_axes(ax, ay);
   if (lead) {
     if (!have_sph) {
       float4 t;
@@ -858,15 +898,22 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
                      : "=v"(t.x), "=v"(t.y), "=v"(t.z), "=v"(t.w) : : "memory");
       if (lane < J) sph = t;
     }
-    int t0, t1;
-    touched_rows(sph, lane < J, ay, ky, 0, H, t0, t1);
+    touched_rows(sph, lane < J, ay, ky, 0, H, lead_v0, lead_v1);
     if (wave_s == 0) {
       s_sph[lane] = sph;
-      if (lane == 0) { s_flag[2] = t0; s_flag[3] = t1; }
+      if (!WHOLE && lane == 0) { s_flag[2] = lead_v0; s_flag[3] = lead_v1; }
     }
   }
-  __syncthreads();   // the touched rows are known to every wave (the others arrive here straight from their requests)
-  const int cv0 = rfl(s_flag[2]), cv1 = rfl(s_flag[3]);
+  // WHOLE (the buffers hold the whole crop: one workgroup per CU): rows sit at their own index, one pass over
+  // [0, H), and only the lead waves -- which know the touched rows -- request what lies outside the speculative
+  // units, at once.  Otherwise the rows start at the first touched one, which every wave has to know before it
+  // writes a unit into LDS: one more barrier (the others arrive at it straight from their requests).
+  int cv0 = 0, cv1 = H - 1;
+  if (!WHOLE) {
+    __syncthreads();
+    cv0 = rfl(s_flag[2]);
+    cv1 = rfl(s_flag[3]);
+  }
 
   // Passes over the touched rows (one, unless they exceed the staging buffers).  The first pass's list and
   // staging stand in front of the loop: the registers of the speculative requests must not become loop-carried
@@ -878,7 +925,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
       if (lane == 0) s_flag[1] = total;
     }
   };
-  auto stage = [&](int r0, int r1, auto first_tag) {
+  auto stage = [&](int r0, int r1, int t_lo, int t_hi, auto first_tag) {   // rows [t_lo, t_hi) of [r0, r1) are wanted
     constexpr bool FIRST = decltype(first_tag)::value;
     const int rh = r1 - r0;
     auto put_unit = [&](int u, const v4f g, uint32_t o) {
@@ -894,7 +941,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     if (VEC4) {
       // the pass's units [ua, ub); those outside the speculative range (first pass only), [ua, min(ub, uc0)) and
       // [max(ua, uc1), ub), are dealt to the waves now
-      const int ua = (r0 * w4) >> 6, ub = min(nunits, (r1 * w4 + 63) >> 6);
+      const int ua = t_hi > t_lo ? (t_lo * w4) >> 6 : 0, ub = t_hi > t_lo ? min(nunits, (t_hi * w4 + 63) >> 6) : 0;
       const int s0 = FIRST ? uc0 : 0, s1 = FIRST ? uc1 : 0;
       const int n_lo = max(0, min(ub, s0) - ua), hi0 = max(ua, s1), n_out = n_lo + max(0, ub - hi0);
       // A batch = kStageBatch units per wave; its requests and their wait are ONE asm statement: the compiler
@@ -903,7 +950,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
       // the speculative units (registers outside the compiler's, kBwdVgprs) and fetches them.
       static_assert(kStageBatch == 4, "the staging statements below name four slots");
       static_assert(kSpecUnits == 2, "... and tie two speculative units");
-      constexpr int DW = NW - 1;   // the units are dealt to waves 1 .. NW-1
+      constexpr int DW = WHOLE ? 3 : NW - 1;   // the units are dealt to waves 1 .. DW
       auto batch = [&](int t0, auto with_spec_tag) {
         constexpr bool first_batch = decltype(with_spec_tag)::value;
         v4f g2[kStageBatch];
@@ -966,7 +1013,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
         for (int b = 0; b < kStageBatch; b++)
           if (ok[b]) put_unit(us[b], g2[b], o2[b]);
       };
-      int t0 = wave_s == 0 ? n_out : wave_s - 1;   // (wave 0 builds the list: its requests would go out last)
+      int t0 = (wave_s == 0 || wave_s > DW) ? n_out : wave_s - 1;   // (wave 0 builds the list: its requests would go out last)
       if (FIRST) {
         batch(t0, std::true_type());
         t0 += DW * kStageBatch;
@@ -980,9 +1027,12 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
       }
     }
   };
-  if (cv1 >= cv0) {
+  if (WHOLE) {
+    build_list(0, H);
+    stage(0, H, lead_v0, lead_v1 + 1, std::true_type());
+  } else if (cv1 >= cv0) {
     build_list(cv0, min(cv0 + rows, cv1 + 1));
-    stage(cv0, min(cv0 + rows, cv1 + 1), std::true_type());
+    stage(cv0, min(cv0 + rows, cv1 + 1), cv0, min(cv0 + rows, cv1 + 1), std::true_type());
   } else if (VEC4) {   // no touched row at all: the speculative requests still have to land before their registers are reused
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
   }
@@ -1032,7 +1082,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     if (r0 <= cv1) {
       __syncthreads();  // this pass's walk is done: list and buffers are rewritten
       build_list(r0, min(r0 + rows, cv1 + 1));
-      stage(r0, min(r0 + rows, cv1 + 1), std::false_type());
+      stage(r0, min(r0 + rows, cv1 + 1), r0, min(r0 + rows, cv1 + 1), std::false_type());
     }
   }
   if (pf_wave && has_next) {   // (arrived long ago: the wave's own walk lies in between)
@@ -1109,7 +1159,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   const int r1 = min(H, r0 + rows_per_region);
   const int rh = r1 - r0;
   const int LW = W + kRowPad;
-  const Axis ax = make_axis(W), ay = make_axis(H);
+  Axis ax = make_axis(W), ay = make_axis(H);
   const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
   const int wave_s = rfl(wave);
   const bool bg_wave = wave_s >= 1 && wave_s <= kBgWaves;
@@ -1129,6 +1179,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     for (int i = tid; i < nvec; i += 1024) reinterpret_cast<ulonglong2 *>(zbuf)[i] = v;
     if (tid == 0 && ((rh * LW) & 1)) zbuf[rh * LW - 1] = bg;
   }
+  pin_axes(ax, ay);
 
   const int w4 = W >> 2;
   const int nchunk = rh * w4;
@@ -1168,7 +1219,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     bool too_big;
     const int total = build_work_list<kSphereCostMse>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
     if (lane == 0) {
-      s_flag[0] = (bad != 0ull) || ((low & 1ull) == 0ull) || too_big;
+      s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
       s_flag[1] = total;
     }
   }
@@ -1222,8 +1273,17 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
       else { v = c / w4; x = (c - v * w4) << 2; }
       ulonglong2 *cell = reinterpret_cast<ulonglong2 *>(zbuf + v * LW + x);
       ulonglong2 k01 = cell[0], k23 = cell[1];
-      const float4 d = make_float4(cell_depth(k01.x), cell_depth(k01.y), cell_depth(k23.x), cell_depth(k23.y));
+      const float4 d = make_float4(key_depth((uint32_t)(k01.x >> 32)), key_depth((uint32_t)(k01.y >> 32)),
+                                   key_depth((uint32_t)(k23.x >> 32)), key_depth((uint32_t)(k23.y >> 32)));
       if (out) stream_store(out4 + c, d);
+      if (is_background_tie(k01.x) || is_background_tie(k01.y) || is_background_tie(k23.x) ||
+          is_background_tie(k23.y)) {   // a hit at exactly 100.0 (practically never): who owns it (tie_owner)
+        const float yg = axis_coord_t<POW2>(ay, v + r0);
+        if (is_background_tie(k01.x)) k01.x = (k01.x & ~0xffull) | tie_owner(s_sph, (uint32_t)k01.x, axis_coord_t<POW2>(ax, x), yg);
+        if (is_background_tie(k01.y)) k01.y = (k01.y & ~0xffull) | tie_owner(s_sph, (uint32_t)k01.y, axis_coord_t<POW2>(ax, x + 1), yg);
+        if (is_background_tie(k23.x)) k23.x = (k23.x & ~0xffull) | tie_owner(s_sph, (uint32_t)k23.x, axis_coord_t<POW2>(ax, x + 2), yg);
+        if (is_background_tie(k23.y)) k23.y = (k23.y & ~0xffull) | tie_owner(s_sph, (uint32_t)k23.y, axis_coord_t<POW2>(ax, x + 3), yg);
+      }
       const float e0 = d.x - t.x, e1 = d.y - t.y, e2 = d.z - t.z, e3 = d.w - t.w;
       sse += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
       k01.x = ((Key)__float_as_uint(2.f * e0) << 32) | (k01.x & 0xffu);
