@@ -1,0 +1,51 @@
+"""Register budgets the launch shapes depend on (no GPU: hipcc cross-compiles gfx950 and the kernel
+descriptors are read from the assembly).
+
+Two forward workgroups of 16 waves share a CU only at 8 waves per SIMD: <= 64 VGPRs AND, on gfx950,
+<= ~96 SGPRs including VCC and the reserved ones (measured: a forward with 97-100 SGPRs lost the second
+workgroup).  The backward keeps its in-flight loads in v[96:113], above the
+96 registers the compiler may allocate."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def descriptors(tmp_path_factory):
+    from spherehand_amd import build
+    out = str(tmp_path_factory.mktemp("asm") / "sphere_raster.s")
+    flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call([build.HIPCC] + flags + ["-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"),
+                                                   "-I", os.path.join(build.PKG, "csrc"), "-o", out,
+                                                   os.path.join(build.PKG, "csrc", "sphere_raster.hip")],
+                          stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    meta = text[text.index("amdhsa.kernels:"):]
+    kernels = {}
+    for block in meta.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        kernels[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
+                         for k in ("sgpr_count", "vgpr_count", "vgpr_spill_count", "sgpr_spill_count")}
+    return kernels
+
+
+def test_two_forward_workgroups_fit_a_cu(descriptors):
+    flags = lambda n: re.findall(r"Lb([01])E", re.search(r"kernelI((?:L[bi]\d+E)+)", n).group(1))
+    box = {n: d for n, d in descriptors.items() if "sphere_zbuf_fwd_kernel" in n and flags(n)[3:5] == ["0", "1"]}
+    assert len(box) == 8          # OWNER x VEC4 x POW2, one workgroup per crop (PERSIST = false), BOX = true
+    for name, d in box.items():
+        assert d["vgpr_count"] <= 64, (name, d)
+        assert d["sgpr_count"] <= 88, (name, d)
+        assert d["vgpr_spill_count"] == 0 and d["sgpr_spill_count"] == 0, (name, d)
+
+
+def test_backward_leaves_its_load_registers_alone(descriptors):
+    bwd = {n: d for n, d in descriptors.items() if "sphere_zbuf_bwd_kernel" in n}
+    assert len(bwd) == 24         # VEC4 x POW2 x PERSIST x (8 waves, 16 waves, 16 waves whole crop)
+    for name, d in bwd.items():
+        assert d["vgpr_count"] <= 114, (name, d)      # 96 for the compiler + v[96:113] named in the asm statements
+        assert d["vgpr_spill_count"] == 0, (name, d)
