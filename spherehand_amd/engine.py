@@ -153,6 +153,11 @@ class Engine:
             # then varies run to run (up to 3e-3 of its largest entry on MI355X, tools/debug_determinism.py).
             # This project's own kernels are deterministic by construction (no float atomics anywhere).
             torch.backends.cudnn.deterministic = True
+        if getattr(opts, 'miopen_find', False) and dev.type == 'cuda':
+            # MIOpen's find mode: every convolution shape is timed once and the fastest solver kept, instead of the
+            # immediate-mode heuristic.  Reference-sized step on MI355X: 9.3-9.6 -> 8.7-8.8 ms, for ~25 s at start-up
+            # (tools/exp_miopen_find.py).  Off by default, like the reference (which never sets cudnn.benchmark).
+            torch.backends.cudnn.benchmark = True
         S = getattr(opts, 'image_size', 64)
         self.constant = Constant(mesh, S)
         c = self.constant
