@@ -570,11 +570,13 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     // (a hit at exactly 100.0: background_cell() / tie_owner()).
     const unsigned long long bad = __ballot(valid && !(sphere_is_tame(sph) && fabsf(sph.z) < 1e30f));
     const unsigned long long low = __ballot(valid && sph.z <= kBackground);
+    const unsigned long long behind = __ballot(valid && sph.z > kBackground);
     bool too_big;   // excluded by the launcher (W <= kMaxFastWidth, H <= 32768)
     const int total = build_work_list<kSphereCostFwd>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
     if (lane == 0) {
       s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
       s_flag[1] = total;
+      s_flag[12] = behind != 0ull;   // only a sphere centred behind the background can hit at exactly 100.0 (tie_owner)
     }
   }
 
@@ -667,6 +669,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   if (pf_wave && has_next && valid) sph_next = spheres[(size_t)(n + crop_step) * J + lane];
 
   const bool general = s_flag[0] != 0;   // workgroup-uniform: the whole region takes the tile code
+  const bool may_tie = rfl(s_flag[12]) != 0;
   int tile_lo = r0, tile_hi = r1;        // rows for the tile code
   if (!general) {
     // (BOX = false: the z-buffer holds the whole region at the image's own pitch -- one workgroup per CU has the LDS
@@ -738,8 +741,8 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
             o = make_float4(key_depth((uint32_t)(k01.x >> 32)), key_depth((uint32_t)(k01.y >> 32)),
                             key_depth((uint32_t)(k23.x >> 32)), key_depth((uint32_t)(k23.y >> 32)));
             a = make_uchar4((uint8_t)k01.x, (uint8_t)k01.y, (uint8_t)k23.x, (uint8_t)k23.y);
-            if (is_background_tie(k01.x) || is_background_tie(k01.y) || is_background_tie(k23.x) ||
-                is_background_tie(k23.y)) {   // (practically never)
+            if (may_tie && (is_background_tie(k01.x) || is_background_tie(k01.y) || is_background_tie(k23.x) ||
+                            is_background_tie(k23.y))) {   // (practically never)
               const float yg = axis_coord_t<POW2>(ay, v + r0);
               if (is_background_tie(k01.x)) a.x = (uint8_t)tie_owner(s_sph, (uint32_t)k01.x, axis_coord_t<POW2>(ax, x), yg);
               if (is_background_tie(k01.y)) a.y = (uint8_t)tie_owner(s_sph, (uint32_t)k01.y, axis_coord_t<POW2>(ax, x + 1), yg);
@@ -762,7 +765,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
         if (OWNER) {
           out[(size_t)(r0 + v) * W + u] = key_depth((uint32_t)((unsigned long long)k >> 32));
           aout[(size_t)(r0 + v) * W + u] =
-              is_background_tie((unsigned long long)k)
+              (may_tie && is_background_tie((unsigned long long)k))
                   ? (uint8_t)tie_owner(s_sph, (uint32_t)k, axis_coord_t<POW2>(ax, u), axis_coord_t<POW2>(ay, v + r0))
                   : (uint8_t)k;
         } else {
@@ -1216,11 +1219,13 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     s_sph[lane] = sph;
     const unsigned long long bad = __ballot(valid && !(sphere_is_tame(sph) && fabsf(sph.z) < 1e30f));
     const unsigned long long low = __ballot(valid && sph.z <= kBackground);
+    const unsigned long long behind = __ballot(valid && sph.z > kBackground);
     bool too_big;
     const int total = build_work_list<kSphereCostMse>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
     if (lane == 0) {
       s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
       s_flag[1] = total;
+      s_flag[12] = behind != 0ull;   // only a sphere centred behind the background can hit at exactly 100.0 (tie_owner)
     }
   }
   __syncthreads();
@@ -1228,6 +1233,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   float4 sph_next = make_float4(0.f, 0.f, 0.f, 0.f);
   if (pf_wave && has_next && valid) sph_next = spheres[(size_t)(n + crop_step) * J + lane];
   const bool general = s_flag[0] != 0;
+  const bool may_tie = rfl(s_flag[12]) != 0;
   ua = rfl(s_flag[2]);
   ub = rfl(s_flag[3]);
 
@@ -1276,8 +1282,8 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
       const float4 d = make_float4(key_depth((uint32_t)(k01.x >> 32)), key_depth((uint32_t)(k01.y >> 32)),
                                    key_depth((uint32_t)(k23.x >> 32)), key_depth((uint32_t)(k23.y >> 32)));
       if (out) stream_store(out4 + c, d);
-      if (is_background_tie(k01.x) || is_background_tie(k01.y) || is_background_tie(k23.x) ||
-          is_background_tie(k23.y)) {   // a hit at exactly 100.0 (practically never): who owns it (tie_owner)
+      if (may_tie && (is_background_tie(k01.x) || is_background_tie(k01.y) || is_background_tie(k23.x) ||
+                      is_background_tie(k23.y))) {   // a hit at exactly 100.0 (practically never): who owns it (tie_owner)
         const float yg = axis_coord_t<POW2>(ay, v + r0);
         if (is_background_tie(k01.x)) k01.x = (k01.x & ~0xffull) | tie_owner(s_sph, (uint32_t)k01.x, axis_coord_t<POW2>(ax, x), yg);
         if (is_background_tie(k01.y)) k01.y = (k01.y & ~0xffull) | tie_owner(s_sph, (uint32_t)k01.y, axis_coord_t<POW2>(ax, x + 1), yg);
