@@ -198,6 +198,31 @@ def test_hit_at_exactly_the_background_depth(ops, oracle):
         assert np.abs(gsp.cpu().numpy() - og2).max() <= 2e-5 * np.abs(og2).max() + 1e-3
 
 
+def test_launches_with_two_workgroups_per_cu(oracle):
+    """768 crops (the golden batch three times): the launcher's own choice is then the box z-buffer at half of a CU's
+    LDS in the forward and 8-wave workgroups over the touched rows in the backward (two workgroups per CU).  Same bits
+    / same gradients as the 256-crop launch (one whole-crop workgroup per CU) and as the golden hashes."""
+    from spherehand_amd import ops
+    g = golden("g3_batch256.npz")
+    sp_h = spheres_from(g["centres"], g["radii"])
+    sp3 = np.concatenate([sp_h, sp_h, sp_h])
+    d1, a1 = ops.sphere_raster_fwd(dev(sp_h), 128, 128, want_argmin=True)
+    d3, a3 = ops.sphere_raster_fwd(dev(sp3), 128, 128, want_argmin=True)
+    d3h = d3.cpu().numpy()
+    sha = [hashlib.sha256(d3h[i].tobytes()).hexdigest() for i in range(768)]
+    assert sha == list(g["depth_ieee_sha256"]) * 3
+    assert np.array_equal(a3.cpu().numpy(), np.concatenate([a1.cpu().numpy()] * 3))
+    assert np.array_equal(bits(ops.sphere_raster_fwd(dev(sp3), 128, 128).cpu().numpy()), bits(d3h))     # depth only
+    gd = np.random.RandomState(int(g["g_seed"])).standard_normal((256, 128, 128)).astype(np.float32)
+    gs1 = ops.sphere_raster_bwd(dev(sp_h), dev(gd), a1).cpu().numpy()
+    gs3 = ops.sphere_raster_bwd(dev(sp3), dev(np.concatenate([gd, gd, gd])), a3).cpu().numpy()
+    og = oracle.sphere_raster_bwd(sp_h, gd)
+    tol = 1e-5 * np.abs(og).max() + 1e-4
+    for k in range(3):
+        assert np.abs(gs3[256 * k:256 * (k + 1)] - og).max() <= tol
+    assert np.abs(gs1 - og).max() <= tol
+
+
 def test_nan_inf(ops, oracle):
     sp = np.array([[[0, 0, 10, 20], [np.nan, 0, 0, 5]],
                    [[0, 0, np.nan, 20], [50, 50, 0, 5]],
