@@ -63,6 +63,9 @@ int shr_device_info(char *name_host, int name_len, int *num_cu_host);
 #define SHR_TUNE_D2M_BAND_UNITS 9  /* 256-pixel units per band handed to a wave: 0 = by crop size */
 #define SHR_TUNE_BWD_WAVES 12      /* waves per backward workgroup: 0 = by launch size (8 with half of a CU's LDS when the
                                     * launch has two workgroups per CU, else 16), 8, 16 */
+#define SHR_TUNE_MSE_BOX 13        /* fused render-and-compare with the box z-buffer (two workgroups per CU): -1 = by launch
+                                    * size, 0 = never, 1 = always (power-of-two images >= 32 wide), > 1 = with that many bytes
+                                    * of LDS per workgroup */
 #define SHR_TUNE_FWD_ZBUF_BYTES 11  /* forward z-buffer bytes per workgroup: 0 = by launch size (half of a CU's LDS when the
                                     * launch has two workgroups per CU, else one pass for any box); a box that exceeds
                                     * it is rasterized in passes over row bands */

@@ -18,6 +18,7 @@ struct Tuning {
   int fwd_shares = 0x24344464;          // work-list shares of the four wave age groups, oldest in the low byte (sum 256)
   int bwd_shares = 0x2c3a4654;
   int lds_pad = 0;                      // experiments: extra dynamic LDS per zbuf workgroup (forces one workgroup per CU)
+  int mse_box = -1;                     // fused kernel's box variant: -1 = by launch size, 0 = never, 1 = always, > 1 = with that much LDS
   int bwd_waves = 0;                    // waves per backward workgroup: 0 = by launch size, 8 or 16
   int fwd_zbuf_bytes = 0;               // forward z-buffer bytes per workgroup; 0 = by launch size (launch_zbuf_fwd_t)
   int persistent = 1;                   // 0: one workgroup per crop; 1: persistent workgroups when N exceeds the device; > 1: that many
@@ -208,6 +209,7 @@ extern "C" int shr_set_tuning(int key, int value) {
       g_tune.fwd_waves = value;
       return SHR_OK;
     case 99: g_tune.lds_pad = value; return SHR_OK;
+    case SHR_TUNE_MSE_BOX: if (value < -1) return SHR_EINVAL; g_tune.mse_box = value; return SHR_OK;
     case SHR_TUNE_BWD_WAVES: if (value != 0 && value != 8 && value != 16) return SHR_EINVAL; g_tune.bwd_waves = value; return SHR_OK;
     case SHR_TUNE_FWD_ZBUF_BYTES: if (value < 0) return SHR_EINVAL; g_tune.fwd_zbuf_bytes = value; return SHR_OK;
     case SHR_TUNE_PERSISTENT: if (value < 0) return SHR_EINVAL; g_tune.persistent = value; return SHR_OK;
@@ -312,6 +314,8 @@ extern "C" int shr_sphere_raster_bwd(const float *spheres, const float *grad_dep
 }
 
 namespace {
+// rows per region of the fused kernel: sized for the most partial sums (SHR_MAX_SPHERES), so that the number of
+// regions -- part of the output layout -- depends on the image only
 int mse_rows(int H, int W) {
   using namespace shr;
   if (H <= 0 || W <= 0 || W > kMaxFastWidth || H > 32768) return 0;
@@ -337,12 +341,32 @@ extern "C" int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, 
   const int rows = mse_rows(H, W);
   if (rows <= 0 || (H + rows - 1) / rows > 65535) return SHR_ETOOLARGE;
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = kHdrBytes + kPartBytes + (size_t)rows * (W + kRowPad) * 8;
+  const size_t part = (size_t)kZWaves * J * 16;   // [wave][J] partial sums
+  const size_t lds = kHdrBytes + part + (size_t)rows * (W + kRowPad) * 8;
   // (persistent workgroups measured no gain for this kernel -- its per-crop chain is longer and the observed image's
   // first read follows an index load -- so it stays at one workgroup per crop and region: PERSIST = false)
-  dim3 grid((unsigned)N, (unsigned)((H + rows - 1) / rows));
-  static AttrDone attr_a, attr_b;
-  if (is_pow2(W) && is_pow2(H)) {
+  const int regions = (H + rows - 1) / rows;
+  dim3 grid((unsigned)N, (unsigned)regions);
+  static AttrDone attr_a, attr_b, attr_c;
+  // Two workgroups per CU when the launch has them (forward with owner map, 1152 crops @256x256: 157 -> 95 us with the
+  // box z-buffer at half of the LDS, tools/exp_fwd256.py): the box variant, 64 VGPRs, zcells cells of z-buffer.
+  const size_t half = kMaxLds / 2;
+  const bool box_ok = is_pow2(W) && is_pow2(H) && W >= 32 && lds > half && (long long)N * regions >= 2LL * num_cus() &&
+                      half >= kHdrBytes + part + 8 * (size_t)max_box_pitch(W) * 8;
+  const int box = g_tune.mse_box < 0 ? (box_ok ? 1 : 0) : (g_tune.mse_box && is_pow2(W) && is_pow2(H) && W >= 32);
+  if (box) {
+    size_t blds = g_tune.mse_box > 1 ? (size_t)g_tune.mse_box : half;
+    const size_t least = kHdrBytes + part + 8 * (size_t)max_box_pitch(W) * 8;
+    if (blds < least) blds = least;
+    if (blds > (size_t)kMaxLds) blds = kMaxLds;
+    const int zcells = (int)((blds - kHdrBytes - part) / 8);
+    auto k = sphere_zbuf_mse_box_kernel<true>;
+    const hipError_t e = allow_big_lds(k, &attr_c);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, grid, dim3(1024), blds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
+                       target_index, depth, sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), rows,
+                       log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, zcells);
+  } else if (is_pow2(W) && is_pow2(H)) {
     auto k = sphere_zbuf_mse_kernel<true, false>;
     const hipError_t e = allow_big_lds(k, &attr_a);
     if (e != hipSuccess) return (int)e;

@@ -1128,12 +1128,15 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
 // tiles like sphere_tile_bwd_kernel with the gradient formed in registers.
 constexpr int kSphereCostMse = 28;
 
-template <bool POW2, bool PERSIST>
-__global__ void __launch_bounds__(1024)
-sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_, const float *__restrict__ target,
-                       const int *__restrict__ target_index, float *__restrict__ depth,
-                       float *__restrict__ sse_out, float4 *__restrict__ grad_out, int rows_per_region_,
-                       int w4_shift_, int shares_fwd, int shares_bwd) {
+// (BOX: the z-buffer covers the touched box only, `zcells` cells, as in the forward -- half of a CU's LDS and, with
+// 64 VGPRs, two workgroups per CU; the rows a box has beyond it go through the tile code of the general path, which
+// adds to the same partial sums.  Needs a power-of-two image at least 32 wide: tile rows are then whole units.)
+template <bool POW2, bool PERSIST, bool BOX>
+__device__ __forceinline__ void
+sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_, const float *__restrict__ target,
+                     const int *__restrict__ target_index, float *__restrict__ depth,
+                     float *__restrict__ sse_out, float4 *__restrict__ grad_out, int rows_per_region_,
+                     int w4_shift_, int shares_fwd, int shares_bwd, int zcells_) {
   using Key = unsigned long long;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
@@ -1141,8 +1144,8 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   int *s_ends = reinterpret_cast<int *>(smem + kOffEnds);
   int *s_flag = reinterpret_cast<int *>(smem + kOffFlags);
   float4 *s_next = reinterpret_cast<float4 *>(smem + kOffNext);
-  float4 *s_part = reinterpret_cast<float4 *>(smem + kHdrBytes);
-  Key *zbuf = reinterpret_cast<Key *>(smem + kHdrBytes + kPartBytes);
+  float4 *s_part = reinterpret_cast<float4 *>(smem + kHdrBytes);                          // [wave][J]
+  Key *zbuf = reinterpret_cast<Key *>(smem + kHdrBytes + (size_t)kZWaves * J_ * sizeof(float4));
 
   // PERSISTENT workgroups (gridDim.x < N: crops blockIdx.x, blockIdx.x + gridDim.x, ... of this region): the youngest
   // wave requests the next crop's records after the first barrier and parks them in LDS (see the forward).
@@ -1152,8 +1155,9 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   // hoists each crop-invariant value out of the crop loop and keeps it in a register (forward: 92 instead of 51
   // VGPRs; the fused kernel spilled).
   int J = J_, H = H_, W = W_, rows_per_region = rows_per_region_, w4_shift = w4_shift_, tid = threadIdx.x;
+  int zcells = zcells_;
   if (PERSIST) {
-    asm volatile("" : "+s"(J), "+s"(H), "+s"(W), "+s"(rows_per_region), "+s"(w4_shift));
+    asm volatile("" : "+s"(J), "+s"(H), "+s"(W), "+s"(rows_per_region), "+s"(w4_shift), "+s"(zcells));
     asm volatile("" : "+v"(tid));
   }
   const int region = blockIdx.y, nregions = gridDim.y;
@@ -1174,13 +1178,14 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
   if (valid && (wave_s == 0 || bg_wave))   // the others: wave 0's LDS copy, later
     sph = crop_it == 0 ? spheres[(size_t)n * J + lane] : s_next[lane];
-  s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // 1024 = 16 waves x 64 spheres
-  {  // background everywhere
+  if (tid < kZWaves * J) s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // (16 waves x J <= 64 spheres)
+  {  // background everywhere (BOX: every cell a box of this region can use)
     const Key bg = (Key)background_cell();
-    const int nvec = (rh * LW) >> 1;
+    const int ninit = BOX ? min(zcells, rh * max_box_pitch(W)) : rh * LW;
+    const int nvec = ninit >> 1;
     const ulonglong2 v = make_ulonglong2(bg, bg);
     for (int i = tid; i < nvec; i += 1024) reinterpret_cast<ulonglong2 *>(zbuf)[i] = v;
-    if (tid == 0 && ((rh * LW) & 1)) zbuf[rh * LW - 1] = bg;
+    if (tid == 0 && (ninit & 1)) zbuf[ninit - 1] = bg;
   }
   pin_axes(ax, ay);
 
@@ -1198,13 +1203,29 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   for (int k = 0; k < kTgtAhead; k++) tpre[k] = tgt4[min(((wave_s + (k << 4)) << 6) + lane, nchunk - 1)];
   int ua = 0, ub = nunits;
   if (bg_wave) {   // rows no sphere touches: depth = background, stored while wave 0 builds the list
-    int cv0, cv1;
-    touched_rows(sph, valid, ay, ky, r0, r1, cv0, cv1);
+    int cv0, cv1, cu0 = 0, cu1 = W - 1;
+    if (BOX) touched_box(sph, valid, ax, ay, kx, ky, W, r0, r1, lane, cv0, cv1, cu0, cu1);
+    else touched_rows(sph, valid, ay, ky, r0, r1, cv0, cv1);
     if (cv1 < cv0) ua = ub = nunits;
     else { ua = ((cv0 - r0) * w4) >> 6; ub = min(nunits, ((cv1 - r0 + 1) * w4 + 63) >> 6); }
     ua = rfl(ua);
     ub = rfl(ub);
-    if (wave_s == 1 && lane == 0) { s_flag[2] = ua; s_flag[3] = ub; }
+    if (wave_s == 1 && lane == 0) {
+      s_flag[2] = ua; s_flag[3] = ub;
+      if (BOX) {   // everything the other waves derive from the box (see the forward)
+        cu0 &= ~3;
+        const int bw = cu1 >= cu0 ? ((cu1 | 3) - cu0 + 1) : 4;
+        const int pitch = box_pitch(bw);
+        const int split = (cv0 + zcells / pitch) & ~(kTileH - 1);        // rows [cv0, split) fit the z-buffer
+        const bool over = split <= cv1;
+        s_flag[4] = cv0; s_flag[5] = over ? split : cv1 + 1; s_flag[6] = cu0; s_flag[7] = bw;
+        s_flag[8] = pitch;
+        s_flag[9] = over ? split : r1;                                   // the walks' clip row
+        // tile rows: from the split to the end of the touched units (whole units: W >= 32 is a power of two)
+        s_flag[10] = over ? split : r1;
+        s_flag[11] = over ? min(r1, (r0 + ((ub << 6) + w4 - 1) / w4 + kTileH - 1) & ~(kTileH - 1)) : r1;
+      }
+    }
     if (out) {
       const float4 bgd = make_float4(kBackground, kBackground, kBackground, kBackground);
       const int nbg = ua + (nunits - ub);
@@ -1236,6 +1257,13 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   const bool may_tie = rfl(s_flag[12]) != 0;
   ua = rfl(s_flag[2]);
   ub = rfl(s_flag[3]);
+  // the z-buffer's rows [p0, pe) and columns [cu0, cu0 + bw) at `pitch` (BOX = false: the whole region at the image's
+  // own), the walks' clip row, and the rows [tile_lo, tile_hi) that go through the tile code
+  const int p0 = BOX ? rfl(s_flag[4]) : r0, pe = BOX ? rfl(s_flag[5]) : r1;
+  const int cu0 = BOX ? rfl(s_flag[6]) : 0, bw = BOX ? rfl(s_flag[7]) : W;
+  const int pitch = BOX ? rfl(s_flag[8]) : LW, clip = BOX ? rfl(s_flag[9]) : r1;
+  const int tile_lo = general ? r0 : (BOX ? rfl(s_flag[10]) : r1), tile_hi = general ? r1 : (BOX ? rfl(s_flag[11]) : r1);
+  Key *zb = zbuf - (p0 * pitch + cu0);   // cell of pixel (v, u) = zb[v * pitch + u]
 
   float sse = 0.f;
   if (!general) {
@@ -1245,7 +1273,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     wl.item = s_items[lane];
     wl.end = s_ends[lane];
     walk_my_slice<POW2, kSphereCostMse, true>(
-        wl, J, s_flag[1], wave, kZWaves, shares_fwd, lane, ax, ay, r0, r1, LW,
+        wl, J, s_flag[1], wave, kZWaves, shares_fwd, lane, ax, ay, 0, clip, pitch,
         [&](int j, const float4 s, int cell_a, int cell_b, float, float ca, float yga, float ygb, bool ok_a,
             bool ok_b, bool has_b, auto row_test) {
           const float dya = yga - s.y, dyb = ygb - s.y;
@@ -1255,10 +1283,10 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
           if (has_b) {
             const bool ha = qa > kHitMin, hb = qb > kHitMin;
             const float da = s.z - sqrt_rn(qa), db = s.z - sqrt_rn(qb);
-            if (ha) put(zbuf + cell_a, da);
-            if (hb) put(zbuf + cell_b, db);
+            if (ha) put(zb + cell_a, da);
+            if (hb) put(zb + cell_b, db);
           } else if (qa > kHitMin) {
-            put(zbuf + cell_a, s.z - sqrt_rn(qa));
+            put(zb + cell_a, s.z - sqrt_rn(qa));
           }
         },
         [](int) {});
@@ -1269,15 +1297,25 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     auto convert_unit = [&](int u, const float4 t) {
       const int c = (u << 6) + lane;
       if (c >= nchunk) return;
+      int v, x;
+      if (POW2 || w4_shift >= 0) { v = c >> w4_shift; x = (c & (w4 - 1)) << 2; }
+      else { v = c / w4; x = (c - v * w4) << 2; }
+      if (BOX && v + r0 >= tile_lo && v + r0 < tile_hi) return;   // rows left to the tile code (whole units, background ones among them)
       if (u < ua || u >= ub) {   // background rows (already stored)
         const float e0 = kBackground - t.x, e1 = kBackground - t.y, e2 = kBackground - t.z, e3 = kBackground - t.w;
         sse += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
         return;
       }
-      int v, x;
-      if (POW2 || w4_shift >= 0) { v = c >> w4_shift; x = (c & (w4 - 1)) << 2; }
-      else { v = c / w4; x = (c - v * w4) << 2; }
-      ulonglong2 *cell = reinterpret_cast<ulonglong2 *>(zbuf + v * LW + x);
+      if (BOX) {
+        if (!((unsigned)(v + r0 - p0) < (unsigned)(pe - p0) && (unsigned)(x - cu0) < (unsigned)bw)) {
+          // a touched row beside the box (or a background row inside a touched unit)
+          const float e0 = kBackground - t.x, e1 = kBackground - t.y, e2 = kBackground - t.z, e3 = kBackground - t.w;
+          sse += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+          if (out) stream_store(out4 + c, make_float4(kBackground, kBackground, kBackground, kBackground));
+          return;
+        }
+      }
+      ulonglong2 *cell = reinterpret_cast<ulonglong2 *>(zb + (v + r0) * pitch + x);
       ulonglong2 k01 = cell[0], k23 = cell[1];
       const float4 d = make_float4(key_depth((uint32_t)(k01.x >> 32)), key_depth((uint32_t)(k01.y >> 32)),
                                    key_depth((uint32_t)(k23.x >> 32)), key_depth((uint32_t)(k23.y >> 32)));
@@ -1310,13 +1348,13 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
 
     // ---- walk (backward): static slices, per-run DPP sums into the wave's LDS row ------------
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const int cell_max = rh * LW - 1;
+    const int cell_max = (p0 * pitch + cu0) + (pe - p0) * pitch - 1;   // the z-buffer's last cell, as the walk counts cells
     walk_my_slice<POW2, kSphereCostMse, true>(
-        wl, J, s_flag[1], wave, kZWaves, shares_bwd, lane, ax, ay, r0, r1, LW,
+        wl, J, s_flag[1], wave, kZWaves, shares_bwd, lane, ax, ay, 0, clip, pitch,
         [&](int j, const float4 s, int cell_a, int cell_b, float dx, float ca, float yga, float ygb, bool ok_a,
             bool ok_b, bool has_b, auto) {
           auto take = [&](int cell, float yg, bool ok) {
-            const Key k = zbuf[min(cell, cell_max)];
+            const Key k = zb[min(cell, cell_max)];
             if ((uint8_t)k == (uint8_t)j && ok) {
               const float dy = yg - s.y, q = ca - dy * dy;
               const float g = __uint_as_float((uint32_t)(k >> 32));
@@ -1334,15 +1372,16 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
           // (the slot belongs to this wave: ds_add_f32 in program order, no read-back to wait for;
           // a crop of several row regions visits a sphere once per region)
           const float t = wave_sum4_transposed(a0, a1, a2, a3, lane);
-          if (lane >= 60) atomicAdd(reinterpret_cast<float *>(s_part + wave * SHR_MAX_SPHERES + j) + (lane & 3), t);
+          if (lane >= 60) atomicAdd(reinterpret_cast<float *>(s_part + wave * J + j) + (lane & 3), t);
           a0 = a1 = a2 = a3 = 0.f;
         });
-  } else {
-    // ---- general path: the region's 32x8 tiles, owners and gradient in registers --------------
+  }
+  if (tile_lo < tile_hi) {
+    // ---- general path (or the rows beyond the z-buffer): 32x8 tiles, owners and gradient in registers ---
     // (rows_per_region is a multiple of the tile height whenever there are several regions)
     const int tiles_x = (W + kTileW - 1) / kTileW;
-    const int t0 = (r0 / kTileH) * tiles_x, t1 = ((r1 + kTileH - 1) / kTileH) * tiles_x;
-    float4 *acc = s_part + wave * SHR_MAX_SPHERES;
+    const int t0 = (tile_lo / kTileH) * tiles_x, t1 = ((tile_hi + kTileH - 1) / kTileH) * tiles_x;
+    float4 *acc = s_part + wave * J;
     const float *tfull = tgt - (size_t)r0 * W;
     float *ofull = out ? out - (size_t)r0 * W : nullptr;
     for (int tile = t0 + wave; tile < t1; tile += kZWaves) {
@@ -1418,7 +1457,7 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   if (tid < J) {
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int w = 0; w < kZWaves; w++) {
-      const float4 a = s_part[w * SHR_MAX_SPHERES + tid];
+      const float4 a = s_part[w * J + tid];
       t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
     }
     t.w = t.w * s_sph[tid].w;
@@ -1426,6 +1465,27 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   }
   if (has_next) __syncthreads();   // records, work list, partials and z-buffer are rewritten next
   }  // crops
+}
+
+template <bool POW2, bool PERSIST>
+__global__ void __launch_bounds__(1024)
+sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J, int H, int W, const float *__restrict__ target,
+                       const int *__restrict__ target_index, float *__restrict__ depth, float *__restrict__ sse_out,
+                       float4 *__restrict__ grad_out, int rows_per_region, int w4_shift, int shares_fwd, int shares_bwd) {
+  sphere_zbuf_mse_body<POW2, PERSIST, false>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
+                                             rows_per_region, w4_shift, shares_fwd, shares_bwd, 0);
+}
+
+// two of these per CU: eight waves per SIMD, i.e. at most 64 VGPRs
+template <bool POW2>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+sphere_zbuf_mse_box_kernel(const float4 *__restrict__ spheres, int N, int J, int H, int W, const float *__restrict__ target,
+                           const int *__restrict__ target_index, float *__restrict__ depth, float *__restrict__ sse_out,
+                           float4 *__restrict__ grad_out, int rows_per_region, int w4_shift, int shares_fwd, int shares_bwd,
+                           int zcells) {
+  static_assert(POW2, "box variant: power-of-two images");
+  sphere_zbuf_mse_body<POW2, false, true>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
+                                          rows_per_region, w4_shift, shares_fwd, shares_bwd, zcells);
 }
 
 }  // namespace shr

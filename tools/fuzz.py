@@ -33,6 +33,7 @@ def sphere_case():
     zb = int(rs.choice([0, 0, 6, 20, 48, 80])) * 1024                           # forward z-buffer: several row bands per box
     ops.set_tuning(ops.TUNE_FWD_ZBUF_BYTES, zb)
     ops.set_tuning(ops.TUNE_BWD_WAVES, int(rs.choice([0, 8, 16])))
+    ops.set_tuning(ops.TUNE_MSE_BOX, int(rs.choice([-1, 0, 1, 20 * 1024, 60 * 1024])))
     d, a = ops.sphere_raster_fwd(dev(sp), H, W, want_argmin=True)
     od, oa = oracle.sphere_raster_fwd(sp, H, W)
     if not np.isfinite(sp).all() or np.abs(sp).max() > 1e20:
