@@ -43,6 +43,13 @@ def test_two_forward_workgroups_fit_a_cu(descriptors):
         assert d["vgpr_spill_count"] == 0 and d["sgpr_spill_count"] == 0, (name, d)
 
 
+def test_two_fused_box_workgroups_fit_a_cu(descriptors):
+    box = {n: d for n, d in descriptors.items() if "sphere_zbuf_mse_box_kernel" in n}
+    assert len(box) == 1
+    for name, d in box.items():
+        assert d["vgpr_count"] <= 64 and d["sgpr_count"] <= 88 and d["vgpr_spill_count"] == 0, (name, d)
+
+
 def test_backward_leaves_its_load_registers_alone(descriptors):
     bwd = {n: d for n, d in descriptors.items() if "sphere_zbuf_bwd_kernel" in n}
     assert len(bwd) == 24         # VEC4 x POW2 x PERSIST x (8 waves, 16 waves, 16 waves whole crop)

@@ -143,8 +143,19 @@ def _random_spheres(rs, n, j=41, spread=80.0):
     return sp
 
 
-@pytest.mark.parametrize("S,H", [(64, 64), (128, 128), (256, 256), (96, 72), (320, 200)])
-def test_fused_render_and_compare_equals_composition(S, H):
+@pytest.fixture
+def mse_box(request):
+    """The fused kernel's launch shape: -1 the launcher's choice, 1 the box variant (touched-box z-buffer at half of a
+    CU's LDS), a byte count: the box variant squeezed into that much LDS (rows beyond it go through the tile code)."""
+    from spherehand_amd import ops
+    ops.set_tuning(ops.TUNE_MSE_BOX, request.param)
+    yield request.param
+    ops.set_tuning(ops.TUNE_MSE_BOX, -1)
+
+
+@pytest.mark.parametrize("mse_box", [-1, 1, 20 * 1024], indirect=True)
+@pytest.mark.parametrize("S,H", [(64, 64), (128, 128), (256, 256), (96, 72), (320, 200), (256, 128), (32, 64)])
+def test_fused_render_and_compare_equals_composition(S, H, mse_box):
     """shr_sphere_raster_mse == raster fwd + (depth - target)^2 + raster bwd (the unfused chain)."""
     from spherehand_amd import ops
     rs = np.random.RandomState(S + H)
