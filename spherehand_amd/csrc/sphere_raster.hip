@@ -124,7 +124,7 @@ int launch_zbuf_fwd_t(const float4 *sp, int N, int J, int H, int W, float *depth
   const size_t full = kHdrBytes + (size_t)rows * pitch * key, least = kHdrBytes + 8 * pitch * key, half = kMaxLds / 2;
   size_t lds = full;
   if (g_tune.fwd_zbuf_bytes > 0) lds = kHdrBytes + (size_t)g_tune.fwd_zbuf_bytes;
-  else if (full > half && (long long)N * regions >= 2LL * num_cus()) lds = half;
+  else if (POW2 && full > half && (long long)N * regions >= 2LL * num_cus()) lds = half;   // (the other instantiations take 84 SGPRs: one workgroup per CU whatever the LDS)
   if (lds < least) lds = least;
   if (lds > full) lds = full;
   // A workgroup with the full budget holds its whole region at the image's own pitch: nothing is derived from a box

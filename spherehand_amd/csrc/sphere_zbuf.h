@@ -1476,7 +1476,9 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J, int H, 
                                              rows_per_region, w4_shift, shares_fwd, shares_bwd, 0);
 }
 
-// two of these per CU: eight waves per SIMD, i.e. at most 64 VGPRs
+// two of these per CU: eight waves per SIMD, i.e. at most 64 VGPRs -- and few enough SGPRs: left alone the kernel takes
+// 93 (descriptor count) and the second workgroup does not become resident (242 us against 172 with the cap's 78 and 15
+// scalar spills, 1152 crops @256x256)
 template <bool POW2>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sphere_zbuf_mse_box_kernel(const float4 *__restrict__ spheres, int N, int J, int H, int W, const float *__restrict__ target,

@@ -1,9 +1,9 @@
 """Register budgets the launch shapes depend on (no GPU: hipcc cross-compiles gfx950 and the kernel
 descriptors are read from the assembly).
 
-Two forward workgroups of 16 waves share a CU only at 8 waves per SIMD: <= 64 VGPRs AND, on gfx950,
-<= ~96 SGPRs including VCC and the reserved ones (measured: a forward with 97-100 SGPRs lost the second
-workgroup).  The backward keeps its in-flight loads in v[96:113], above the
+Two workgroups of 16 waves share a CU only at 8 waves per SIMD: <= 64 VGPRs AND, on gfx950, few enough
+SGPRs (measured on the descriptors' sgpr_count: kernels with 84, 93 and 98-106 lost the second workgroup,
+kernels with 71-78 kept it).  The backward keeps its in-flight loads in v[96:113], above the
 96 registers the compiler may allocate."""
 import os
 import re
@@ -35,11 +35,12 @@ def descriptors(tmp_path_factory):
 
 def test_two_forward_workgroups_fit_a_cu(descriptors):
     flags = lambda n: re.findall(r"Lb([01])E", re.search(r"kernelI((?:L[bi]\d+E)+)", n).group(1))
-    box = {n: d for n, d in descriptors.items() if "sphere_zbuf_fwd_kernel" in n and flags(n)[3:5] == ["0", "1"]}
-    assert len(box) == 8          # OWNER x VEC4 x POW2, one workgroup per crop (PERSIST = false), BOX = true
+    box = {n: d for n, d in descriptors.items()
+           if "sphere_zbuf_fwd_kernel" in n and flags(n)[2:5] == ["1", "0", "1"]}
+    assert len(box) == 4          # OWNER x VEC4; power-of-two images, one workgroup per crop (PERSIST = false), BOX = true
     for name, d in box.items():
         assert d["vgpr_count"] <= 64, (name, d)
-        assert d["sgpr_count"] <= 88, (name, d)
+        assert d["sgpr_count"] <= 80, (name, d)
         assert d["vgpr_spill_count"] == 0 and d["sgpr_spill_count"] == 0, (name, d)
 
 
@@ -47,7 +48,7 @@ def test_two_fused_box_workgroups_fit_a_cu(descriptors):
     box = {n: d for n, d in descriptors.items() if "sphere_zbuf_mse_box_kernel" in n}
     assert len(box) == 1
     for name, d in box.items():
-        assert d["vgpr_count"] <= 64 and d["sgpr_count"] <= 88 and d["vgpr_spill_count"] == 0, (name, d)
+        assert d["vgpr_count"] <= 64 and d["sgpr_count"] <= 80 and d["vgpr_spill_count"] == 0, (name, d)
 
 
 def test_backward_leaves_its_load_registers_alone(descriptors):
