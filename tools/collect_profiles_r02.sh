@@ -4,7 +4,6 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r02; rm -rf "$O"; mkdir -p "$O"
-export SHR_BENCH_SKIP_FIND=1   # (the find-mode training step: only in the plain bench line below)
 B="python bench.py --steps 300 --warmup 30 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o bench -- $B > "$O/stats.log" 2>&1
 BS="python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-secondary"
@@ -25,7 +24,6 @@ for S in 128 256; do
   S=$S REPS=10 timeout 300 rocprofv3 --kernel-trace --pmc $SQB --output-format csv -d "$O/sq_b_d2m$S" -o d2m -- python tools/prof_d2m.py > "$O/sq_b_d2m$S.log" 2>&1
   S=$S REPS=10 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/fetch_d2m$S" -o d2m -- python tools/prof_d2m.py > "$O/fetch_d2m$S.log" 2>&1
 done
-unset SHR_BENCH_SKIP_FIND
 timeout 400 python bench.py > "$O/bench_line.json" 2> "$O/bench_line.err"
 timeout 300 python bench.py --launch graph --no-secondary --no-cpu-baseline > "$O/bench_line_graph.json" 2>> "$O/bench_line.err"
 # summarise on the box and drop the raw counter / trace CSVs (gpurun merges at most 64 MiB back)
