@@ -51,23 +51,24 @@ __device__ __forceinline__ SoftArgmaxStats soft_argmax_stats(const float *uvm, c
 }
 
 template <bool BACKWARD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 soft_argmax_kernel(const float *__restrict__ hm, long long sn, long long sc, long long sp, int J, int h, int w,
                    float cx, float cy, float inv_fx, float inv_fy, float d_scale, float *__restrict__ xyz,
                    const float *__restrict__ grad_xyz, float *__restrict__ grad_hm) {
   extern __shared__ float slab[];                 // [2J][npx]
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nwaves = nthr >> 6;   // 16 waves: a sample's 41 key-points in three rounds (4 waves: 31 / 50 us forward / backward for 123 samples, half of the CUs idle)
   const int npx = h * w, C = 2 * J;
   const float *src = hm + (size_t)n * sn;
   const bool nhwc = sc == 1;
   // stage (coalesced along the input's fast axis)
-  for (int e = tid; e < C * npx; e += 256) {
+  for (int e = tid; e < C * npx; e += nthr) {
     int c, p;
     if (nhwc) { p = e / C; c = e - p * C; } else { c = e / npx; p = e - c * npx; }
     slab[c * npx + p] = src[(size_t)c * sc + (size_t)p * sp];
   }
   __syncthreads();
-  for (int j = wave; j < J; j += 4) {
+  for (int j = wave; j < J; j += nwaves) {
     float *uvm = slab + (size_t)j * npx, *dm = slab + (size_t)(J + j) * npx;
     const SoftArgmaxStats s = soft_argmax_stats(uvm, dm, npx, w, lane);
     if (!BACKWARD) {
@@ -93,7 +94,7 @@ soft_argmax_kernel(const float *__restrict__ hm, long long sn, long long sc, lon
   if (BACKWARD) {
     __syncthreads();
     float *dst = grad_hm + (size_t)n * sn;
-    for (int e = tid; e < C * npx; e += 256) {
+    for (int e = tid; e < C * npx; e += nthr) {
       int c, p;
       if (nhwc) { p = e / C; c = e - p * C; } else { c = e / npx; p = e - c * npx; }
       dst[(size_t)c * sc + (size_t)p * sp] = slab[c * npx + p];
@@ -125,10 +126,10 @@ static int soft_argmax_launch(bool backward, const float *hm, long long sn, long
     done[backward] = true;
   }
   if (backward)
-    hipLaunchKernelGGL(soft_argmax_kernel<true>, dim3((unsigned)N), dim3(256), lds, (hipStream_t)stream, hm, sn, sc, sp, J,
+    hipLaunchKernelGGL(soft_argmax_kernel<true>, dim3((unsigned)N), dim3(1024), lds, (hipStream_t)stream, hm, sn, sc, sp, J,
                        h, w, cx, cy, 1.0f / fx, 1.0f / fy, d_scale, xyz, grad_xyz, grad_hm);
   else
-    hipLaunchKernelGGL(soft_argmax_kernel<false>, dim3((unsigned)N), dim3(256), lds, (hipStream_t)stream, hm, sn, sc, sp, J,
+    hipLaunchKernelGGL(soft_argmax_kernel<false>, dim3((unsigned)N), dim3(1024), lds, (hipStream_t)stream, hm, sn, sc, sp, J,
                        h, w, cx, cy, 1.0f / fx, 1.0f / fy, d_scale, xyz, grad_xyz, grad_hm);
   return (int)hipGetLastError();
 }
