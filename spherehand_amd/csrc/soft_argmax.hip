@@ -116,14 +116,17 @@ static int soft_argmax_launch(bool backward, const float *hm, long long sn, long
   if (!hm || N < 0 || fx == 0.f || fy == 0.f || !shr_soft_argmax_supported(J, h, w)) return SHR_EINVAL;
   if (backward ? (!grad_xyz || !grad_hm) : !xyz) return SHR_EINVAL;
   const size_t lds = (size_t)2 * J * h * w * 4;
-  static bool done[2] = {false, false};
-  if (!done[backward]) {
+  // (the attribute is per device: one flag per device ordinal and direction)
+  static bool done_dev[64][2] = {};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = -1;
+  if (d < 0 || !done_dev[d][backward]) {
     const hipError_t e = backward ? hipFuncSetAttribute(reinterpret_cast<const void *>(soft_argmax_kernel<true>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
                                   : hipFuncSetAttribute(reinterpret_cast<const void *>(soft_argmax_kernel<false>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    done[backward] = true;
+    if (d >= 0) done_dev[d][backward] = true;
   }
   if (backward)
     hipLaunchKernelGGL(soft_argmax_kernel<true>, dim3((unsigned)N), dim3(1024), lds, (hipStream_t)stream, hm, sn, sc, sp, J,
