@@ -50,7 +50,10 @@ namespace shr {
 constexpr int kZWaves = 16;   // 1024 threads
 constexpr int kRowPad = 8;    // LDS row padding (elements): chunk rows start in different banks (no lane writes there)
 constexpr int kPadRows = 0;   // rows after the region's last (none: a chunk never overhangs its box)
-constexpr int kBgWaves = 7;   // forward: waves that store the background rows before the first barrier
+#ifndef SHR_BG_WAVES
+#define SHR_BG_WAVES 7
+#endif
+constexpr int kBgWaves = SHR_BG_WAVES;   // forward: waves that store the background rows before the first barrier
 // (storing them after the barrier instead, with smaller list shares for those waves, moves the barrier from 4.6 k
 // to 3.8 k cycles but the stores then cost the scan conversion more than that: measured 8.9 vs 8.6 us)
 // LDS header: spheres [64] float4 | work items [64] int4 | ends [64] int | flags [16] | next crop's spheres [64] float4
