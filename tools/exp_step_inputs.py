@@ -21,9 +21,12 @@ eng.network.train()
 real = [torch.stack([ds[i][k] for i in range(25)]) for k in range(4)]
 pose = sample_poses(48, seed=1)
 for _ in range(10): eng.step(real, pose, True, True)
+import gc
+if os.environ.get("GC") == "off": gc.disable()
+if os.environ.get("GC") == "freeze": gc.collect(); gc.freeze()
 b = []
-for _ in range(5):
+for _ in range(12):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(10): eng.step(real, pose, True, True)
     torch.cuda.synchronize(); b.append((time.perf_counter() - t0) / 10 * 1e3)
-print("real batch on %s: %s ms" % ("device" if on_dev else "host", " ".join("%.2f" % t for t in sorted(b))))
+print("gc=%s real batch on %s: %s ms" % (os.environ.get("GC", "default"), "device" if on_dev else "host", " ".join("%.2f" % t for t in sorted(b))))
