@@ -90,6 +90,15 @@ int shr_selftest_sqrt(unsigned lo_bits, unsigned hi_bits,
  * IEEE sqrt). */
 int shr_sphere_raster_fwd(const float *spheres, int N, int J, int H, int W,
                           float *depth, uint8_t *argmin, void *stream);
+/* The same with `flags` (0 = shr_sphere_raster_fwd).
+ * SHR_RASTER_OWNER_TOUCHED_ROWS: argmin is written only on the rows some sphere's pixel box touches; the
+ * owner bytes of the other rows (background whatever the depths, half of a hand crop) are left as they were.
+ * shr_sphere_raster_bwd never reads them -- it derives the same rows from the same records -- so the
+ * autograd pair that replaces mesh/render.py:26-53 + :89 saves a tenth of the forward's stores; a caller that
+ * wants the full owner map (the public `argmin` contract above) passes 0.  depth is always complete. */
+#define SHR_RASTER_OWNER_TOUCHED_ROWS 1
+int shr_sphere_raster_fwd_ex(const float *spheres, int N, int J, int H, int W,
+                             float *depth, uint8_t *argmin, int flags, void *stream);
 
 /* Analytic backward of the above (the reference gets it from autograd of
  * mesh/render.py:37-52 + torch.min): for upstream grad_depth[N,H,W],

@@ -39,11 +39,38 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+OBJ_DIR = os.path.join(PKG, "csrc", "build")     # per-file objects (git-ignored: `build/`)
+
+
+def _headers():
+    return glob.glob(os.path.join(PKG, "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + \
+        [os.path.abspath(__file__)]
+
+
+def _compile(src, force, verbose):
+    """One translation unit -> object (skipped when the object is newer than the source and every header)."""
+    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+    if not force and os.path.exists(obj):
+        t = os.path.getmtime(obj)
+        if all(os.path.getmtime(d) <= t for d in [src] + _headers()):
+            return obj
+    cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + \
+        ["-c", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "csrc"), "-o", obj, src]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return obj
+
+
 def build(force=False, verbose=False):
+    """Compile every csrc/*.hip for gfx950 (in parallel, one object per file) and link the shared library."""
     if not (force or stale()):
         return SO
-    cmd = [HIPCC] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "csrc"),
-                             "-o", SO] + sources()
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(lambda src: _compile(src, force, verbose), sources()))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -17,7 +17,6 @@ struct Tuning {
   int fwd_waves = 16;                   // waves per forward workgroup
   int fwd_shares = 0x24344464;          // work-list shares of the four wave age groups, oldest in the low byte (sum 256)
   int bwd_shares = 0x2c3a4654;
-  int lds_pad = 0;                      // experiments: extra dynamic LDS per zbuf workgroup (forces one workgroup per CU)
   int mse_box = -1;                     // fused kernel's box variant: -1 = by launch size, 0 = never, 1 = always, > 1 = with that much LDS
   int bwd_waves = 0;                    // waves per backward workgroup: 0 = by launch size, 8 or 16
   int fwd_zbuf_bytes = 0;               // forward z-buffer bytes per workgroup; 0 = by launch size (launch_zbuf_fwd_t)
@@ -100,19 +99,19 @@ int persistent_grid(int N, int regions, size_t lds, int nwaves) {
 
 template <bool OWNER, bool VEC4, bool POW2, bool PERSIST, bool BOX>
 int launch_zbuf_fwd_p(const float4 *sp, int N, int J, int H, int W, float *depth, uint8_t *argmin, int rows, size_t lds,
-                      int zcells, dim3 grid, hipStream_t s) {
+                      int zcells, dim3 grid, int flags, hipStream_t s) {
   static AttrDone attr_done;
   auto k = sphere_zbuf_fwd_kernel<OWNER, VEC4, POW2, PERSIST, BOX>;
   const hipError_t e = allow_big_lds(k, &attr_done);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k, grid, dim3(64 * g_tune.fwd_waves), lds, s, sp, N, J, H, W, depth, argmin, rows,
-                     log2_if_pow2(W / 4), g_tune.fwd_shares, zcells);
+                     log2_if_pow2(W / 4), g_tune.fwd_shares, zcells, flags);
   return (int)hipGetLastError();
 }
 
 template <bool OWNER, bool VEC4, bool POW2>
 int launch_zbuf_fwd_t(const float4 *sp, int N, int J, int H, int W, float *depth, uint8_t *argmin, int rows,
-                      hipStream_t s) {
+                      int flags, hipStream_t s) {
   // LDS per workgroup.  `full` holds any touched box of a region in one pass (pick_rows sized the regions for it).
   // With at least two workgroups per CU in the launch a workgroup gets HALF of the CU's LDS instead: two resident
   // workgroups overlap each other's prologue, scan conversion and stream-out (depth-only forward at 9216 crops:
@@ -132,23 +131,22 @@ int launch_zbuf_fwd_t(const float4 *sp, int N, int J, int H, int W, float *depth
   const bool box = lds < full;
   if (!box) lds = kHdrBytes + (size_t)rows * (W + kRowPad) * key;
   const int zcells = (int)((lds - kHdrBytes) / key);
-  if (lds + g_tune.lds_pad <= (size_t)kMaxLds) lds += g_tune.lds_pad;
   dim3 grid((unsigned)persistent_grid(N, regions, lds, g_tune.fwd_waves), (unsigned)regions);
   if (box)
     return (int)grid.x < N
-               ? launch_zbuf_fwd_p<OWNER, VEC4, POW2, true, true>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, s)
-               : launch_zbuf_fwd_p<OWNER, VEC4, POW2, false, true>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, s);
+               ? launch_zbuf_fwd_p<OWNER, VEC4, POW2, true, true>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, flags, s)
+               : launch_zbuf_fwd_p<OWNER, VEC4, POW2, false, true>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, flags, s);
   return (int)grid.x < N
-             ? launch_zbuf_fwd_p<OWNER, VEC4, POW2, true, false>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, s)
-             : launch_zbuf_fwd_p<OWNER, VEC4, POW2, false, false>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, s);
+             ? launch_zbuf_fwd_p<OWNER, VEC4, POW2, true, false>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, flags, s)
+             : launch_zbuf_fwd_p<OWNER, VEC4, POW2, false, false>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, flags, s);
 }
 
 template <bool OWNER, bool VEC4>
 int launch_zbuf_fwd(const float4 *sp, int N, int J, int H, int W, float *depth, uint8_t *argmin, int rows,
-                    hipStream_t s) {
+                    int flags, hipStream_t s) {
   return (is_pow2(W) && is_pow2(H))
-             ? launch_zbuf_fwd_t<OWNER, VEC4, true>(sp, N, J, H, W, depth, argmin, rows, s)
-             : launch_zbuf_fwd_t<OWNER, VEC4, false>(sp, N, J, H, W, depth, argmin, rows, s);
+             ? launch_zbuf_fwd_t<OWNER, VEC4, true>(sp, N, J, H, W, depth, argmin, rows, flags, s)
+             : launch_zbuf_fwd_t<OWNER, VEC4, false>(sp, N, J, H, W, depth, argmin, rows, flags, s);
 }
 
 template <bool VEC4, bool POW2, bool PERSIST, int NW, bool WHOLE>
@@ -208,7 +206,6 @@ extern "C" int shr_set_tuning(int key, int value) {
       if (value < 1 || value > 16) return SHR_EINVAL;
       g_tune.fwd_waves = value;
       return SHR_OK;
-    case 99: g_tune.lds_pad = value; return SHR_OK;
     case SHR_TUNE_MSE_BOX: if (value < -1) return SHR_EINVAL; g_tune.mse_box = value; return SHR_OK;
     case SHR_TUNE_BWD_WAVES: if (value != 0 && value != 8 && value != 16) return SHR_EINVAL; g_tune.bwd_waves = value; return SHR_OK;
     case SHR_TUNE_FWD_ZBUF_BYTES: if (value < 0) return SHR_EINVAL; g_tune.fwd_zbuf_bytes = value; return SHR_OK;
@@ -240,7 +237,13 @@ extern "C" int shr_set_tuning(int key, int value) {
 
 extern "C" int shr_sphere_raster_fwd(const float *spheres, int N, int J, int H, int W, float *depth,
                                      uint8_t *argmin, void *stream) {
+  return shr_sphere_raster_fwd_ex(spheres, N, J, H, W, depth, argmin, 0, stream);
+}
+
+extern "C" int shr_sphere_raster_fwd_ex(const float *spheres, int N, int J, int H, int W, float *depth,
+                                        uint8_t *argmin, int flags, void *stream) {
   if (N == 0) return SHR_OK;
+  if (flags & ~SHR_RASTER_OWNER_TOUCHED_ROWS) return SHR_EINVAL;
   if (!spheres || !depth || N < 0 || J <= 0 || H <= 0 || W <= 0) return SHR_EINVAL;
   if (J > SHR_MAX_SPHERES || (long long)H * W > (1LL << 30)) return SHR_ETOOLARGE;
   if (((uintptr_t)spheres & 15u) != 0) return SHR_EINVAL;
@@ -260,10 +263,10 @@ extern "C" int shr_sphere_raster_fwd(const float *spheres, int N, int J, int H, 
                        : pick_rows(H, row_bytes, argmin ? owner_cap : g_tune.fwd_lds_bytes,
                                    kHdrBytes + kPadRows * row_bytes);
   if (rows > 0 && (H + rows - 1) / rows <= 65535 && W <= kMaxFastWidth && H <= 32768) {
-    if (argmin) return vec4 ? launch_zbuf_fwd<true, true>(sp, N, J, H, W, depth, argmin, rows, s)
-                            : launch_zbuf_fwd<true, false>(sp, N, J, H, W, depth, argmin, rows, s);
-    return vec4 ? launch_zbuf_fwd<false, true>(sp, N, J, H, W, depth, argmin, rows, s)
-                : launch_zbuf_fwd<false, false>(sp, N, J, H, W, depth, argmin, rows, s);
+    if (argmin) return vec4 ? launch_zbuf_fwd<true, true>(sp, N, J, H, W, depth, argmin, rows, flags, s)
+                            : launch_zbuf_fwd<true, false>(sp, N, J, H, W, depth, argmin, rows, flags, s);
+    return vec4 ? launch_zbuf_fwd<false, true>(sp, N, J, H, W, depth, argmin, rows, 0, s)
+                : launch_zbuf_fwd<false, false>(sp, N, J, H, W, depth, argmin, rows, 0, s);
   }
 
   // general tile kernels: 4 waves per workgroup, one 32x8 tile per wave

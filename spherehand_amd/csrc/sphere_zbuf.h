@@ -497,7 +497,7 @@ template <bool OWNER, bool VEC4, bool POW2, bool PERSIST, bool BOX>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_,
                        float *__restrict__ depth, uint8_t *__restrict__ argmin, int rows_per_region_,
-                       int w4_shift_, int shares, int zcells_) {
+                       int w4_shift_, int shares, int zcells_, int flags) {
   using Key = typename KeyOf<OWNER>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
@@ -615,6 +615,10 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   // owner bytes go out 16 at a time when rows allow it (a wave-wide store of 4-byte pieces
   // occupies the write queue like a 16-byte one and carries a quarter of the data)
   const bool own16 = OWNER && (W & 15) == 0 && is_aligned16(argmin);
+  // SHR_RASTER_OWNER_TOUCHED_ROWS: the owner bytes of background ROWS stay unwritten -- the backward stages and walks
+  // the touched rows only (same touched_rows() on the same records), so a forward whose owner map is only ever handed
+  // to shr_sphere_raster_bwd saves a tenth of its stores (8 of a hand crop's 82 KB)
+  const bool bg_owner = OWNER && !(flags & SHR_RASTER_OWNER_TOUCHED_ROWS);
   auto store_background = [&](int first, int step) {
     const int nbg = ua + (nunits - ub);
     for (int t = first; t < nbg; t += step) {
@@ -622,10 +626,10 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
       const int c = (u << 6) + lane;
       if (c < nchunk) {
         stream_store(out4 + c, bgd);
-        if (OWNER && !own16) stream_store(aout4 + c, bga);
+        if (bg_owner && !own16) stream_store(aout4 + c, bga);
       }
     }
-    if (own16) {   // 16-pixel pieces: unit u = pieces [16u, 16u + 16)
+    if (bg_owner && own16) {   // 16-pixel pieces: unit u = pieces [16u, 16u + 16)
       const int npiece = nchunk >> 2, pa = ua << 4, pb = ub << 4;
       const int nbgp = min(pa, npiece) + max(npiece - pb, 0);
       const uint4 bg16 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);

@@ -49,8 +49,12 @@ def _check_input(t, name, dtype=torch.float32):
         raise RuntimeError("%s must be %s" % (name, dtype))
 
 
-def sphere_raster_fwd(spheres, H, W, want_argmin=False):
-    """spheres [N,J,4] (x,y,z,r) -> depth [N,H,W] (and uint8 argmin [N,H,W])."""
+RASTER_OWNER_TOUCHED_ROWS = 1   # shr_sphere_raster_fwd_ex flag (include/spherehand_hip.h)
+
+
+def sphere_raster_fwd(spheres, H, W, want_argmin=False, flags=0):
+    """spheres [N,J,4] (x,y,z,r) -> depth [N,H,W] (and uint8 argmin [N,H,W]).  flags = RASTER_OWNER_TOUCHED_ROWS:
+    the owner bytes of rows no sphere touches stay unwritten (all sphere_raster_bwd needs)."""
     _check_input(spheres, "spheres")
     if spheres.dim() != 3 or spheres.shape[2] != 4:
         raise RuntimeError("spheres must be [N,J,4]")
@@ -58,8 +62,8 @@ def sphere_raster_fwd(spheres, H, W, want_argmin=False):
     with _on(spheres.device):
         depth = torch.empty((N, H, W), dtype=torch.float32, device=spheres.device)
         arg = torch.empty((N, H, W), dtype=torch.uint8, device=spheres.device) if want_argmin else None
-        _lib.check(_lib.lib().shr_sphere_raster_fwd(_ptr(spheres), N, J, H, W, _ptr(depth), _ptr(arg),
-                                                    _stream()), "shr_sphere_raster_fwd")
+        _lib.check(_lib.lib().shr_sphere_raster_fwd_ex(_ptr(spheres), N, J, H, W, _ptr(depth), _ptr(arg), int(flags),
+                                                       _stream()), "shr_sphere_raster_fwd")
     return (depth, arg) if want_argmin else depth
 
 
@@ -96,13 +100,14 @@ def set_tuning(key, value):
 class SphereDepthRaster(torch.autograd.Function):
     """depth[N,H,W] = min over the J spheres of a crop (SURVEY 8b "new
     differentiable op").  Differentiable w.r.t. spheres[N,J,4] = (x,y,z,r).
-    The forward saves its uint8 owner map (1 byte/pixel) for the backward."""
+    The forward saves its uint8 owner map (1 byte/pixel) for the backward -- written on the rows the backward
+    will look at only (RASTER_OWNER_TOUCHED_ROWS: the map never leaves this Function)."""
 
     @staticmethod
     def forward(ctx, spheres, H, W):
         spheres = spheres.contiguous()
         if ctx.needs_input_grad[0]:
-            depth, owner = sphere_raster_fwd(spheres, H, W, want_argmin=True)
+            depth, owner = sphere_raster_fwd(spheres, H, W, want_argmin=True, flags=RASTER_OWNER_TOUCHED_ROWS)
             ctx.save_for_backward(spheres, owner)
         else:
             depth = sphere_raster_fwd(spheres, H, W)

@@ -23,6 +23,7 @@ def ops(request):
     from spherehand_amd import ops as o
     assert torch.cuda.is_available()
     o.set_tuning(o.TUNE_FORCE_GENERAL, 1 if request.param == "general" else 0)
+    o._shr_test_general = request.param == "general"
     small = request.param == "zbuf-small-lds"
     o.set_tuning(o.TUNE_FWD_LDS_BYTES, 16 * 1024 if small else 80 * 1024)
     o.set_tuning(o.TUNE_FWD_OWNER_LDS_BYTES, 24 * 1024 if small else 0)
@@ -34,6 +35,7 @@ def ops(request):
     # through the tile code)
     o.set_tuning(o.TUNE_MSE_BOX, {"zbuf-4-waves": 1, "zbuf-bands": 28 * 1024}.get(request.param, -1))
     yield o
+    o._shr_test_general = False
     o.set_tuning(o.TUNE_FWD_ZBUF_BYTES, 0)
     o.set_tuning(o.TUNE_MSE_BOX, -1)
     o.set_tuning(o.TUNE_BWD_WAVES, 0)
@@ -225,6 +227,54 @@ def test_launches_with_two_workgroups_per_cu(oracle):
     for k in range(3):
         assert np.abs(gs3[256 * k:256 * (k + 1)] - og).max() <= tol
     assert np.abs(gs1 - og).max() <= tol
+
+
+@pytest.mark.parametrize("S,reps", [(64, 1), (128, 1), (128, 3), (256, 1)])
+def test_owner_map_on_touched_rows_only(ops, oracle, S, reps):
+    """shr_sphere_raster_fwd_ex(SHR_RASTER_OWNER_TOUCHED_ROWS): what SphereDepthRaster saves for its backward.  The
+    owner buffer starts as GARBAGE (random bytes, valid sphere indices among them): depth is complete and bit-exact,
+    every row with a foreground pixel carries the oracle's owners, every other byte is either 255 or still the
+    garbage it was (rows no sphere touches are not written: 8 of a hand crop's 82 KB), and the backward returns,
+    bit for bit, what it returns with the complete owner map -- it never looks at the rows the forward skipped."""
+    from spherehand_amd import _lib
+    g = golden("g3_batch256.npz")
+    sp_h = np.concatenate([spheres_from(g["centres"], g["radii"])] * reps)
+    N = sp_h.shape[0]
+    sp = dev(sp_h)
+    rs = np.random.RandomState(S + reps)
+    garbage = rs.randint(0, 256, (N, S, S)).astype(np.uint8)
+    owner = dev(garbage)
+    depth = torch.empty(N, S, S, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().shr_sphere_raster_fwd_ex(sp.data_ptr(), N, 41, S, S, depth.data_ptr(), owner.data_ptr(),
+                                                   ops.RASTER_OWNER_TOUCHED_ROWS, st), "fwd_ex")
+    od, oa = oracle.sphere_raster_fwd(sp_h, S, S)
+    assert np.array_equal(bits(depth.cpu().numpy()), bits(od))
+    a = owner.cpu().numpy()
+    fg_row = (oa != 255).any(axis=2)                                    # [N, S]
+    assert np.array_equal(a[fg_row], oa[fg_row])
+    rest = ~fg_row
+    assert np.all((a[rest] == 255) | (a[rest] == garbage[rest]))
+    # on the z-buffer kernels the skipped rows really are skipped (the general tile kernels write every byte)
+    kept = float((a[rest] == garbage[rest]).mean())
+    d_full, a_full = ops.sphere_raster_fwd(sp, S, S, want_argmin=True)
+    assert np.array_equal(a_full.cpu().numpy(), oa)
+    gd = dev(rs.standard_normal((N, S, S)).astype(np.float32))
+    g_part = ops.sphere_raster_bwd(sp, gd, owner).cpu().numpy()
+    g_full = ops.sphere_raster_bwd(sp, gd, a_full).cpu().numpy()
+    assert np.array_equal(bits(g_part), bits(g_full))
+    if not _forced_general(ops):
+        assert kept > 0.5, kept
+    # and through the autograd Function (which passes the flag)
+    spg = sp.clone().requires_grad_(True)
+    (ops.SphereDepthRaster.apply(spg, S, S) * gd).sum().backward()
+    assert np.array_equal(bits(spg.grad.cpu().numpy()), bits(g_full))
+
+
+def _forced_general(ops):
+    """True under the `general` parametrisation of the ops fixture (probed: a depth-only launch that the tile kernels
+    serve writes the same bits either way, so the fixture's own state is read back through a tuning round trip)."""
+    return getattr(ops, "_shr_test_general", False)
 
 
 def test_nan_inf(ops, oracle):
