@@ -26,7 +26,7 @@ import torch.utils.data as data
 
 from .criterion import HeatmapEstimationNetwork, MultiTaskLoss, average_joint_error, combine_loss, stack_terms
 from .hand_model import load_mesh
-from .joint_angle import JointAngleDataset
+from .joint_angle import JointAngleDataset, sample_poses_batched
 from .pose_denoiser import default_pose_denoiser
 from .pose_vae import default_pose_vae
 from .util_modules import DepthResample, HandSynthesizer
@@ -139,7 +139,7 @@ def _unwrap(m):
 
 class Engine:
     """opts: the reference's argparse namespace (network/run_engine.py:10-31) plus the
-    optional attributes image_size, log_every, real_batch, synt_batch, steps_per_epoch.
+    optional attributes image_size, log_every, real_batch, synt_batch, steps_per_epoch, num_workers.
     Datasets default to the NYU shards under opts.dataset_dir/{train,test}; any
     Dataset yielding (dms [V,S,S] mm, gt_joints [V,36,3], cam [V,4,4], inv_cam [V,4,4])
     can be passed instead."""
@@ -185,6 +185,7 @@ class Engine:
         self.real_batch = getattr(opts, 'real_batch', 25)
         self.synt_batch = getattr(opts, 'synt_batch', 48)
         self.steps_per_epoch = getattr(opts, 'steps_per_epoch', None)
+        self.num_workers = int(getattr(opts, 'num_workers', 0) or 0)
         # network/engine.py:100: Adam(lr, weight_decay=1e-5); on the GPU the single-kernel (fused) implementation
         on_gpu = self.env.device.type == 'cuda'
         self.optimizer = torch.optim.Adam(self.network.parameters(), lr=opts.lr, weight_decay=1e-5,
@@ -242,17 +243,18 @@ class Engine:
         if self.env.world > 1:
             sampler = data.distributed.DistributedSampler(dataset, self.env.world, self.env.rank, shuffle=shuffle)
             shuffle = False
-        return data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, sampler=sampler, num_workers=0,
-                               drop_last=train)
+        # (the reference: num_workers=2, network/engine.py:158-159, :326-327; opts.num_workers, default 0: the shards are
+        # memory-mapped and a batch is a slice copy, cheaper than a worker hand-over at these batch sizes)
+        return data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, sampler=sampler,
+                               num_workers=self.num_workers, persistent_workers=self.num_workers > 0, drop_last=train)
 
     def _pose_iter(self, batch_size):
+        """Pose batches of the synthetic branch (the reference: a DataLoader over JointAngleDataset, shuffle=True,
+        one worker, network/engine.py:328-329): one vectorised draw per step from a per-rank generator -- the same
+        distribution as JointAngleDataset[i], without its ~55 torch.rand(1) calls per pose on the step's host path."""
         g = torch.Generator().manual_seed(1234 + self.env.rank)
         while True:
-            state = torch.get_rng_state()
-            torch.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=g)))
-            batch = torch.stack([self.synt_dataset[0] for _ in range(batch_size)])
-            torch.set_rng_state(state)
-            yield batch
+            yield sample_poses_batched(batch_size, generator=g)
 
     def _prepare_real(self, batch):
         dev, c = self.env.device, self.constant

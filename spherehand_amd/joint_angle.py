@@ -135,3 +135,68 @@ def sample_poses(n, seed=None):
     if seed is not None:
         torch.manual_seed(seed)
     return torch.stack([sample_pose() for _ in range(n)])
+
+
+# --------------------------------------------------------------------------- vectorised sampler
+_DEG = pi / 180
+# generator kinds per (sample, finger): 0 straight, 1 open, 2 half-open, 3 pinching, 4 closed (= _ANY's order)
+_TABLE_KINDS = {"O": (0, 1, 2), "C": (3, 4), "A": (0, 1, 2, 3, 4)}
+_PATTERN_TABLES = {5: "OCCC", 6: "CCCO", 7: "OOCC", 8: "COOO", 9: "AAAA"}
+
+
+def sample_poses_batched(n, generator=None):
+    """[n,26] poses from the SAME distribution as n calls of sample_pose() (dataset/joint_angle.py:7-236), drawn
+    with a handful of [n, .] tensor operations instead of ~55 torch.rand(1) calls per pose (48 poses: 7 ms of host
+    time per training step against 0.15 ms).  The draw SEQUENCE differs from sample_pose's -- as it does between the
+    reference's own DataLoader workers (network/engine.py:328-329: shuffle=True, num_workers=1); the pinned sequence
+    (tests/golden/g3_batch256.npz) stays with sample_pose / sample_poses.  tests/test_network_cpu.py compares the
+    two samplers' moments, ranges and per-finger generator frequencies."""
+    def u(*shape):
+        return torch.rand(*shape, generator=generator)
+    p = torch.zeros(n, NUM_PARAMETER)
+    # palm (:22-29)
+    p[:, 0] = u(n) * 6.28 - 3.14
+    p[:, 1] = -u(n) * 3.14
+    p[:, 2] = u(n) * 6.28 - 3.14
+    p[:, 3] = u(n) * 30 - 15
+    p[:, 4] = u(n) * 30 - 15
+    p[:, 5] = u(n) * 50 - 35
+    # finger spread (:32-40)
+    spread = ((u(n) - 0.35) / 1.55).unsqueeze(1)
+    wiggle = (u(n, 4) * 10 - 5) * _DEG
+    p[:, [6, 10, 14, 18]] = torch.tensor([1.55, 0.75, -0.75, -2.2]) * (spread + wiggle)
+    # thumb (:118-129)
+    flex = torch.where(u(n) < 0.5, u(n) * 0.35 - 0.25, u(n) * 0.6 + 0.1)
+    p[:, 22] = u(n) - 0.5
+    p[:, 23] = flex
+    p[:, 24] = 0.25 * flex
+    p[:, 25] = u(n) * 2 - 1.7
+    # which generator each of the four fingers uses (:160-214): modes 0-4 = one generator for all four,
+    # modes 5-9 = a uniform pick from the pattern's table per finger
+    mode = (u(n) * 10).long().clamp_(max=9)
+    pick = u(n, 4)
+    kind = mode.unsqueeze(1).expand(n, 4).clone()
+    for m, tables in _PATTERN_TABLES.items():
+        rows = mode == m
+        if bool(rows.any()):
+            for k, t in enumerate(tables):
+                opts = torch.tensor(_TABLE_KINDS[t])
+                kind[rows, k] = opts[(pick[rows, k] * len(opts)).long().clamp_(max=len(opts) - 1)]
+    # the five generators, evaluated for every (sample, finger) and selected
+    scale = torch.tensor([0.25, 0.4, 0.34])
+    straight = u(n, 4, 3) * scale - scale                                    # :112-116
+    opened = u(n, 4, 3) * scale - 0.1                                        # :106-110
+
+    def curl(first_lo, first_span, rest_lo, rest_span):                     # :42-104
+        jit = (u(n, 4, 3) * 20 - 10) * _DEG
+        c1 = (u(n, 4) * first_span + first_lo) * _DEG + jit[..., 0]
+        c2 = (u(n, 4) * rest_span + rest_lo) * _DEG + jit[..., 1]
+        c3 = (u(n, 4) * rest_span + rest_lo) * _DEG + jit[..., 2]
+        f1, f2, f3 = _REST_CURL
+        return torch.stack([f1 + c1 + 0.2 * c2, f2 + 0.2 * c1 + c2 + 0.2 * c3, f3 + 0.7 * c2 + c3], -1)
+    variants = torch.stack([straight, opened, curl(0, 30, 60, 30), curl(60, 30, 5, 30), curl(60, 30, 60, 30)], 2)
+    flexes = torch.gather(variants, 2, kind.view(n, 4, 1, 1).expand(n, 4, 1, 3)).squeeze(2)      # [n,4,3]
+    for k, name in enumerate(("index", "middle", "ring", "pinky")):
+        b = FINGER_BASE[name]
+        p[:, b + 1:b + 4] = flexes[:, k]
+    return p

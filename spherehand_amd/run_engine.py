@@ -31,6 +31,8 @@ def build_parser():
                    help='use N sphere-rendered multiview samples in place of the NYU shards')
     p.add_argument('--steps_per_epoch', default=None, type=int)
     p.add_argument('--log_every', default=100, type=int)
+    p.add_argument('--num_workers', default=0, type=int,
+                   help='DataLoader workers for the real shards (the reference: 2, network/engine.py:158-159)')
     p.add_argument('--deterministic', default=False, action='store_true',
                    help='deterministic MIOpen solvers (run-to-run reproducible hourglass gradients)')
     p.add_argument('--miopen_find', default=False, action='store_true',

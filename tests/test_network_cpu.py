@@ -150,3 +150,35 @@ def test_resize_crop_batched_equals_per_image_loop():
     dms = torch.rand(75, 64, 64, generator=g)
     u, v = scale + torch.rand(75, generator=g) * 0.1 - 0.05, scale + torch.rand(75, generator=g) * 0.1 - 0.05
     assert torch.equal(m(dms, u, v), m.forward_loop(dms, u, v))
+
+
+def test_batched_pose_sampler_has_the_sequential_samplers_distribution():
+    """spherehand_amd.joint_angle.sample_poses_batched (what Engine._pose_iter draws per step) against n calls of
+    sample_pose (the draw-for-draw port of dataset/joint_angle.py:7-236, pinned by g3): per-parameter means within
+    5 standard errors, standard deviations within 6 %, the 5/25/50/75/95 % quantiles within 8 % of the parameter's
+    spread (the flex angles are mixtures of five generators: a wrong table or weight moves the quantiles), and the
+    support inside the sequential sampler's analytic bounds."""
+    from spherehand_amd.joint_angle import sample_poses, sample_poses_batched
+    n = 3000
+    a = sample_poses(n, seed=11).double()
+    b = sample_poses_batched(20000, generator=torch.Generator().manual_seed(5)).double()
+    assert b.shape == (20000, 26) and b.dtype == torch.float64 and torch.isfinite(b).all()
+    se = (a.var(0) / n + b.var(0) / 20000).sqrt()
+    assert ((a.mean(0) - b.mean(0)).abs() <= 5 * se + 1e-9).all(), (a.mean(0) - b.mean(0)) / se
+    assert ((a.std(0) / b.std(0) - 1).abs() <= 0.06).all(), a.std(0) / b.std(0)
+    q = torch.tensor([0.05, 0.25, 0.5, 0.75, 0.95], dtype=torch.float64)
+    spread = a.quantile(0.99, 0) - a.quantile(0.01, 0)
+    dq = (a.quantile(q, 0) - b.quantile(q, 0)).abs() / spread
+    assert (dq <= 0.08).all(), dq.max()
+    # palm ranges (joint_angle.py:22-29), thumb (:118-129)
+    lo = torch.tensor([-3.14, -3.14, -3.14, -15, -15, -35], dtype=torch.float64)
+    hi = torch.tensor([3.14, 0, 3.14, 15, 15, 15], dtype=torch.float64)
+    assert (b[:, :6] >= lo - 1e-6).all() and (b[:, :6] <= hi + 1e-6).all()
+    assert (b[:, 22].abs() <= 0.5).all() and (b[:, 23] >= -0.25 - 1e-6).all() and (b[:, 23] <= 0.7 + 1e-6).all()
+    assert torch.allclose(b[:, 24], 0.25 * b[:, 23]) and (b[:, 25] >= -1.7 - 1e-6).all() and (b[:, 25] <= 0.3 + 1e-6).all()
+    # every finger sees every generator family: straight/open flexes are <= 0.25, curled ones reach > 1 rad
+    for base in (6, 10, 14, 18):
+        assert (b[:, base + 1] < 0).float().mean() > 0.1 and (b[:, base + 1] > 0.9).float().mean() > 0.1
+    # same generator, same draws
+    g1, g2 = torch.Generator().manual_seed(3), torch.Generator().manual_seed(3)
+    assert torch.equal(sample_poses_batched(48, g1), sample_poses_batched(48, g2))
