@@ -40,6 +40,27 @@ __host__ __device__ inline Axis make_axis(int size) {
   return a;
 }
 
+// The same with 300 / size supplied by the launcher: the zbuf kernels take the two IEEE divisions of an image's axes
+// (and the two of size / 300, the pixels per millimetre of the boxes) as launch constants -- sixteen waves per crop
+// each spent ~45 VALU instructions on them (7 % of a crop's VALU work once the SIMDs are the contended resource).
+struct AxisK { float mulx, muly, kx, ky; };   // 300 / W, 300 / H, W / 300, H / 300: fp32 divisions, host == device (IEEE)
+inline AxisK make_axis_k(int W, int H) {
+  AxisK k;
+  k.mulx = 300.0f / (float)W;
+  k.muly = 300.0f / (float)H;
+  k.kx = (float)W / 300.0f;
+  k.ky = (float)H / 300.0f;
+  return k;
+}
+__device__ __forceinline__ Axis axis_of(int size, float mul) {
+  Axis a;
+  a.size = (float)size;
+  a.half = a.size * 0.5f;   // exact (size < 2^24), == (float)((double)size / 2)
+  a.mul = mul;
+  a.pow2 = (size & (size - 1)) == 0;
+  return a;
+}
+
 __device__ __forceinline__ float axis_coord(const Axis &a, int u) {
   const float t = (float)u - a.half;
   if (a.pow2) return t * a.mul;
@@ -131,16 +152,24 @@ __device__ __forceinline__ float wave_min4_transposed(float a0, float a1, float 
 }
 
 // Correctly rounded fp32 square root for x in [0.01, 1e12] (sphere_zbuf.h documents the range and the
-// exhaustive test): v_sqrt_f32 (<= 1 ulp) corrected by the exact residuals of its two neighbours.
+// exhaustive test).  s = v_sqrt_f32(x) is within one ulp u of the root, so the result is s - u, s or s + u, and
+// which one is read off ONE residual r = fma(-s, s, x) (exact whenever it matters: |x - s^2| < 2^24 granules of
+// s^2's last place there):  sqrt(x) > s + u/2  <=>  x - s^2 > s u (+ u^2/4, below a granule)  <=>  r > t,
+// sqrt(x) < s - u/2  <=>  r <= -t,  with t = s * u formed on the bit pattern (exponent field of s added to itself).
+// Eight VALU instructions where the two-neighbour form (two increments, two residuals, two selects) takes nine;
+// the carry forms of the integer add / subtract take the comparison's result directly.
 __device__ __forceinline__ float sqrt_rn(float x) {
   const float s = __builtin_amdgcn_sqrtf(x);
-  const float dn = __uint_as_float(__float_as_uint(s) - 1u);
-  const float up = __uint_as_float(__float_as_uint(s) + 1u);
-  const float e_dn = __builtin_fmaf(-dn, s, x);
-  const float e_up = __builtin_fmaf(-up, s, x);
-  float r = (e_dn <= 0.0f) ? dn : s;
-  r = (e_up > 0.0f) ? up : r;
-  return r;
+  const float r = __builtin_fmaf(-s, s, x);
+  const uint32_t sb = __float_as_uint(s);
+  const float t = __uint_as_float(sb + (sb & 0x7f800000u) - 0x4B000000u);   // s * 2^(E - 23), E = s's exponent
+  uint32_t out;
+  // (s_nop 1: a VALU write of vcc needs two wait states before a VALU reads it as a carry / mask on gfx950, and
+  // the hazard recognizer does not look inside an asm statement)
+  asm("v_cmp_gt_f32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, 0, %3, vcc\n\t"
+      "v_cmp_le_f32 vcc, %1, -%2\n\ts_nop 1\n\tv_subbrev_co_u32 %0, vcc, 0, %0, vcc"
+      : "=&v"(out) : "v"(r), "v"(t), "v"(sb) : "vcc");
+  return __uint_as_float(out);
 }
 
 int d2m_set_waves(int waves);        // data_to_model.hip: launch-shape hooks behind SHR_TUNE_D2M_WAVES /

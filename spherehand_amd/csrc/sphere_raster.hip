@@ -105,7 +105,7 @@ int launch_zbuf_fwd_p(const float4 *sp, int N, int J, int H, int W, float *depth
   const hipError_t e = allow_big_lds(k, &attr_done);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k, grid, dim3(64 * g_tune.fwd_waves), lds, s, sp, N, J, H, W, depth, argmin, rows,
-                     log2_if_pow2(W / 4), g_tune.fwd_shares, zcells, flags);
+                     (log2_if_pow2(W / 4) & 0xff) | (flags << 8), g_tune.fwd_shares, zcells, make_axis_k(W, H));
   return (int)hipGetLastError();
 }
 
@@ -157,7 +157,7 @@ int launch_zbuf_bwd_p(const float4 *sp, const float *grad, const uint8_t *argmin
   const hipError_t e = allow_big_lds(k, &attr_done);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k, dim3((unsigned)gridx), dim3(64 * NW), lds, s, sp, grad, argmin, N, J, H, W, gs, rows,
-                     log2_if_pow2(W / 4), g_tune.bwd_shares);
+                     log2_if_pow2(W / 4), g_tune.bwd_shares, make_axis_k(W, H));
   return (int)hipGetLastError();
 }
 
@@ -368,21 +368,21 @@ extern "C" int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, 
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(1024), blds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
                        target_index, depth, sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), rows,
-                       log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, zcells);
+                       log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, zcells, make_axis_k(W, H));
   } else if (is_pow2(W) && is_pow2(H)) {
     auto k = sphere_zbuf_mse_kernel<true, false>;
     const hipError_t e = allow_big_lds(k, &attr_a);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
                        target_index, depth, sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), rows,
-                       log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares);
+                       log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, make_axis_k(W, H));
   } else {
     auto k = sphere_zbuf_mse_kernel<false, false>;
     const hipError_t e = allow_big_lds(k, &attr_b);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
                        target_index, depth, sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), rows,
-                       log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares);
+                       log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, make_axis_k(W, H));
   }
   return (int)hipGetLastError();
 }

@@ -163,9 +163,6 @@ __device__ __forceinline__ float rfl(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-// The axes' 300 / size are IEEE divisions the compiler sinks to their first use -- behind the first barrier, where all
-// sixteen waves evaluate them on the critical path.  pin_axes() fixes the place: after the first requests are out.
-__device__ __forceinline__ void pin_axes(Axis &ax, Axis &ay) { asm volatile("" : "+v"(ax.mul), "+v"(ay.mul)); }
 
 // The work list is the sequence of chunks, sphere after sphere, on a weight axis where a
 // chunk is 2^kChunkShift long and starting a sphere (broadcasts, lane layout, column terms)
@@ -497,7 +494,7 @@ template <bool OWNER, bool VEC4, bool POW2, bool PERSIST, bool BOX>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_,
                        float *__restrict__ depth, uint8_t *__restrict__ argmin, int rows_per_region_,
-                       int w4_shift_, int shares, int zcells_, int flags) {
+                       int w4_shift_flags, int shares, int zcells_, AxisK axk) {
   using Key = typename KeyOf<OWNER>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
@@ -517,7 +514,10 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   // Every crop starts from OPAQUE copies of the launch constants and of the thread index: otherwise the compiler
   // hoists each crop-invariant value out of the crop loop and keeps it in a register (forward: 92 instead of 51
   // VGPRs; the fused kernel spilled).
-  int J = J_, H = H_, W = W_, rows_per_region = rows_per_region_, w4_shift = w4_shift_, tid = threadIdx.x;
+  // (w4_shift_flags: log2(W / 4) or -1 in the low byte (signed), the SHR_RASTER_* flags above it -- one SGPR less
+  // in a kernel whose box variant sits at the occupancy limit of 80)
+  int J = J_, H = H_, W = W_, rows_per_region = rows_per_region_, w4_shift = (int)(signed char)(w4_shift_flags & 0xff), tid = threadIdx.x;
+  const int flags = w4_shift_flags >> 8;
   int zcells = zcells_;
   if (PERSIST) {
     asm volatile("" : "+s"(J), "+s"(H), "+s"(W), "+s"(rows_per_region), "+s"(w4_shift), "+s"(zcells));
@@ -528,8 +528,10 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   const int r0 = blockIdx.y * rows_per_region;
   const int r1 = min(H, r0 + rows_per_region);
   const int rh = r1 - r0;
-  Axis ax = make_axis(W), ay = make_axis(H);
-  const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
+  Axis ax = axis_of(W, axk.mulx), ay = axis_of(H, axk.muly);
+  const float kx = axk.kx, ky = axk.ky;   // pixels per millimetre (launch constants: common.h AxisK)
+  // (the box variant sits at gfx950's occupancy limit of 80 SGPRs: its axis constants live in vector registers)
+  if (BOX) asm volatile("" : "+v"(ax.mul), "+v"(ay.mul), "+v"(ax.half), "+v"(ay.half));
 
   // the waves that need the crop's records before the first barrier (wave 0: work list; the
   // background waves: touched box) read them from memory, lane j = sphere j; the others take
@@ -558,7 +560,6 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   };
   // (the box is not known yet: every cell a one-pass box of this region can use; overlaps the read above)
   init_zbuf(BOX ? min(zcells, rh * max_box_pitch(W)) : rh * (W + kRowPad));
-  pin_axes(ax, ay);
 
   // Waves 1..kBgWaves store the background rows while wave 0 builds the list: they are the
   // first to finish the z-buffer initialisation (the SIMD arbitration favours old waves) and
@@ -706,10 +707,14 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
             const float dya = yga - s.y, dyb = ygb - s.y;
             float qa = ca - dya * dya, qb = ca - dyb * dyb;
             if (decltype(row_test)::value) { qa = ok_a ? qa : -1.f; qb = ok_b ? qb : -1.f; }
+            // (the owner index as an opaque vector value: the compiler then keeps it in the low register of the
+            // 64-bit pair across the run instead of re-materialising it from the scalar in front of every atomic)
+            unsigned jv = (unsigned)j;
+            if (OWNER) asm("" : "+v"(jv));
             auto put = [&](Key *cell, float d) {
               if (OWNER)
                 atomicMin(reinterpret_cast<unsigned long long *>(cell),
-                          ((unsigned long long)depth_key(d) << 32) | (unsigned)j);
+                          ((unsigned long long)depth_key(d) << 32) | jv);
               else
                 atomicMin(reinterpret_cast<unsigned int *>(cell), depth_key(d));
             };
@@ -813,7 +818,7 @@ template <bool VEC4, bool POW2, bool PERSIST, int NW, bool WHOLE>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_num_vgpr(kBwdVgprs)))
 sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restrict__ grad_depth,
                        const uint8_t *__restrict__ argmin, int N, int J_, int H_, int W_,
-                       float4 *__restrict__ grad_spheres, int rows_, int w4_shift_, int shares) {
+                       float4 *__restrict__ grad_spheres, int rows_, int w4_shift_, int shares, AxisK axk) {
   static_assert(NW == 8 || NW == 16, "waves per workgroup");
   constexpr int NT = 64 * NW, NW_SHIFT = NW == 16 ? 4 : 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -839,8 +844,8 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   const int LW = W + kRowPad;
   float *gbuf = reinterpret_cast<float *>(smem + kHdrBytes + kPartBytes);
   uint8_t *obuf = smem + kHdrBytes + kPartBytes + (size_t)(rows + kPadRows) * LW * 4;
-  Axis ax = make_axis(W), ay = make_axis(H);
-  const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
+  const Axis ax = axis_of(W, axk.mulx), ay = axis_of(H, axk.muly);
+  const float kx = axk.kx, ky = axk.ky;   // pixels per millimetre (launch constants: common.h AxisK)
   typedef float v4f __attribute__((ext_vector_type(4)));
   const int wave_s = rfl(wave);
   // The four OLDEST waves (one per SIMD: the arbitration serves them first, their requests head the memory
@@ -896,7 +901,6 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   }
   // owner padding = "nobody": the walk may overhang the image edge
   for (int i = tid; i < rows * kRowPad; i += NT) obuf[(i / kRowPad) * LW + W + (i % kRowPad)] = SHR_ARGMIN_NONE;
-  pin_axes(ax, ay);
   if (lead) {
     if (!have_sph) {
       float4 t;
@@ -1143,7 +1147,7 @@ __device__ __forceinline__ void
 sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_, const float *__restrict__ target,
                      const int *__restrict__ target_index, float *__restrict__ depth,
                      float *__restrict__ sse_out, float4 *__restrict__ grad_out, int rows_per_region_,
-                     int w4_shift_, int shares_fwd, int shares_bwd, int zcells_) {
+                     int w4_shift_, int shares_fwd, int shares_bwd, int zcells_, AxisK axk) {
   using Key = unsigned long long;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
@@ -1173,8 +1177,9 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   const int r1 = min(H, r0 + rows_per_region);
   const int rh = r1 - r0;
   const int LW = W + kRowPad;
-  Axis ax = make_axis(W), ay = make_axis(H);
-  const float kx = rfl(ax.size / 300.0f), ky = rfl(ay.size / 300.0f);   // pixels per millimetre, before any load is awaited
+  Axis ax = axis_of(W, axk.mulx), ay = axis_of(H, axk.muly);
+  const float kx = axk.kx, ky = axk.ky;   // pixels per millimetre (launch constants: common.h AxisK)
+  if (BOX) asm volatile("" : "+v"(ax.mul), "+v"(ay.mul), "+v"(ax.half), "+v"(ay.half));   // (SGPR budget, see the forward)
   const int wave_s = rfl(wave);
   const bool bg_wave = wave_s >= 1 && wave_s <= kBgWaves;
   const bool valid = lane < J;
@@ -1194,7 +1199,6 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
     for (int i = tid; i < nvec; i += 1024) reinterpret_cast<ulonglong2 *>(zbuf)[i] = v;
     if (tid == 0 && (ninit & 1)) zbuf[ninit - 1] = bg;
   }
-  pin_axes(ax, ay);
 
   const int w4 = W >> 2;
   const int nchunk = rh * w4;
@@ -1286,7 +1290,9 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
           const float dya = yga - s.y, dyb = ygb - s.y;
           float qa = ca - dya * dya, qb = ca - dyb * dyb;
           if (decltype(row_test)::value) { qa = ok_a ? qa : -1.f; qb = ok_b ? qb : -1.f; }
-          auto put = [&](Key *cell, float d) { atomicMin(cell, ((Key)depth_key(d) << 32) | (unsigned)j); };
+          unsigned jv = (unsigned)j;
+          asm("" : "+v"(jv));   // (kept in the low register of the 64-bit pair across the run, see the forward)
+          auto put = [&](Key *cell, float d) { atomicMin(cell, ((Key)depth_key(d) << 32) | jv); };
           if (has_b) {
             const bool ha = qa > kHitMin, hb = qb > kHitMin;
             const float da = s.z - sqrt_rn(qa), db = s.z - sqrt_rn(qb);
@@ -1478,9 +1484,10 @@ template <bool POW2, bool PERSIST>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J, int H, int W, const float *__restrict__ target,
                        const int *__restrict__ target_index, float *__restrict__ depth, float *__restrict__ sse_out,
-                       float4 *__restrict__ grad_out, int rows_per_region, int w4_shift, int shares_fwd, int shares_bwd) {
+                       float4 *__restrict__ grad_out, int rows_per_region, int w4_shift, int shares_fwd, int shares_bwd,
+                       AxisK axk) {
   sphere_zbuf_mse_body<POW2, PERSIST, false>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
-                                             rows_per_region, w4_shift, shares_fwd, shares_bwd, 0);
+                                             rows_per_region, w4_shift, shares_fwd, shares_bwd, 0, axk);
 }
 
 // two of these per CU: eight waves per SIMD, i.e. at most 64 VGPRs -- and few enough SGPRs: left alone the kernel takes
@@ -1491,10 +1498,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)
 sphere_zbuf_mse_box_kernel(const float4 *__restrict__ spheres, int N, int J, int H, int W, const float *__restrict__ target,
                            const int *__restrict__ target_index, float *__restrict__ depth, float *__restrict__ sse_out,
                            float4 *__restrict__ grad_out, int rows_per_region, int w4_shift, int shares_fwd, int shares_bwd,
-                           int zcells) {
+                           int zcells, AxisK axk) {
   static_assert(POW2, "box variant: power-of-two images");
   sphere_zbuf_mse_body<POW2, false, true>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
-                                          rows_per_region, w4_shift, shares_fwd, shares_bwd, zcells);
+                                          rows_per_region, w4_shift, shares_fwd, shares_bwd, zcells, axk);
 }
 
 }  // namespace shr
