@@ -105,7 +105,8 @@ int launch_zbuf_fwd_p(const float4 *sp, int N, int J, int H, int W, float *depth
   const hipError_t e = allow_big_lds(k, &attr_done);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k, grid, dim3(64 * g_tune.fwd_waves), lds, s, sp, N, J, H, W, depth, argmin, rows,
-                     (log2_if_pow2(W / 4) & 0xff) | (flags << 8), g_tune.fwd_shares, zcells, make_axis_k(W, H));
+                     (log2_if_pow2(W / 4) & 0xff) | (flags << 8) | (g_tune.fwd_waves << 16), g_tune.fwd_shares, zcells,
+                     make_axis_k(W, H));
   return (int)hipGetLastError();
 }
 
@@ -367,22 +368,22 @@ extern "C" int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, 
     const hipError_t e = allow_big_lds(k, &attr_c);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(1024), blds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
-                       target_index, depth, sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), rows,
-                       log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, zcells, make_axis_k(W, H));
+                       target_index, rows, log2_if_pow2(W / 4), zcells, g_tune.fwd_shares, g_tune.bwd_shares, depth,
+                       sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H));
   } else if (is_pow2(W) && is_pow2(H)) {
     auto k = sphere_zbuf_mse_kernel<true, false>;
     const hipError_t e = allow_big_lds(k, &attr_a);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
-                       target_index, depth, sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), rows,
-                       log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, make_axis_k(W, H));
+                       target_index, rows, log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, depth, sse_partial,
+                       reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H));
   } else {
     auto k = sphere_zbuf_mse_kernel<false, false>;
     const hipError_t e = allow_big_lds(k, &attr_b);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
-                       target_index, depth, sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), rows,
-                       log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, make_axis_k(W, H));
+                       target_index, rows, log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, depth, sse_partial,
+                       reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H));
   }
   return (int)hipGetLastError();
 }

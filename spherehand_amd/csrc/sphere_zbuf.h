@@ -514,24 +514,24 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   // Every crop starts from OPAQUE copies of the launch constants and of the thread index: otherwise the compiler
   // hoists each crop-invariant value out of the crop loop and keeps it in a register (forward: 92 instead of 51
   // VGPRs; the fused kernel spilled).
-  // (w4_shift_flags: log2(W / 4) or -1 in the low byte (signed), the SHR_RASTER_* flags above it -- one SGPR less
-  // in a kernel whose box variant sits at the occupancy limit of 80)
+  // (w4_shift_flags: log2(W / 4) or -1 in the low byte (signed), the SHR_RASTER_* flags in the second, the waves per
+  // workgroup in the third -- one SGPR less in a kernel whose box variant sits at the occupancy limit of 80)
   int J = J_, H = H_, W = W_, rows_per_region = rows_per_region_, w4_shift = (int)(signed char)(w4_shift_flags & 0xff), tid = threadIdx.x;
-  const int flags = w4_shift_flags >> 8;
+  const int flags = (w4_shift_flags >> 8) & 0xff;
   int zcells = zcells_;
   if (PERSIST) {
     asm volatile("" : "+s"(J), "+s"(H), "+s"(W), "+s"(rows_per_region), "+s"(w4_shift), "+s"(zcells));
     asm volatile("" : "+v"(tid));
   }
   const int lane = tid & 63, wave = tid >> 6;
-  const int nthr = blockDim.x, nwaves = nthr >> 6;
+  // (the workgroup size rides in the same launch argument: blockDim.x is a hidden kernel argument that is NOT among
+  // the preloaded ones -- reading it put an s_load round trip in front of the records' request)
+  const int nwaves = (w4_shift_flags >> 16) & 0xff, nthr = nwaves << 6;
   const int r0 = blockIdx.y * rows_per_region;
   const int r1 = min(H, r0 + rows_per_region);
   const int rh = r1 - r0;
   Axis ax = axis_of(W, axk.mulx), ay = axis_of(H, axk.muly);
   const float kx = axk.kx, ky = axk.ky;   // pixels per millimetre (launch constants: common.h AxisK)
-  // (the box variant sits at gfx950's occupancy limit of 80 SGPRs: its axis constants live in vector registers)
-  if (BOX) asm volatile("" : "+v"(ax.mul), "+v"(ay.mul), "+v"(ax.half), "+v"(ay.half));
 
   // the waves that need the crop's records before the first barrier (wave 0: work list; the
   // background waves: touched box) read them from memory, lane j = sphere j; the others take
@@ -544,22 +544,45 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   const bool pf_wave = wave_s == nwaves - 1 && !list_wave && !bg_wave;
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
   if (valid && (list_wave || bg_wave)) sph = crop_it == 0 ? spheres[(size_t)n * J + lane] : s_next[lane];
+  // (the box variant sits at gfx950's occupancy limit of 80 SGPRs: its axis constants live in vector registers;
+  // they are not among the preloaded arguments -- touched here, behind the records' request, not in front of it)
+  if (BOX) asm volatile("" : "+v"(ax.mul), "+v"(ay.mul), "+v"(ax.half), "+v"(ay.half));
 
   const Key bg = OWNER ? (Key)background_cell() : (Key)depth_key(kBackground);
-  auto init_zbuf = [&](int ncell) {   // background everywhere
+  // The z-buffer is initialised by the waves that have nothing else to do before the first barrier (neither the
+  // list nor background rows: waves 8 .. 15 of 16) -- the LDS takes these stores at ~50 B/clk whoever issues them,
+  // and the list wave and the storing waves used to spend their share in front of the work the barrier waits for.
+  // Whole-region z-buffers (BOX = false) are initialised where they will be READ only: the rows of the touched units
+  // (the stream-out decodes nothing else, the scan writes inside them).  Those are known once the records are in, so
+  // the idle waves take the central half of the region, speculatively, and the storing waves -- which derive the
+  // touched rows anyway -- the touched rows outside it, in front of their stores: ~75 instead of 139 KB for a hand crop.
+  const int ninitw = nwaves - 1 - nbgw;
+  const bool init_all = ninitw < 4;                                      // small workgroups: everybody, as before
+  const bool init_wave = init_all || wave_s > nbgw;
+  const int itid = init_all ? tid : tid - ((nbgw + 1) << 6), inthr = init_all ? nthr : ninitw << 6;
+  auto init_cells = [&](int c0, int c1, int t, int nt) {   // background in cells [c0, c1), by threads t of nt
     constexpr int per16 = 16 / sizeof(Key);
-    const int nvec = ncell / per16;
+    const int v0 = (c0 + per16 - 1) / per16, v1 = c1 / per16;
     if (OWNER) {
       const ulonglong2 v = make_ulonglong2(bg, bg);
-      for (int i = tid; i < nvec; i += nthr) reinterpret_cast<ulonglong2 *>(zbuf)[i] = v;
+      for (int i = v0 + t; i < v1; i += nt) reinterpret_cast<ulonglong2 *>(zbuf)[i] = v;
     } else {
       const uint4 v = make_uint4((uint32_t)bg, (uint32_t)bg, (uint32_t)bg, (uint32_t)bg);
-      for (int i = tid; i < nvec; i += nthr) reinterpret_cast<uint4 *>(zbuf)[i] = v;
+      for (int i = v0 + t; i < v1; i += nt) reinterpret_cast<uint4 *>(zbuf)[i] = v;
     }
-    for (int i = nvec * per16 + tid; i < ncell; i += nthr) zbuf[i] = bg;
+    // (the ragged ends of a range)
+    for (int i = c0 + t; i < min(c1, v0 * per16); i += nt) zbuf[i] = bg;
+    for (int i = max(c0, v1 * per16) + t; i < c1; i += nt) zbuf[i] = bg;
   };
+  // whole-region z-buffers of 16-byte-row images in big workgroups take the two-step initialisation
+  const bool init_split = !BOX && VEC4 && !init_all;
+  const int zpitch = W + kRowPad;
+  const int spec_lo = rh >> 2, spec_hi = rh - (rh >> 2);   // the speculative rows of the region
   // (the box is not known yet: every cell a one-pass box of this region can use; overlaps the read above)
-  init_zbuf(BOX ? min(zcells, rh * max_box_pitch(W)) : rh * (W + kRowPad));
+  if (init_wave) {
+    if (init_split) init_cells(spec_lo * zpitch, spec_hi * zpitch, itid, inthr);
+    else init_cells(0, BOX ? min(zcells, rh * max_box_pitch(W)) : rh * zpitch, itid, inthr);
+  }
 
   // Waves 1..kBgWaves store the background rows while wave 0 builds the list: they are the
   // first to finish the z-buffer initialisation (the SIMD arbitration favours old waves) and
@@ -642,6 +665,13 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
       }
     }
   };
+  if (init_split && bg_wave && ub > ua) {
+    // the rows of the touched units outside the speculative ones (a unit = 64 chunks = 256 / W rows or a row segment)
+    const int row_a = (ua << 6) / w4, row_b = min(rh, ((ub << 6) + w4 - 1) / w4);
+    const int bt = tid - 64, bnt = nbgw << 6;
+    if (row_a < spec_lo) init_cells(row_a * zpitch, min(row_b, spec_lo) * zpitch, bt, bnt);
+    if (row_b > spec_hi) init_cells(max(row_a, spec_hi) * zpitch, row_b * zpitch, bt, bnt);
+  }
   if (VEC4 && bg_wave) store_background(nwaves == 1 ? 0 : wave_s - 1, nwaves == 1 ? 1 : nbgw);
   if (!BOX) {
     if (VEC4 && wave_s == (nwaves == 1 ? 0 : 1) && lane == 0) { s_flag[2] = ua; s_flag[3] = ub; }   // for the other waves
@@ -1179,17 +1209,18 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   const int LW = W + kRowPad;
   Axis ax = axis_of(W, axk.mulx), ay = axis_of(H, axk.muly);
   const float kx = axk.kx, ky = axk.ky;   // pixels per millimetre (launch constants: common.h AxisK)
-  if (BOX) asm volatile("" : "+v"(ax.mul), "+v"(ay.mul), "+v"(ax.half), "+v"(ay.half));   // (SGPR budget, see the forward)
   const int wave_s = rfl(wave);
   const bool bg_wave = wave_s >= 1 && wave_s <= kBgWaves;
   const bool valid = lane < J;
   const bool pf_wave = wave_s == kZWaves - 1;
-  const float *tgt = target + (size_t)(target_index ? target_index[n] : n) * H * W + (size_t)r0 * W;
-  float *out = depth ? depth + (size_t)n * H * W + (size_t)r0 * W : nullptr;
   const bool has_next = PERSIST && n + crop_step < N;
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
   if (valid && (wave_s == 0 || bg_wave))   // the others: wave 0's LDS copy, later
     sph = crop_it == 0 ? spheres[(size_t)n * J + lane] : s_next[lane];
+  // (behind the records' request: the index is a scalar load, the output pointers are not among the preloaded arguments)
+  const float *tgt = target + (size_t)(target_index ? target_index[n] : n) * H * W + (size_t)r0 * W;
+  float *out = depth ? depth + (size_t)n * H * W + (size_t)r0 * W : nullptr;
+  if (BOX) asm volatile("" : "+v"(ax.mul), "+v"(ay.mul), "+v"(ax.half), "+v"(ay.half));   // (SGPR budget, see the forward)
   if (tid < kZWaves * J) s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // (16 waves x J <= 64 spheres)
   {  // background everywhere (BOX: every cell a box of this region can use)
     const Key bg = (Key)background_cell();
@@ -1480,12 +1511,15 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   }  // crops
 }
 
+// (argument order of the two wrappers: what a wave needs before it requests its records -- and the observed image's
+// index -- comes first, among the 14 argument dwords that are preloaded into SGPRs; the outputs and the axis constants
+// follow and are fetched by an s_load whose wait sits behind those requests)
 template <bool POW2, bool PERSIST>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J, int H, int W, const float *__restrict__ target,
-                       const int *__restrict__ target_index, float *__restrict__ depth, float *__restrict__ sse_out,
-                       float4 *__restrict__ grad_out, int rows_per_region, int w4_shift, int shares_fwd, int shares_bwd,
-                       AxisK axk) {
+                       const int *__restrict__ target_index, int rows_per_region, int w4_shift, int shares_fwd,
+                       int shares_bwd, float *__restrict__ depth, float *__restrict__ sse_out,
+                       float4 *__restrict__ grad_out, AxisK axk) {
   sphere_zbuf_mse_body<POW2, PERSIST, false>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
                                              rows_per_region, w4_shift, shares_fwd, shares_bwd, 0, axk);
 }
@@ -1496,9 +1530,9 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J, int H, 
 template <bool POW2>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sphere_zbuf_mse_box_kernel(const float4 *__restrict__ spheres, int N, int J, int H, int W, const float *__restrict__ target,
-                           const int *__restrict__ target_index, float *__restrict__ depth, float *__restrict__ sse_out,
-                           float4 *__restrict__ grad_out, int rows_per_region, int w4_shift, int shares_fwd, int shares_bwd,
-                           int zcells, AxisK axk) {
+                           const int *__restrict__ target_index, int rows_per_region, int w4_shift, int zcells,
+                           int shares_fwd, int shares_bwd, float *__restrict__ depth, float *__restrict__ sse_out,
+                           float4 *__restrict__ grad_out, AxisK axk) {
   static_assert(POW2, "box variant: power-of-two images");
   sphere_zbuf_mse_body<POW2, false, true>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
                                           rows_per_region, w4_shift, shares_fwd, shares_bwd, zcells, axk);
