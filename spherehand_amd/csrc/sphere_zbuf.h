@@ -549,40 +549,23 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   if (BOX) asm volatile("" : "+v"(ax.mul), "+v"(ay.mul), "+v"(ax.half), "+v"(ay.half));
 
   const Key bg = OWNER ? (Key)background_cell() : (Key)depth_key(kBackground);
-  // The z-buffer is initialised by the waves that have nothing else to do before the first barrier (neither the
-  // list nor background rows: waves 8 .. 15 of 16) -- the LDS takes these stores at ~50 B/clk whoever issues them,
-  // and the list wave and the storing waves used to spend their share in front of the work the barrier waits for.
-  // Whole-region z-buffers (BOX = false) are initialised where they will be READ only: the rows of the touched units
-  // (the stream-out decodes nothing else, the scan writes inside them).  Those are known once the records are in, so
-  // the idle waves take the central half of the region, speculatively, and the storing waves -- which derive the
-  // touched rows anyway -- the touched rows outside it, in front of their stores: ~75 instead of 139 KB for a hand crop.
-  const int ninitw = nwaves - 1 - nbgw;
-  const bool init_all = ninitw < 4;                                      // small workgroups: everybody, as before
-  const bool init_wave = init_all || wave_s > nbgw;
-  const int itid = init_all ? tid : tid - ((nbgw + 1) << 6), inthr = init_all ? nthr : ninitw << 6;
-  auto init_cells = [&](int c0, int c1, int t, int nt) {   // background in cells [c0, c1), by threads t of nt
+  auto init_zbuf = [&](int ncell) {   // background everywhere, by every wave: they are all waiting for the records
     constexpr int per16 = 16 / sizeof(Key);
-    const int v0 = (c0 + per16 - 1) / per16, v1 = c1 / per16;
+    const int nvec = ncell / per16;
     if (OWNER) {
       const ulonglong2 v = make_ulonglong2(bg, bg);
-      for (int i = v0 + t; i < v1; i += nt) reinterpret_cast<ulonglong2 *>(zbuf)[i] = v;
+      for (int i = tid; i < nvec; i += nthr) reinterpret_cast<ulonglong2 *>(zbuf)[i] = v;
     } else {
       const uint4 v = make_uint4((uint32_t)bg, (uint32_t)bg, (uint32_t)bg, (uint32_t)bg);
-      for (int i = v0 + t; i < v1; i += nt) reinterpret_cast<uint4 *>(zbuf)[i] = v;
+      for (int i = tid; i < nvec; i += nthr) reinterpret_cast<uint4 *>(zbuf)[i] = v;
     }
-    // (the ragged ends of a range)
-    for (int i = c0 + t; i < min(c1, v0 * per16); i += nt) zbuf[i] = bg;
-    for (int i = max(c0, v1 * per16) + t; i < c1; i += nt) zbuf[i] = bg;
+    for (int i = nvec * per16 + tid; i < ncell; i += nthr) zbuf[i] = bg;
   };
-  // whole-region z-buffers of 16-byte-row images in big workgroups take the two-step initialisation
-  const bool init_split = !BOX && VEC4 && !init_all;
-  const int zpitch = W + kRowPad;
-  const int spec_lo = rh >> 2, spec_hi = rh - (rh >> 2);   // the speculative rows of the region
-  // (the box is not known yet: every cell a one-pass box of this region can use; overlaps the read above)
-  if (init_wave) {
-    if (init_split) init_cells(spec_lo * zpitch, spec_hi * zpitch, itid, inthr);
-    else init_cells(0, BOX ? min(zcells, rh * max_box_pitch(W)) : rh * zpitch, itid, inthr);
-  }
+  // (the box is not known yet: every cell a one-pass box of this region can use; overlaps the read above.  Tried
+  // in round 3 and dropped, tools/exp_ztime.py: the idle waves 8 .. 15 alone -- the young waves' LDS stores take
+  // until 3.0-3.8 k cycles and hold the barrier; whole-crop z-buffers on the central half of the rows first and the
+  // touched rows outside it by the storing waves -- their stores start later than the initialisation saves)
+  init_zbuf(BOX ? min(zcells, rh * max_box_pitch(W)) : rh * (W + kRowPad));
 
   // Waves 1..kBgWaves store the background rows while wave 0 builds the list: they are the
   // first to finish the z-buffer initialisation (the SIMD arbitration favours old waves) and
@@ -665,13 +648,6 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
       }
     }
   };
-  if (init_split && bg_wave && ub > ua) {
-    // the rows of the touched units outside the speculative ones (a unit = 64 chunks = 256 / W rows or a row segment)
-    const int row_a = (ua << 6) / w4, row_b = min(rh, ((ub << 6) + w4 - 1) / w4);
-    const int bt = tid - 64, bnt = nbgw << 6;
-    if (row_a < spec_lo) init_cells(row_a * zpitch, min(row_b, spec_lo) * zpitch, bt, bnt);
-    if (row_b > spec_hi) init_cells(max(row_a, spec_hi) * zpitch, row_b * zpitch, bt, bnt);
-  }
   if (VEC4 && bg_wave) store_background(nwaves == 1 ? 0 : wave_s - 1, nwaves == 1 ? 1 : nbgw);
   if (!BOX) {
     if (VEC4 && wave_s == (nwaves == 1 ? 0 : 1) && lane == 0) { s_flag[2] = ua; s_flag[3] = ub; }   // for the other waves

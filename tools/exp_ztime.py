@@ -42,5 +42,5 @@ i = (t[:, :, 2] - t[:, :, 1])
 print("init cycles by wave (mean):", np.round(i.mean(0)).astype(int).tolist())
 # absolute times inside a workgroup (relative to its earliest wave start)
 b0 = t[:, :, 0].min(1, keepdims=True)
-for i, nm in [(0, "T0 wave start"), (1, "T1 records requested"), (2, "T2 pre-barrier work done"), (3, "T3 after barrier1"), (7, "T3b scan starts"), (4, "T4 scan done"), (6, "T6 end")]:
+for i, nm in [(0, "T0 wave start"), (1, "T1 records requested"), (5, "T1b z-buffer init done"), (2, "T2 pre-barrier work done"), (3, "T3 after barrier1"), (7, "T3b scan starts"), (4, "T4 scan done"), (6, "T6 end")]:
     print("%-26s by wave (mean, since the workgroup's first wave start):" % nm, np.round((t[:, :, i] - b0).mean(0)).astype(int).tolist())
