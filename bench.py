@@ -10,7 +10,9 @@ spheres per crop from 256 JointAngleDataset poses (torch seed 0 on rank 0, seed
 r on rank r) pushed through forward kinematics; upstream gradient N(0,1).  One
 STEP = one forward launch (spheres -> depth[256,128,128] + uint8 owner map) + one backward launch
 (grad_depth, owner map -> grad_spheres[256,41,4]) through the C ABI, inputs and outputs
-resident in HBM.  Multi-GPU: every rank rasterizes its own 256 crops (weak
+resident in HBM -- the pair ops.SphereDepthRaster issues: the owner map never leaves that pair,
+so the forward runs with SHR_RASTER_OWNER_TOUCHED_ROWS (owner bytes on the rows the backward
+reads; `roofline.full_owner_map` times the public full-map forward beside it).  Multi-GPU: every rank rasterizes its own 256 crops (weak
 scaling, no data-path collective -- crops are independent); value =
 crops of all ranks / max-over-ranks time.
 
@@ -26,6 +28,13 @@ Prints ONE JSON line on rank 0 (the driver's contract), with
                 replay of the headline step, the reference-sized training step;
   cpu_baseline  the CPU oracle (oracle/, a port of the reference algorithm)
                 timed on this host on the same batch, rank 0, N=1 only.
+  N > 1         `secondary` carries the only communication of the design, max over ranks: the bare
+                9.24-MB flat-bucket gradient all-reduce and the DDP training step at the reference's
+                per-rank batch (network/engine.py:318-376).
+
+Before the W warm-up steps the step runs for CLOCK_WARMUP_MS: the device's clocks ramp over tens
+of milliseconds after an idle period, W = 5 steps are 70 us, and the timed region is meant to
+measure the kernels, not the ramp (`config.clock_warmup_ms`).
 """
 import argparse
 import ctypes
@@ -43,6 +52,9 @@ S = 128
 BATCH = 256
 J = 41
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CLOCK_WARMUP_MS = 50.0
+OWNER_TOUCHED_ROWS = 1   # SHR_RASTER_OWNER_TOUCHED_ROWS (include/spherehand_hip.h)
+GRAD_BUCKET_FLOATS = 2308946   # the 1-stack hourglass: 9.24 MB of fp32 gradients
 
 
 def make_inputs(rank, device):
@@ -108,6 +120,26 @@ def pmc_traffic(kernel):
         return int(d[kernel]["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except (KeyError, ValueError):
         return None, None
+
+
+def rocprof_avg_us():
+    """AverageNs of the two headline kernels in the newest committed rocprofv3 --kernel-trace --stats summary of this
+    command (profiles/rNN_bench_kernel_stats.csv), beside the live HIP-event means: {fwd, bwd, source} or None."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))
+    if not files:
+        return None
+    out = {"source": os.path.relpath(files[-1], ROOT)}
+    try:
+        for r in csv.DictReader(open(files[-1])):
+            for key, name in (("fwd", "sphere_zbuf_fwd_kernel"), ("bwd", "sphere_zbuf_bwd_kernel")):
+                if name in r["Name"] and key not in out:
+                    out[key] = round(float(r["AverageNs"]) / 1e3, 3)
+                    out[key + "_calls"] = int(r["Calls"])
+    except (KeyError, ValueError):
+        return None
+    return out if "fwd" in out and "bwd" in out else None
 
 
 def timed_steps(step, steps, warmup, dist, device):
@@ -186,11 +218,15 @@ def large_batch(lib, _lib, dev, stream):
         gs = torch.empty(n, J, 4, device=dev)
         p = [t.data_ptr() for t in (sph, depth, owner, grad, gs)]
         reps = 40 if n == 1152 else 8
-        f = mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_fwd(p[0], n, J, S, S, p[1], p[2], s), "fwd"),
-                           stream, reps, 5, 3, warm_ms=40.0)
+        owner.fill_(254)
+        _lib.check(lib.shr_sphere_raster_fwd_ex(p[0], n, J, S, S, p[1], p[2], OWNER_TOUCHED_ROWS, stream.cuda_stream), "fwd")
+        stream.synchronize()
+        written = float((owner != 254).float().mean())
+        f = mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_fwd_ex(p[0], n, J, S, S, p[1], p[2], OWNER_TOUCHED_ROWS, s),
+                                                "fwd"), stream, reps, 5, 3, warm_ms=40.0)
         b = mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_bwd(p[0], p[3], p[2], n, J, S, S, p[4], s), "bwd"),
                            stream, reps, 5, 3, warm_ms=40.0)
-        bf, bb = n * (4 * S * S + S * S + 16 * J), n * (4 * S * S + S * S + 32 * J)
+        bf, bb = int(n * (4 * S * S + written * S * S + 16 * J)), n * (4 * S * S + S * S + 32 * J)
         out[str(n)] = {"fwd_us": round(f, 2), "bwd_us": round(b, 2), "fwd_us_per_256": round(f * 256 / n, 3),
                        "bwd_us_per_256": round(b * 256 / n, 3), "fwd_frac": roof(bf, f)["frac"],
                        "bwd_frac": roof(bb, b)["frac"], "crops_per_s_fwd_bwd": round(n / ((f + b) * 1e-6), 1)}
@@ -341,10 +377,91 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     sec["depth_rasterization_forward_640x640_256_crops"] = dict(us=round(t_tri, 1), **roof(BATCH * (36 * nf + 4 * 640 * 640), t_tri))
     del raw, fv
 
+    # ---- the whole north-star chain once: pose[256,26] -> FK -> key-point skinning -> raster forward -> backward ->
+    # skinning / FK backward -> d/d pose (mesh/kinematicsTransformation.py:157-177, mesh/render.py:81-90), captured
+    # as ONE hipGraph (no Python between the launches) and replayed
+    from spherehand_amd.render import HandBallPrimitiveRender
+    hbr = HandBallPrimitiveRender(mesh["bones"], S, S).to(dev)
+    pose = sample_poses(BATCH, seed=0).to(dev).requires_grad_(True)
+    gdepth = torch.randn(BATCH, S, S, device=dev)
+
+    def chain():
+        pose.grad = None
+        depth = ops.SphereDepthRaster.apply(hbr.spheres(fkm(pose)).contiguous(), S, S)
+        depth.backward(gdepth)
+    for _ in range(3):
+        chain()
+    stream.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        chain()
+    t_chain = mean_launch_us(lambda _s: g.replay(), stream, 100, 3, 10)
+    t_eager = torch_us(chain, 50)
+    sec["pose_to_depth_to_pose_us"] = {"graph_replay_us": round(t_chain, 2), "eager_autograd_us": round(t_eager, 1),
+                                       "crops_per_s_graph": round(BATCH / (t_chain * 1e-6), 1),
+                                       "chain": "pose[256,26] -> fk_fwd -> key-point skinning -> sphere raster fwd (+ owner map) "
+                                                "-> bwd -> skinning bwd -> fk_bwd -> grad pose[256,26]"}
+    del g
+
     if os.environ.get("SHR_BENCH_SKIP_TRAIN"):      # counter passes: the step's ~700 launches only bloat the trace
         return sec
     sec["training_step_25x3_real_48_synt_64x64_ms"], sec["training_step_fastest_slowest_batch_ms"] = training_step_ms()
     return sec
+
+
+def collective_secondary(dist, rank, world, dev):
+    """N > 1: the design's only communication (network/engine.py:318-376), max over ranks.
+    (i) the bare all-reduce of the flat 9.24-MB gradient bucket; (ii) the DDP training step at the reference's
+    per-rank batch (25 x 3 real + 48 synthetic crops @64x64, every loss term on) with that bucket in its backward."""
+    import tempfile
+    from types import SimpleNamespace
+    from spherehand_amd import hand_model
+    from spherehand_amd.datasets import SyntheticMultiviewDataset
+    from spherehand_amd.engine import Engine
+    from spherehand_amd.joint_angle import sample_poses
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    def max_over_ranks(v):
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    bucket = torch.randn(GRAD_BUCKET_FLOATS, device=dev)
+    for _ in range(5):
+        dist.all_reduce(bucket)
+    sync(); dist.barrier(); sync()
+    reps = 50
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(bucket)
+    sync()
+    ar_us = max_over_ranks((time.perf_counter() - t0) / reps * 1e6)
+    out = {"grad_bucket_allreduce_us": round(ar_us, 1), "grad_bucket_bytes": GRAD_BUCKET_FLOATS * 4,
+           "grad_bucket_busbw_GBs": round(2 * (world - 1) / world * GRAD_BUCKET_FLOATS * 4 / (ar_us * 1e-6) / 1e9, 2)}
+    mesh = hand_model.load_mesh()
+    o = SimpleNamespace(synthesize=True, mv_projection=True, mv_consistency=True, temporal=False, prior=False,
+                        collision=True, bone_length=True, mode="Train", model_dir=tempfile.mkdtemp(), initial_model=None,
+                        restore_from_model=None, restore_from_epoch=-1, num_stacks=1, epoch=3, dataset_dir=None,
+                        depth_resample=0, lr=1e-3, tag="b", image_size=64, log_every=10 ** 9, real_batch=25, synt_batch=48)
+    ds = SyntheticMultiviewDataset(mesh, 50, 64, seed=rank, device=dev)
+    eng = Engine(o, mesh=mesh, real_train_dataset=ds, real_eval_dataset=ds, device=dev)
+    assert eng.env.world == world and type(eng.ddp_network).__name__ == "DistributedDataParallel"
+    eng.network.train()
+    realb = [torch.stack([ds[i][k] for i in range(25)]) for k in range(4)]
+    pose = sample_poses(48, seed=1 + rank)
+    nsteps = int(os.environ.get("SHR_BENCH_DDP_STEPS", "10"))
+    for _ in range(3):
+        eng.step(realb, pose, True, True)
+    sync(); dist.barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        eng.step(realb, pose, True, True)
+    sync()
+    out["ddp_training_step_25x3_real_48_synt_64x64_ms"] = round(max_over_ranks((time.perf_counter() - t0) / nsteps * 1e3), 3)
+    out["ddp_samples_per_s"] = round(world * (25 * 3 + 48) / (out["ddp_training_step_25x3_real_48_synt_64x64_ms"] * 1e-3), 1)
+    return out
 
 
 def main():
@@ -399,6 +516,9 @@ def main():
     sp, gp, dp, op, ap = spheres.data_ptr(), grad.data_ptr(), depth.data_ptr(), gsph.data_ptr(), owner.data_ptr()
 
     def fwd(s):
+        _lib.check(lib.shr_sphere_raster_fwd_ex(sp, BATCH, J, S, S, dp, ap, OWNER_TOUCHED_ROWS, s), "fwd")
+
+    def fwd_full(s):     # the public contract: owner map complete
         _lib.check(lib.shr_sphere_raster_fwd(sp, BATCH, J, S, S, dp, ap, s), "fwd")
 
     def bwd(s):
@@ -420,12 +540,23 @@ def main():
             else:
                 fwd(sh); bwd(sh)
 
+        # owner bytes the flagged forward writes (its algorithmic bytes: the rows some sphere's box touches)
+        owner.fill_(254)
+        fwd(sh)
+        stream.synchronize()
+        owner_written = float((owner != 254).float().mean())
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < CLOCK_WARMUP_MS:
+            for _ in range(50):
+                step()
+            stream.synchronize()
         elapsed = timed_steps(step, args.steps, args.warmup, dist, dev)
 
         def kernel_us(fn, reps=200, batches=5, warm=20):
             return mean_launch_us(fn, stream, reps, batches, warm)
         fwd_us = kernel_us(fwd)
         bwd_us = kernel_us(bwd)
+        fwd_full_us = kernel_us(fwd_full)
         # context for the roofline: what ONE plain fill launch of the depth output (16.8 of the
         # forward's 21.1 MB, no arithmetic, same stream) takes at this batch size -- the practical
         # ceiling of any kernel that has to write a 256-crop batch per launch
@@ -441,11 +572,17 @@ def main():
             big = large_batch(lib, _lib, dev, stream)
             sec = secondary(lib, _lib, dev, stream, graph_us)
 
+    coll = None
+    if dist is not None and not args.no_secondary:
+        coll = collective_secondary(dist, rank, world, dev)   # every rank takes part; rank 0 prints
     if rank == 0:
         # algorithmic bytes ("u8 argmin saved" variant: 165 808 B/crop fwd+bwd @128):
         #   fwd writes depth f32 + owner u8, reads the spheres; bwd reads grad f32 + owner u8 +
         #   spheres, writes grad_spheres
-        bytes_fwd = BATCH * (4 * S * S + S * S + 16 * J)
+        #   (forward with SHR_RASTER_OWNER_TOUCHED_ROWS: the owner bytes of the touched rows only -- the measured
+        #   fraction; the backward is priced at the whole images although it reads the touched rows only)
+        bytes_fwd = int(BATCH * (4 * S * S + owner_written * S * S + 16 * J))
+        bytes_fwd_full = BATCH * (4 * S * S + S * S + 16 * J)
         bytes_bwd = BATCH * (4 * S * S + S * S + 16 * J + 16 * J)
         dom, dom_us, dom_bytes = ("sphere_zbuf_bwd_kernel", bwd_us, bytes_bwd) if bwd_us >= fwd_us else \
             ("sphere_zbuf_fwd_kernel", fwd_us, bytes_fwd)
@@ -467,14 +604,22 @@ def main():
             "config": {"workload": "BASELINE configs[1]: batch-256 128x128 sphere raster fwd+bwd, 41 spheres/crop, "
                                    "JointAngleDataset poses (seed 0), grad N(0,1)",
                        "crops_per_gpu": BATCH, "image": [S, S], "spheres_per_crop": J,
-                       "launch": args.launch, "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                       "launch": args.launch, "clock_warmup_ms": CLOCK_WARMUP_MS,
+                       "parallelism": "batch-sharded x%d, no data-path collective" % world,
                        "rccl_ranks": rccl_ranks, "backend": os.environ.get("SHR_BENCH_BACKEND", "nccl") if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes,
                          "launch_us": {"fwd": round(fwd_us, 3), "bwd": round(bwd_us, 3)},
-                         "launch_us_is": "mean of 1000 back-to-back launches (HIP events)",
+                         "launch_us_is": "mean of 1000 back-to-back launches (HIP events on the launching stream, this "
+                                         "process); `frac` uses it.  rocprof_avg_us = AverageNs of the committed "
+                                         "rocprofv3 --kernel-trace --stats run of this command (tracing adds the "
+                                         "difference: profiles/README.md)",
+                         "rocprof_avg_us": rocprof_avg_us(),
+                         "owner_map": "touched rows only (SHR_RASTER_OWNER_TOUCHED_ROWS): %.1f %% of the owner bytes"
+                                      % (100 * owner_written),
+                         "full_owner_map": dict(fwd_us=round(fwd_full_us, 3), **roof(bytes_fwd_full, fwd_full_us)),
                          "frac_fwd": roof(bytes_fwd, fwd_us)["frac"], "frac_bwd": roof(bytes_bwd, bwd_us)["frac"],
                          "plain_fill_of_the_depth_output_us": round(fill_us, 3)},
         }
@@ -482,6 +627,8 @@ def main():
             out["roofline"]["large_batch"] = big
         if sec is not None:
             out["secondary"] = sec
+        if coll is not None:
+            out["secondary"] = coll
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spheres.cpu().numpy(), grad.cpu().numpy())
         print(json.dumps(out), flush=True)

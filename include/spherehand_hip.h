@@ -305,6 +305,19 @@ int shr_lbs_project(const float *T, int B, int NB, int NV, const int32_t *skin_v
                     int project, float cx, float cy, float fx, float fy,
                     const float *rand_f, float *out, void *stream);
 
+/* Key-point skinning -> sphere records -----------------------------------------------------
+ * Replaces, inside HandBallPrimitiveRender (mesh/render.py:65-88), the LinearBlendSkinning of the key-points (each
+ * bound to ONE bone with weight 1: mesh/pointTransformation.py:39-46 reduces to p = T[bone[j]] @ wv[j], x -> -x for
+ * the right hand) and the cat with the radii:  spheres[B,J,4] = (+-p.x, p.y, p.z, radii[j]).
+ * T[B,NB,4,4]; bone[J] (bone of key-point j), wv[J,4] = fp32(weight * key-point) as the reference stores it (:31). */
+int shr_keypoint_spheres_fwd(const float *T, int B, int NB, int J, const int32_t *bone, const float *wv,
+                             const float *radii, int right_hand, float *spheres, void *stream);
+/* Its autograd backward: grad_T[B,NB,4,4] = d<grad_spheres, spheres>/dT (the radii are buffers in the reference and
+ * get no gradient, the homogeneous row gets none).  bone_start[NB+1], bone_points[J]: the key-points of every bone
+ * (CSR, ascending: the sums run in index order). */
+int shr_keypoint_spheres_bwd(const float *grad_spheres, int B, int NB, int J, const int32_t *bone_start,
+                             const int32_t *bone_points, const float *wv, int right_hand, float *grad_T, void *stream);
+
 /* Forward kinematics -------------------------------------------------------------------
  * Replaces HandTransformationMat.forward (mesh/kinematicsTransformation.py:157-177)
  * and its autograd backward.  params[B,26] (palm Euler xyz, palm translation, 5 x

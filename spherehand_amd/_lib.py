@@ -15,7 +15,7 @@ import torch  # noqa: F401  (device memory, streams: the plumbing this library s
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libspherehand_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -28,6 +28,8 @@ SIGNATURES = {
     "shr_device_info": ([ctypes.c_char_p, _i, ctypes.POINTER(_i)], _i),
     "shr_sphere_raster_fwd": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "shr_sphere_raster_fwd_ex": ([_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp], _i),
+    "shr_keypoint_spheres_fwd": ([_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp], _i),
+    "shr_keypoint_spheres_bwd": ([_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp], _i),
     "shr_sphere_raster_bwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp], _i),
     "shr_set_tuning": ([_i, _i], _i),
     "shr_data_to_model": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),

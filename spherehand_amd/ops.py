@@ -389,6 +389,43 @@ def lbs_project(T, skin_vertex_start, skin_bone, skin_wv, right_hand=True, camer
     return out
 
 
+class KeypointSpheres(torch.autograd.Function):
+    """T[B,NB,4,4] -> the rasterizer's records spheres[B,J,4] = (+-p.x, p.y, p.z, radii[j]), p = T[bone[j]] @ wv[j]: the
+    key-point skinning + cat of HandBallPrimitiveRender (mesh/render.py:65-88) as one launch per direction; gradient
+    w.r.t. T (the radii are buffers in the reference).  Tables: pointTransformation.LinearBlendSkinning.kp_*."""
+
+    @staticmethod
+    def forward(ctx, T, bone, wv, radii, bone_start, bone_points, right_hand):
+        T = T.contiguous().float()
+        _check_input(T, "transformation matrices")
+        if T.dim() != 4 or T.shape[2:] != (4, 4):
+            raise RuntimeError("transformation matrices must be [B,NB,4,4]")
+        B, NB, J = T.shape[0], T.shape[1], bone.shape[0]
+        if bone_start.shape[0] != NB + 1 or wv.shape != (J, 4) or radii.numel() != J:
+            raise RuntimeError("key-point tables do not match the bones")
+        with _on(T.device):
+            sph = torch.empty((B, J, 4), dtype=torch.float32, device=T.device)
+            _lib.check(_lib.lib().shr_keypoint_spheres_fwd(_ptr(T), B, NB, J, _ptr(bone), _ptr(wv), _ptr(radii),
+                                                           int(bool(right_hand)), _ptr(sph), _stream()),
+                       "shr_keypoint_spheres_fwd")
+        ctx.save_for_backward(wv, bone_start, bone_points)
+        ctx.dims = (B, NB, J, int(bool(right_hand)))
+        return sph
+
+    @staticmethod
+    def backward(ctx, grad_spheres):
+        wv, bone_start, bone_points = ctx.saved_tensors
+        B, NB, J, right = ctx.dims
+        g = grad_spheres.contiguous().float()
+        with _on(g.device):
+            gT = torch.zeros((B, NB, 4, 4), dtype=torch.float32, device=g.device) if B == 0 else \
+                torch.empty((B, NB, 4, 4), dtype=torch.float32, device=g.device)
+            _lib.check(_lib.lib().shr_keypoint_spheres_bwd(_ptr(g), B, NB, J, _ptr(bone_start), _ptr(bone_points),
+                                                           _ptr(wv), right, _ptr(gT), _stream()),
+                       "shr_keypoint_spheres_bwd")
+        return gT, None, None, None, None, None, None
+
+
 class ForwardKinematics(torch.autograd.Function):
     """params [B,26] -> bone transforms [B,17,4,4] (mesh/kinematicsTransformation.py:169-177),
     analytic backward; offset / offset_inv [17,4,4] are constants."""

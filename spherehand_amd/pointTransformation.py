@@ -44,6 +44,19 @@ class LinearBlendSkinning(nn.Module):
         self.register_buffer('skin_vertex_start', torch.from_numpy(np.cumsum(start).astype(np.int32)))
         # one-bone-per-vertex (the 41 key-points: mesh/render.py:65-77) is a pure gather
         self.single_bone = bool(len(vid) == nv and np.array_equal(np.sort(vid), np.arange(nv)))
+        if self.single_bone:
+            # the key-point kernels' tables (ops.KeypointSpheres): bone of every point, and the points of every bone (CSR)
+            kb = bid[order].astype(np.int64)
+            nb = len(skinning_weights)
+            bstart = np.zeros(nb + 1, np.int64)
+            np.add.at(bstart, kb + 1, 1)
+            self.register_buffer('kp_bone', torch.from_numpy(kb.astype(np.int32)), persistent=False)
+            self.register_buffer('kp_bone_start', torch.from_numpy(np.cumsum(bstart).astype(np.int32)), persistent=False)
+            self.register_buffer('kp_bone_points', torch.from_numpy(np.argsort(kb, kind='stable').astype(np.int32)),
+                                 persistent=False)
+        # x -> -x for the right hand (:44-45) as a resident constant (a new_tensor() per call is a host -> device copy
+        # on every step and cannot be captured in a hipGraph)
+        self.register_buffer('hand_sign', torch.tensor([-1.0, 1.0, 1.0, 1.0]), persistent=False)
 
     def forward(self, bone_transformations):
         T = bone_transformations
@@ -57,7 +70,7 @@ class LinearBlendSkinning(nn.Module):
             out = torch.zeros(B, self.num_vertices, 4, dtype=T.dtype, device=T.device)
             out.index_add_(1, self.skin_vertex, per_entry)
         if self.right_hand:
-            out = out * out.new_tensor([-1.0, 1.0, 1.0, 1.0])
+            out = out * self.hand_sign.to(out.dtype)
         return out
 
 

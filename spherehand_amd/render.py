@@ -52,6 +52,13 @@ class HandBallPrimitiveRender(nn.Module):
         self.differentiable_part_maps = differentiable_part_maps
 
     def spheres(self, transformation_mats):
+        T = transformation_mats
+        if T.is_cuda and T.dtype == torch.float32 and self.lbs.single_bone:   # one launch per direction (keypoint_skin.hip)
+            if T.dim() == 5:
+                T = T.squeeze(2)
+            lbs = self.lbs
+            return ops.KeypointSpheres.apply(T, lbs.kp_bone, lbs.skin_wv, self.radiuses.view(-1), lbs.kp_bone_start,
+                                             lbs.kp_bone_points, lbs.right_hand)
         pts = self.lbs(transformation_mats)                                  # [B,41,4]
         B = pts.shape[0]
         return torch.cat([pts[:, :, 0:3], self.radiuses.expand(B, -1).unsqueeze(-1)], dim=2)

@@ -1,7 +1,8 @@
 """GPU: bench.py's multi-rank path end to end -- two ranks launched exactly as the driver launches them
 (`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`) on ONE MI355X (backend gloo and a
 pinned device through bench.py's test hooks: RCCL refuses two ranks on one device).  Checks the JSON contract:
-whole-job value = crops of all ranks / max-over-ranks time, weak scaling, the rank count the collective saw."""
+whole-job value = crops of all ranks / max-over-ranks time, weak scaling, the rank count the collective saw, and
+the two timings of the design's only communication (bare gradient-bucket all-reduce, DDP training step)."""
 import json
 import os
 import subprocess
@@ -16,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 
 def test_bench_two_ranks_one_gpu():
-    env = dict(os.environ, SHR_BENCH_BACKEND="gloo", SHR_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env = dict(os.environ, SHR_BENCH_BACKEND="gloo", SHR_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
+               SHR_BENCH_DDP_STEPS="3")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "10"]
     out = subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT, capture_output=True, text=True).stdout
@@ -26,7 +28,11 @@ def test_bench_two_ranks_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 50 and d["warmup"] == 10 and d["scaling"] == "weak"
     assert d["config"]["rccl_ranks"] == 2 and d["config"]["crops_per_gpu"] == 256
     assert abs(d["value"] - 2 * 256 * 50 / (d["ms_per_step"] * 1e-3 * 50)) <= 1e-3 * d["value"]
-    assert "cpu_baseline" not in d and "secondary" not in d   # N = 1 only
+    assert "cpu_baseline" not in d                            # N = 1 only
+    sec = d["secondary"]                                      # N > 1: the collective, max over ranks
+    assert sec["grad_bucket_bytes"] == 2308946 * 4 and sec["grad_bucket_allreduce_us"] > 0
+    assert sec["ddp_training_step_25x3_real_48_synt_64x64_ms"] > 0 and sec["ddp_samples_per_s"] > 0
+    assert "config5_per_gpu_1152_crops_256x256" not in sec   # the single-GPU kernel table stays with N = 1
     assert 0 < d["roofline"]["frac"] < 1
 
 

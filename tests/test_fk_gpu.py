@@ -111,3 +111,36 @@ def test_pose_to_depth_end_to_end(fk):
     hbr.spheres(fk.forward_torch(p3)).backward(dev(gs))
     b, r = p2.grad.cpu().numpy(), p3.grad.cpu().numpy()
     assert np.linalg.norm(b - r) / np.linalg.norm(r) <= 1e-3
+
+
+def test_keypoint_spheres_kernel_vs_torch_skinning(fk):
+    """ops.KeypointSpheres (keypoint_skin.hip: T -> sphere records in one launch, analytic backward) against the torch
+    formulation of the same module (LinearBlendSkinning.forward + cat, mesh/render.py:65-88 / pointTransformation.py:
+    39-46) on the g3 poses: records <= 2e-5 mm (4-term dot products in another association), radii bit-exact,
+    d/dT <= 1e-6 of the largest entry for a random upstream; and against the reference's own centres (g3, 3e-4: the
+    FK tolerance).  Empty batch and the 5-D [B,NB,1,4,4] input the reference's callers pass."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.render import HandBallPrimitiveRender
+    g = golden("g3_batch256.npz")
+    hbr = HandBallPrimitiveRender(hand_model.load_mesh()["bones"], 128, 128).cuda()
+    T1 = fk(dev(g["params"])).detach().requires_grad_(True)
+    T2 = T1.detach().clone().requires_grad_(True)
+    sph = hbr.spheres(T1)                                                          # the kernel
+    pts = hbr.lbs(T2)                                                              # torch ops
+    ref = torch.cat([pts[:, :, 0:3], hbr.radiuses.expand(256, -1).unsqueeze(-1)], dim=2)
+    assert sph.shape == (256, 41, 4) and sph.is_contiguous()
+    assert (sph[..., :3] - ref[..., :3]).abs().max().item() <= 2e-5
+    assert torch.equal(sph[..., 3], ref[..., 3])
+    assert np.abs(sph[..., :3].detach().cpu().numpy() - g["centres"][..., :3]).max() <= 3e-4
+    G = torch.randn(256, 41, 4, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    (sph * G).sum().backward()
+    (ref * G).sum().backward()
+    assert (T1.grad - T2.grad).abs().max().item() <= 1e-6 * T2.grad.abs().max().item()
+    assert torch.equal(T1.grad[:, :, 3], torch.zeros_like(T1.grad[:, :, 3]))       # the homogeneous row
+    assert torch.equal(T1.grad[:, 1], torch.zeros_like(T1.grad[:, 1]))             # bone 1 carries no key-point
+    assert torch.equal(hbr.spheres(T1.detach().unsqueeze(2)), sph.detach())        # [B,NB,1,4,4]
+    assert hbr.spheres(T1.detach()[:0]).shape == (0, 41, 4)
+    with pytest.raises(RuntimeError):
+        from spherehand_amd import ops
+        ops.KeypointSpheres.apply(T1.detach()[:, :5], hbr.lbs.kp_bone, hbr.lbs.skin_wv, hbr.radiuses.view(-1),
+                                  hbr.lbs.kp_bone_start, hbr.lbs.kp_bone_points, True)
