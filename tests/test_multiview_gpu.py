@@ -110,12 +110,8 @@ def test_config5_per_gpu_shard_properties(oracle):
     # occlusion edge between two spheres may differ
     obs = real.unsqueeze(1).expand(B, V, V, S, S)
     assert ((depth - obs).abs() > 0.05).float().mean().item() < 2e-4
-    # oracle spot check on 6 crops (bit-exact given the same projected centres)
+    # (the oracle comparison of every crop: test_config5_full_size_against_the_oracle)
     sph = torch.cat([pts.squeeze(-1), mp.radiuses.view(1, 1, 1, -1, 1).expand(B, V, V, -1, 1)], -1)
-    idx = [0, 5, 100, 577, 1000, 1151]
-    sub = sph.view(-1, 41, 4)[idx].contiguous()
-    od = oracle.sphere_raster_fwd(sub.cpu().numpy(), S, S, want_argmin=False)
-    assert np.array_equal(bits(depth.view(-1, S, S)[idx].cpu().numpy()), bits(od))
     # the loss at the truth is (near) its minimum; away from it, larger
     crit = MutualProjectionLoss(S, mesh).cuda()
     j0 = truth.clone().requires_grad_(True)
@@ -133,6 +129,91 @@ def test_config5_per_gpu_shard_properties(oracle):
     gs = ops.sphere_raster_bwd(spheres, g, owner)
     fg_sum = (g.double() * (d < 100)).sum(dim=(1, 2))
     assert (gs[:, :, 2].double().sum(1) - fg_sum).abs().max().item() < 5e-3
+
+
+def test_config5_full_size_against_the_oracle(oracle):
+    """BASELINE configs[4] at its per-GPU size -- ALL 1152 crops @256x256 -- against the CPU oracle (OpenMP over the
+    host's cores: seconds), what mesh/multiview_utility.py:55-130 must match:
+      forward          depth bits and owner maps of every crop (bit-exact), with the full owner map and in the autograd
+                       pair's touched-rows mode;
+      backward         d<g, depth>/d spheres for an N(0,1) upstream (1e-5 of the largest entry + 1e-4: fp32 summation
+                       order against the oracle's fp64 sums);
+      fused            render-and-compare: projected depth bits, per-crop sum of squares (2e-5) and its gradient
+                       against the oracle's backward of 2 (depth - observed);
+      data -> model    per-crop loss sums (1e-5) and unit gradients (1e-5 of the largest entry, but for the unit vectors of
+                       pixels equidistant from two spheres) through the image index;
+      the criterion    MutualProjectionLoss(is_mv=True): loss (1e-4) and d loss / d joints (1e-3 of the largest entry)
+                       against the value ASSEMBLED from the oracle's pieces with the reference's weights (9 x MSE +
+                       500 x 9 x data->model, :98-105, :129) and pulled back through the view transforms in fp64."""
+    from spherehand_amd import hand_model, ops
+    from spherehand_amd.datasets import SyntheticMultiviewDataset
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    mesh = hand_model.load_mesh()
+    B, V, S, J = 128, 3, 256, 41
+    N = B * V * V
+    ds = SyntheticMultiviewDataset(mesh, B, S, seed=5)
+    cam, inv, real = ds.cam.cuda(), ds.inv_cam.cuda(), ds.dms.cuda()
+    joints = (ds.joints.cuda() + 1.5 * torch.randn(ds.joints.shape, device="cuda",
+                                                   generator=torch.Generator(device="cuda").manual_seed(3)))
+    crit = MutualProjectionLoss(S, mesh).cuda()
+    radii = crit.mutual_projection.radiuses.view(-1)
+    sph = ops.MutualProject.apply(cam, inv, joints, radii).view(N, J, 4).contiguous()
+    sph_h = sph.cpu().numpy()
+    # ---- forward: every crop's depth and owner map
+    od, oa = oracle.sphere_raster_fwd(sph_h, S, S, want_argmin=True)
+    d, a = ops.sphere_raster_fwd(sph, S, S, want_argmin=True)
+    assert np.array_equal(bits(d.cpu().numpy()), bits(od)) and np.array_equal(a.cpu().numpy(), oa)
+    d2, a2 = ops.sphere_raster_fwd(sph, S, S, want_argmin=True, flags=ops.RASTER_OWNER_TOUCHED_ROWS)
+    assert torch.equal(d2, d)
+    fg_rows = torch.from_numpy((od < 100).any(2)).cuda()                       # rows with foreground are touched rows
+    assert torch.equal(a2[fg_rows], a[fg_rows])
+    # ---- backward for a random upstream gradient (from either owner map)
+    g = torch.randn(N, S, S, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    og = oracle.sphere_raster_bwd(sph_h, g.cpu().numpy())
+    tol = 1e-5 * np.abs(og).max() + 1e-4
+    for owner in (a, a2):
+        assert np.abs(ops.sphere_raster_bwd(sph, g, owner).cpu().numpy() - og).max() <= tol
+    del g, d2, a2
+    # ---- fused render-and-compare against the observed images (crop (b,i,j) vs image b*V+j)
+    obs = real.view(B * V, S, S).contiguous()
+    index, _ = crit._indices(B, V, sph.device)
+    obs_h = obs.cpu().numpy()
+    idx_h = index.cpu().numpy()
+    e_h = od.astype(np.float64) - obs_h[idx_h]
+    sse_ref = (e_h ** 2).sum((1, 2))
+    gs_ref = oracle.sphere_raster_bwd(sph_h, (2.0 * e_h).astype(np.float32))
+    proj, sse, gs = ops.sphere_raster_mse(sph, obs, index)
+    assert np.array_equal(bits(proj.cpu().numpy()), bits(od))
+    assert np.abs(sse.double().cpu().numpy() - sse_ref).max() <= 2e-5 * sse_ref.max()
+    assert np.abs(gs.cpu().numpy() - gs_ref).max() <= 2e-5 * np.abs(gs_ref).max() + 1e-3
+    # ---- data -> model through the same index
+    cen = sph[..., :3].contiguous()
+    exp_h = obs_h[idx_h]                                                        # the reference's 3x expansion (:99)
+    dl_ref = oracle.data_to_model_fwd(exp_h, sph_h[..., :3], radii.cpu().numpy())
+    dg_ref = oracle.data_to_model_bwd(exp_h, sph_h[..., :3], radii.cpu().numpy()).astype(np.float64) * exp_h.size
+    # (the oracle returns d mean / d centres; the kernel the unit gradient of the per-crop sums)
+    dl, dg = ops.data_to_model(obs, cen, radii, want_grad=True, depth_index=index)
+    assert np.abs(dl.double().cpu().numpy() - dl_ref).max() <= 1e-5 * dl_ref.max()
+    # (a pixel equidistant from two spheres to within an ulp of the root -- v_sqrt_f32 in the kernel, sqrtf in the oracle --
+    # may be assigned to either: the loss is continuous there, the pixel's UNIT vector moves between two gradient
+    # entries.  Ten million foreground pixels hold a few of those: entries off by more than the rounding bar must be
+    # rare and off by no more than a couple of unit vectors)
+    dd = np.abs(dg.cpu().numpy() - dg_ref)
+    off = dd > 1e-5 * np.abs(dg_ref).max() + 1e-6
+    assert off.sum() <= 6 * 16 and dd.max() <= 2.5, (off.sum(), dd.max())     # <= 16 such pixels x (2 spheres x 3 components)
+    del exp_h, e_h
+    # ---- the criterion, assembled from the oracle's pieces
+    count = float(N) * S * S
+    loss_ref = 9.0 * sse_ref.sum() / count + 500.0 * 9.0 * dl_ref.sum() / count
+    gp = (9.0 / count) * gs_ref[..., :3].astype(np.float64) + (500.0 * 9.0 / count) * dg_ref
+    M = np.matmul(inv.cpu().numpy().astype(np.float64)[:, None], cam.cpu().numpy().astype(np.float64)[:, :, None])
+    gj_ref = np.einsum("bijrc,bijkr->bikc", M[..., :3, :3], gp.reshape(B, V, V, J, 3))
+    jr = joints.clone().requires_grad_(True)
+    loss, projected = crit(cam, inv, jr, real, True)
+    loss.backward()
+    assert abs(loss.item() - loss_ref) <= 1e-4 * abs(loss_ref)
+    assert np.array_equal(bits(projected.view(N, S, S).cpu().numpy()), bits(od))
+    assert np.abs(jr.grad.cpu().numpy() - gj_ref).max() <= 1e-3 * np.abs(gj_ref).max()
 
 
 def _random_spheres(rs, n, j=41, spread=80.0):
