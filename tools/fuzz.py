@@ -1,5 +1,9 @@
 """Randomised differential testing of the HIP kernels against the CPU oracle (run on the GPU box; the permanent
-tests in tests/ are fixed seeds, this explores).  usage: python tools/fuzz.py [seconds per family] [seed] [families]"""
+tests in tests/ are fixed seeds, this explores).
+
+    python tools/fuzz.py [seconds per family] [seed] [families]      # the long run (profiles/rNN_fuzz_summary.txt)
+    fuzz.run(families, cases, seconds, seed)                          # tests/test_fuzz_gpu.py: a bounded, seeded slice
+"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,8 +12,7 @@ import depth_rasterization
 from oracle import oracle
 from spherehand_amd import ops
 oracle.build()
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
-rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+rs = np.random.RandomState(0)
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
 fails = 0
@@ -48,10 +51,16 @@ def sphere_case():
     why = [] if ok else ['fwd depth %d px, owner %d px' % (int((bits(d.cpu().numpy()) != bits(od)).sum()), int((a.cpu().numpy() != oa).sum()))]
     gd = rs.standard_normal((N, H, W)).astype(np.float32)
     og = oracle.sphere_raster_bwd(sp, gd)
-    for owner in (a, None):
+    # the autograd pair's owner map: written on the touched rows only, over whatever the buffer held
+    d2, a2 = ops.sphere_raster_fwd(dev(sp), H, W, want_argmin=True, flags=ops.RASTER_OWNER_TOUCHED_ROWS)
+    fg_rows = (od < 100).any(2)
+    if not (torch.equal(d2, d) and np.array_equal(a2.cpu().numpy()[fg_rows], oa[fg_rows])):
+        ok = False
+        why.append('touched-rows forward')
+    for owner, label in ((a, 'owner map'), (a2, 'touched-rows owner map'), (None, 'recomputed')):
         gs = ops.sphere_raster_bwd(dev(sp), dev(gd), owner).cpu().numpy()
         okb = bool(np.abs(gs - og).max() <= 1e-5 * np.abs(og).max() + 2e-4)
-        if not okb: why.append('bwd(%s) err %.3g of %.3g' % ('owner map' if owner is not None else 'recomputed', np.abs(gs - og).max(), np.abs(og).max()))
+        if not okb: why.append('bwd(%s) err %.3g of %.3g' % (label, np.abs(gs - og).max(), np.abs(og).max()))
         ok = ok and okb
     tgt = rs.uniform(-50, 100, (N, H, W)).astype(np.float32)
     if ops.sphere_raster_mse_supported(dev(sp), dev(tgt), H, W):
@@ -338,10 +347,67 @@ def pl_case():
         fails += 1
         print("PAIR-LOSS MISMATCH", dict(B=B, V=V), col.item(), ca.item(), bone.item(), ba.item(), (b.grad - a.grad).abs().max().item(), a.grad.abs().max().item())
 
-for name, fn in (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case), ("mv", mv_case), ("sa", sa_case), ("pl", pl_case), ("lbs", lbs_case), ("hm", hm_case)):
-    if len(sys.argv) > 3 and name not in sys.argv[3].split(","): continue
-    t0 = time.time(); n = 0
-    while time.time() - t0 < budget:
-        fn(); n += 1
-    print("%s: %d cases, %d mismatches so far" % (name, n, fails))
-sys.exit(1 if fails else 0)
+def ks_case():
+    """key-point skinning -> sphere records (keypoint_skin.hip) against the torch ops of the same module, both directions"""
+    global fails, _fk
+    from spherehand_amd import hand_model
+    from spherehand_amd.render import HandBallPrimitiveRender
+    if _fk is None:
+        fk_case()
+    if "hbr" not in _hm:
+        _hm["hbr"] = HandBallPrimitiveRender(hand_model.load_mesh()["bones"], 64, 64).cuda()
+    hbr = _hm["hbr"]
+    B = int(rs.randint(1, 70))
+    p = (rs.uniform(-1, 1, (B, 26)) * rs.choice([0.3, 1.5, 3.0])).astype(np.float32); p[:, 3:6] = rs.uniform(-60, 60, (B, 3))
+    T1 = _fk(dev(p)).detach().requires_grad_(True)
+    T2 = T1.detach().clone().requires_grad_(True)
+    sph = hbr.spheres(T1)
+    pts = hbr.lbs(T2)
+    ref = torch.cat([pts[:, :, 0:3], hbr.radiuses.expand(B, -1).unsqueeze(-1)], dim=2)
+    G = dev(rs.standard_normal((B, 41, 4)).astype(np.float32))
+    (sph * G).sum().backward(); (ref * G).sum().backward()
+    ok = (sph - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item()) + 2e-5 and \
+        (T1.grad - T2.grad).abs().max().item() <= 2e-6 * max(1.0, T2.grad.abs().max().item())
+    if not ok:
+        fails += 1
+        print("KEYPOINT-SPHERES MISMATCH", dict(B=B), (sph - ref).abs().max().item(), (T1.grad - T2.grad).abs().max().item())
+
+
+FAMILIES = (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case),
+            ("mv", mv_case), ("sa", sa_case), ("pl", pl_case), ("lbs", lbs_case), ("hm", hm_case), ("ks", ks_case))
+
+
+def reset_tuning():
+    """the sphere family varies the launch shapes through shr_set_tuning: back to the launcher's choices"""
+    for key, val in ((ops.TUNE_FORCE_GENERAL, 0), (ops.TUNE_FWD_LDS_BYTES, 80 * 1024), (ops.TUNE_FWD_OWNER_LDS_BYTES, 0),
+                     (ops.TUNE_BWD_LDS_BYTES, 128 * 1024), (ops.TUNE_FWD_WAVES, 16), (ops.TUNE_FWD_ZBUF_BYTES, 0),
+                     (ops.TUNE_BWD_WAVES, 0), (ops.TUNE_MSE_BOX, -1)):
+        ops.set_tuning(key, val)
+
+
+def run(families=None, cases=None, seconds=None, seed=0, log=print):
+    """Each family until `cases` cases or `seconds` seconds (whichever comes first; None = unbounded by that measure).
+    Returns {family: (cases run, mismatches)}."""
+    global rs, fails
+    rs = np.random.RandomState(seed)
+    out = {}
+    try:
+        for name, fn in FAMILIES:
+            if families and name not in families:
+                continue
+            before, t0, n = fails, time.time(), 0
+            while (cases is None or n < cases) and (seconds is None or time.time() - t0 < seconds):
+                fn(); n += 1
+            out[name] = (n, fails - before)
+            log("%s: %d cases in %.1f s, %d mismatches" % (name, n, time.time() - t0, fails - before))
+    finally:
+        reset_tuning()
+    return out
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+    res = run(sys.argv[3].split(",") if len(sys.argv) > 3 else None, None, budget, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print("TOTAL: %d cases over %d families, %d mismatches (seed %s, %.0f s per family)"
+          % (sum(n for n, _ in res.values()), len(res), sum(m for _, m in res.values()), sys.argv[2] if len(sys.argv) > 2 else "0", budget))
+    sys.exit(1 if fails else 0)
