@@ -47,6 +47,16 @@ namespace shr {
 constexpr int kD2mK = 4;                    // points per lane per search
 constexpr int kD2mGroup = 64 * kD2mK;       // entries per full search
 constexpr int kD2mCap = 512;                // ring entries per wave (< 256 left over + <= 256 new per unit)
+// The ring is stored TRANSPOSED: entry e sits in row e & 3, column (e >> 2) & 127 of a [4][128 + pad] array.  A search
+// reads entries head + 4 l + i for lane l: row (head + i) & 3, columns consecutive in l -- one conflict-free
+// ds_read_b64 per point, where the linear layout put a lane's four entries 32 bytes from the next lane's (every
+// eighth lane on the same banks).  The append writes entries consecutive in pixel order: the four of a dense lane
+// go to the four rows at one column, the rows' pitch shifts them by 16 banks each.
+constexpr int kD2mTables = 4;
+constexpr int kD2mTableStride = SHR_MAX_SPHERES * 4 + 2;   // u64 per copy (+ 16 bytes)
+constexpr int kD2mRingCols = kD2mCap / 4;
+constexpr int kD2mRingPitch = kD2mRingCols + 8;   // uint2 per row (+ 64 bytes: rows start 16 banks apart)
+__device__ __forceinline__ int d2m_slot(int e) { return (e & 3) * kD2mRingPitch + ((e >> 2) & (kD2mRingCols - 1)); }
 constexpr float kLossScale = 1048576.f;     // 2^20: loss in units of 2^-20 mm (e <= 50 -> < 2^26 per point)
 constexpr float kGradScale = 67108864.f;    // 2^26 per unit-vector component
 
@@ -74,8 +84,12 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
   __shared__ float4 s_c[SHR_MAX_SPHERES];                 // (cx, cy, cz, r)
   __shared__ int s_odd, s_nan;                            // non-finite sphere table / a NaN loss term
   __shared__ unsigned long long s_loss;                   // fixed-point loss sum
-  __shared__ unsigned long long s_acc[WANT_GRAD ? SHR_MAX_SPHERES * 4 : 1];   // fixed-point gradient rows [sphere][x,y,z,-]
-  __shared__ uint2 s_q[WAVES][kD2mCap];                   // per-wave rings of foreground pixels
+  // fixed-point gradient rows [table][sphere][x,y,z,-]: kD2mTables copies, a lane adds into copy lane & (kD2mTables - 1).
+  // Neighbouring lanes hold neighbouring pixels -- mostly one owner -- and a 64-bit LDS atomic is serialised over the
+  // lanes that share its ADDRESS (SQ_LDS_ADDR_CONFLICT was 3/4 of the kernel's bank-conflict cycles with one table);
+  // the copies start 4 banks apart.  Integer sums: adding the copies at the end changes nothing in the result.
+  __shared__ unsigned long long s_acc[WANT_GRAD ? kD2mTables * kD2mTableStride : 1];
+  __shared__ uint2 s_q[WAVES][4 * kD2mRingPitch];         // per-wave rings of foreground pixels (transposed: d2m_slot)
   __shared__ int s_next_band;                             // bands are handed out dynamically (see below)
   __shared__ int s_bandq[WAVES][8];                       // per wave: bands its loads have entered, not yet processed
 
@@ -94,7 +108,7 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
     if (lane == 0) { s_odd = any; s_nan = 0; s_loss = 0ull; s_next_band = WAVES; }
   }
   if (WANT_GRAD)
-    for (int i = tid; i < SHR_MAX_SPHERES * 4; i += WAVES * 64) s_acc[i] = 0ull;
+    for (int i = tid; i < kD2mTables * kD2mTableStride; i += WAVES * 64) s_acc[i] = 0ull;
   __syncthreads();
   const bool table_odd = s_odd != 0;
   // lanes = spheres: this lane's record for the box bounds
@@ -132,7 +146,7 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
     for (int i = 0; i < K; i++) {
       const int idx = K * lane + i;
       valid[i] = idx < count;
-      const uint2 e = ring[(head + (valid[i] ? idx : 0)) & (kD2mCap - 1)];
+      const uint2 e = ring[d2m_slot(head + (valid[i] ? idx : 0))];
       px[i] = axis_coord(ax, (int)(e.x & 0xffffu));
       py[i] = axis_coord(ay, (int)(e.x >> 16));
       pz[i] = __uint_as_float(e.y);
@@ -158,8 +172,8 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
 #endif
       // All inputs finite: no NaN can arise (an overflowing distance is +inf).  Strip bounds with
       // lanes = spheres: rows of the first / last entry (pixel order inside a band).
-      const int v_lo = __builtin_amdgcn_readfirstlane((int)(ring[head & (kD2mCap - 1)].x >> 16));
-      const int v_hi = __builtin_amdgcn_readfirstlane((int)(ring[(head + count - 1) & (kD2mCap - 1)].x >> 16));
+      const int v_lo = __builtin_amdgcn_readfirstlane((int)(ring[d2m_slot(head)].x >> 16));
+      const int v_hi = __builtin_amdgcn_readfirstlane((int)(ring[d2m_slot(head + count - 1)].x >> 16));
       const float y_lo = axis_coord(ay, v_lo), y_hi = axis_coord(ay, v_hi);
       // <= | ||p - c_j|| - r_j | for every point of the strip, up to the rounding the margins below cover
       const float lb = fmaxf(fmaxf(y_lo - cj.y, cj.y - y_hi), 0.f) - cj.w;
@@ -269,7 +283,7 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
 #pragma unroll
       for (int i = 0; i < K; i++) {
         if (live[i]) {
-          unsigned long long *row = s_acc + bj[i] * 4;
+          unsigned long long *row = s_acc + (lane & (kD2mTables - 1)) * kD2mTableStride + bj[i] * 4;
 #ifdef EXP_NOATOMIC
           s_acc[tid & 255] = (unsigned long long)(g[i][0] + g[i][1] + g[i][2]);
           if (J < 0)
@@ -356,7 +370,7 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
       for (int c = 0; c < 4; c++) {
         while (uc >= W) { uc -= W; vc++; }      // never taken when W % 4 == 0
         if (fg[c]) {
-          ring[pos & (kD2mCap - 1)] = make_uint2(((unsigned)vc << 16) | (unsigned)uc, __float_as_uint(z0[c]));
+          ring[d2m_slot(pos)] = make_uint2(((unsigned)vc << 16) | (unsigned)uc, __float_as_uint(z0[c]));
           pos++;
         }
         uc++;
@@ -399,7 +413,10 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
     loss_sum[blockIdx.x] = s_nan ? __builtin_nanf("") : (float)((double)(long long)s_loss * (1.0 / (double)kLossScale));
   if (WANT_GRAD && tid < J * 3) {
     const int j = tid / 3, c = tid - j * 3;
-    grad_centres[(size_t)blockIdx.x * J * 3 + tid] = (float)((double)(long long)s_acc[j * 4 + c] * (1.0 / (double)kGradScale));
+    long long t = 0;
+#pragma unroll
+    for (int k = 0; k < kD2mTables; k++) t += (long long)s_acc[k * kD2mTableStride + j * 4 + c];
+    grad_centres[(size_t)blockIdx.x * J * 3 + tid] = (float)((double)t * (1.0 / (double)kGradScale));
   }
 }
 
