@@ -105,8 +105,48 @@ __device__ __forceinline__ FaceSetup face_setup_sorted(const float4 *__restrict_
   return s;
 }
 
-constexpr int kMeshQueue = 3584;   // work items per round (14 KB next to the 66-KB slot array: two workgroups per CU)
+constexpr int kMeshQueue = 3584;   // work items per round (14 KB next to the 66-KB slot array)
 constexpr int kMeshFaces = 4;      // faces per thread and round (one round for the 3382-face hand mesh)
+// Everything phase B needs of a face, computed ONCE in phase A (lanes = faces) and parked in LDS: the sorted
+// vertices, the inverse barycentric matrix (9 IEEE divisions, .cu:62-66) and the three edge slopes (.cu:75-85; the
+// reference divides per column, the quotient depends on the face only), so that a work item -- one sampled column
+// of a face, ~3 per face -- starts from six 16-byte LDS reads instead of a vertex gather, the sort and 12 divisions
+// (DepthRender B = 256, S = 128: 59 -> 3x us, round 3).  A face beyond the table's capacity keeps the old path
+// (its items carry the face index and recompute): any mesh stays exact.
+constexpr int kMeshRows = 768;
+struct __attribute__((aligned(16))) FaceRow {
+  float fi[9];        // inverse barycentric matrix / den
+  float s01, s12, s02;   // (y1 - y0) / (x1 - x0), (y2 - y1) / (x2 - x1), (y2 - y0) / (x2 - x0)
+  float x0, y0, x1, y1;  // sorted vertices 0 and 1 (the spans' base points)
+  float z0, z1, z2;
+  int xr;             // xi_min | xi_max << 16
+  int yr;             // r_lo | r_hi << 16
+  int flags;          // bit 0: x1 - x0 != 0, bit 1: x2 - x1 != 0
+  int pad[2];
+};
+static_assert(sizeof(FaceRow) == 96, "six 16-byte reads per work item");
+
+__device__ __forceinline__ FaceRow face_row(const FaceSetup &fs) {
+  const float (&p)[3][3] = fs.p;
+  FaceRow r;
+  r.fi[0] = p[1][1] - p[2][1]; r.fi[1] = p[2][0] - p[1][0]; r.fi[2] = p[1][0] * p[2][1] - p[2][0] * p[1][1];
+  r.fi[3] = p[2][1] - p[0][1]; r.fi[4] = p[0][0] - p[2][0]; r.fi[5] = p[2][0] * p[0][1] - p[0][0] * p[2][1];
+  r.fi[6] = p[0][1] - p[1][1]; r.fi[7] = p[1][0] - p[0][0]; r.fi[8] = p[0][0] * p[1][1] - p[1][0] * p[0][1];
+  const float den = (p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1])) + p[1][0] * (p[2][1] - p[0][1]);
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.fi[k] = r.fi[k] / den;
+  const bool d01 = p[1][0] - p[0][0] != 0.f, d12 = p[2][0] - p[1][0] != 0.f;
+  r.s01 = d01 ? (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) : 0.f;
+  r.s12 = d12 ? (p[2][1] - p[1][1]) / (p[2][0] - p[1][0]) : 0.f;
+  r.s02 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]);
+  r.x0 = p[0][0]; r.y0 = p[0][1]; r.x1 = p[1][0]; r.y1 = p[1][1];
+  r.z0 = p[0][2]; r.z1 = p[1][2]; r.z2 = p[2][2];
+  r.xr = fs.xi_min | (fs.xi_max << 16);   // (source sizes up to 32767: the launcher checks)
+  r.yr = fs.r_lo | (fs.r_hi << 16);
+  r.flags = (d01 ? 1 : 0) | (d12 ? 2 : 0);
+  r.pad[0] = r.pad[1] = 0;
+  return r;
+}
 
 // TO = output pixels per tile side, SL = source slots per output pixel and axis: 1 when the
 // resize ratio is an odd integer (the bilinear weights are exactly (1, 0): S = 128 from
@@ -126,7 +166,8 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
                   int S, float clamp_max, float *__restrict__ depth) {
   __shared__ uint32_t s_z[SL * TO][SL * TO + 1];   // [SL*dy + sy][SL*dx + sx], +1: bank spread
   __shared__ int s_queue[kMeshQueue];
-  __shared__ int s_wave_cnt[16];
+  __shared__ int s_wave_cnt[16], s_next_item;
+  __shared__ FaceRow s_rows[kMeshRows];
   const int b = blockIdx.y;
   const int tiles = (S + TO - 1) / TO;
   const int ty0 = (blockIdx.x / tiles) * TO, tx0 = (blockIdx.x % tiles) * TO;
@@ -155,11 +196,21 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
     return (l.l0 != 0.f && l.i0 >= lo && l.i0 <= hi) || (SL == 2 && l.l1 != 0.f && l.i1 >= lo && l.i1 <= hi);
   };
 
+  // SL == 1 (odd integer ratio R): output index d samples source index R d + h, h = (R - 1) / 2, with weight exactly 1
+  // (lin_index's fma is exact there), so "the output pixels whose sample falls in [lo, hi]" is a closed form instead of
+  // a loop over candidates: d in [ceil((lo - h) / R), floor((hi - h) / R)].  (x + 0.5) * (1 / R) is at least 0.5 / R
+  // from an integer and the product's error below 1e-4 for |x| < 2^15: the floor is exact.
+  const int ratio = src / S, half_r = (ratio - 1) >> 1;
+  const float rcp_r = 1.0f / (float)ratio;
+  auto fdiv = [&](int x) { return (int)floorf(((float)x + 0.5f) * rcp_r); };   // floor(x / R), x may be negative
+  auto first_out = [&](int lo, int t0) { return max(t0, fdiv(lo - half_r + ratio - 1)); };
+  auto last_out = [&](int hi, int t0) { return min(min(t0 + TO, S) - 1, fdiv(hi - half_r)); };
+
   for (int f0 = 0; f0 < F; f0 += 1024 * kMeshFaces) {
     // ---- A. cull, count work items, block scan ---------------------------------------------
     int nk[kMeshFaces], dx0[kMeshFaces];
     unsigned colmask[kMeshFaces];   // bit i: output column dx0 + i holds a sampled source column of the face
-    int n = 0;
+    int n = 0, nrow = 0;
 #pragma unroll
     for (int k = 0; k < kMeshFaces; k++) {
       const int f = f0 + k * 1024 + tid;
@@ -167,6 +218,14 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
       if (f < F) {
         const FaceSetup fs = face_setup_sorted(verts, faces, f, src);
         if (fs.live && !(fs.xi_max < tlx.i0 || fs.xi_min > thx.i1 || fs.r_hi < tly.i0 || fs.r_lo > thy.i1)) {
+          if (SL == 1) {   // closed forms: every output column / row in the range samples the box
+            const int dx_lo = first_out(fs.xi_min, tx0), dx_hi = last_out(fs.xi_max, tx0);
+            if (dx_lo <= dx_hi && first_out(fs.r_lo, ty0) <= last_out(fs.r_hi, ty0)) {
+              dx0[k] = dx_lo;
+              nk[k] = dx_hi - dx_lo + 1;
+              colmask[k] = nk[k] >= 32 ? 0xffffffffu : ((1u << nk[k]) - 1u);
+            }
+          } else {
           const int dx_lo = out_lo(fs.xi_min, tx0), dx_hi = out_hi(fs.xi_max, tx0);
           bool cx = false, cy = false;   // any sampled column AND any sampled row inside the box?
           for (int dx = dx_lo; dx <= dx_hi && !cx; dx++) cx = samples(dx, fs.xi_min, fs.xi_max);
@@ -179,10 +238,14 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
               if (c && dx - dx_lo < 32) colmask[k] |= 1u << (dx - dx_lo);
             }
           }
+          }
         }
       }
       n += nk[k];
+      nrow += nk[k] > 0;
     }
+    // (work items and surviving faces share one scan: the face count rides in the upper half)
+    n |= nrow << 20;
     int incl = n;   // inclusive scan over the workgroup: DPP inside rows of 16, SGPR row totals, LDS wave totals
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
@@ -203,6 +266,28 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
       if (w < wave) off += c;
       total += c;
     }
+    int row = off >> 20;                       // this thread's first row in the face table
+    off &= 0xfffff; total &= 0xfffff; n &= 0xfffff;
+    // ---- the surviving faces' rows: lanes = SURVIVORS (a quarter of the faces: computed where they were found, every
+    // wave would run the divisions for each of its four face slots at a quarter of its lanes) -------------------
+    int rowk[kMeshFaces];
+    const int nrows = min(kMeshRows, (int)((unsigned)s_wave_cnt[15] >> 20) + 0 * row);
+    int total_rows = 0;
+    for (int w = 0; w < 16; w++) total_rows += (int)((unsigned)s_wave_cnt[w] >> 20);
+#pragma unroll
+    for (int k = 0; k < kMeshFaces; k++) {
+      rowk[k] = -1;
+      if (nk[k] == 0) continue;
+      if (row < kMeshRows) {
+        rowk[k] = row;
+        s_rows[row].pad[0] = f0 + k * 1024 + tid;      // the face of this row (the row itself follows)
+      }
+      row++;
+    }
+    __syncthreads();
+    (void)nrows;
+    for (int r = tid; r < min(kMeshRows, total_rows); r += blockDim.x)
+      s_rows[r] = face_row(face_setup_sorted(verts, faces, s_rows[r].pad[0], src));
     for (int w0 = 0; w0 < total; w0 += kMeshQueue) {
       if (w0 > 0) __syncthreads();
       {
@@ -211,76 +296,81 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
         for (int k = 0; k < kMeshFaces; k++) {
           if (nk[k] == 0) continue;
           const int f = f0 + k * 1024 + tid;
+          // an item = (row in the face table, or face index | bit 31 beyond its capacity) << 7 | output column
+          const int tag = rowk[k] >= 0 ? rowk[k] << 7 : (int)(0x80000000u | ((unsigned)f << 7));
           for (unsigned m = colmask[k]; m; m &= m - 1, slot++)
-            if (slot >= 0 && slot < kMeshQueue) s_queue[slot] = (f << 7) | (dx0[k] + __builtin_ctz(m) - tx0);
+            if (slot >= 0 && slot < kMeshQueue) s_queue[slot] = tag | (dx0[k] + __builtin_ctz(m) - tx0);
           if (nk[k] > __builtin_popcount(colmask[k])) {   // a face wider than 32 output columns: the rest by re-enumeration
             const FaceSetup fs = face_setup_sorted(verts, faces, f, src);
-            const int dx_hi = out_hi(fs.xi_max, tx0);
+            const int dx_hi = SL == 1 ? last_out(fs.xi_max, tx0) : out_hi(fs.xi_max, tx0);
             for (int dx = dx0[k] + 32; dx <= dx_hi; dx++)
-              if (column_slots(dx, fs.xi_min, fs.xi_max)) {
-                if (slot >= 0 && slot < kMeshQueue) s_queue[slot] = (f << 7) | (dx - tx0);
+              if (SL == 1 || column_slots(dx, fs.xi_min, fs.xi_max)) {
+                if (slot >= 0 && slot < kMeshQueue) s_queue[slot] = tag | (dx - tx0);
                 slot++;
               }
           }
         }
       }
+      if (tid == 0) s_next_item = 0;
       __syncthreads();
       // ---- B. rasterize the queued items (order is irrelevant: integer minima) ---------------
+      // (64 items at a time from a counter: consecutive items are one face's columns and neighbouring faces -- with a
+      // static stride the wave that holds the crop's large faces finished at 33 k cycles against a mean of 26 k)
       const int count = min(kMeshQueue, total - w0);
-      for (int q = tid; q < count; q += blockDim.x) {
+      for (;;) {
+        int q0 = 0;
+        if (lane == 0) q0 = atomicAdd(&s_next_item, 64);
+        q0 = __builtin_amdgcn_readfirstlane(q0);
+        if (q0 >= count) break;
+        const int q = q0 + lane;
+        if (q >= count) continue;
         const int item = s_queue[q];
-        const FaceSetup fs = face_setup_sorted(verts, faces, item >> 7, src);
-        const float (&p)[3][3] = fs.p;
-        const int xi_min = fs.xi_min, xi_max = fs.xi_max;
-        float fi[9];
-        fi[0] = p[1][1] - p[2][1]; fi[1] = p[2][0] - p[1][0]; fi[2] = p[1][0] * p[2][1] - p[2][0] * p[1][1];
-        fi[3] = p[2][1] - p[0][1]; fi[4] = p[0][0] - p[2][0]; fi[5] = p[2][0] * p[0][1] - p[0][0] * p[2][1];
-        fi[6] = p[0][1] - p[1][1]; fi[7] = p[1][0] - p[0][0]; fi[8] = p[0][0] * p[1][1] - p[1][0] * p[0][1];
-        const float den = (p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1])) + p[1][0] * (p[2][1] - p[0][1]);
-#pragma unroll
-        for (int k = 0; k < 9; k++) fi[k] = fi[k] / den;
-        const int dy_lo = out_lo(fs.r_lo, ty0), dy_hi = out_hi(fs.r_hi, ty0);
+        FaceRow r;
+        if (item >= 0) r = s_rows[item >> 7];
+        else r = face_row(face_setup_sorted(verts, faces, (int)(((unsigned)item & 0x7fffffffu) >> 7), src));
+        const int xi_min = r.xr & 0xffff, xi_max = r.xr >> 16;
+        const int dy_lo = out_lo(r.yr & 0xffff, ty0), dy_hi = out_hi(r.yr >> 16, ty0);
         {
           const int dx = tx0 + (item & 127);
-          const Lin lx = lin_index(dx, scale, src);
+          Lin lx;
+          if (SL == 1) { lx.i0 = lx.i1 = ratio * dx + half_r; lx.l0 = 1.f; lx.l1 = 0.f; }
+          else lx = lin_index(dx, scale, src);
 #pragma unroll
           for (int sx = 0; sx < SL; sx++) {
             const int xi = sx ? lx.i1 : lx.i0;
-            if ((sx ? lx.l1 : lx.l0) == 0.f || xi < xi_min || xi > xi_max) continue;
-            // ---- column span (.cu:72-90) -------------------------------------------------
+            if (SL != 1 && ((sx ? lx.l1 : lx.l0) == 0.f || xi < xi_min || xi > xi_max)) continue;
+            // ---- column span (.cu:72-90; the slopes are the face's) --------------------------
             const float xf = (float)xi;
             float yi1;
-            if (xf <= p[1][0]) {
-              if (p[1][0] - p[0][0] != 0.f) yi1 = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (xf - p[0][0]) + p[0][1];
-              else yi1 = p[1][1];
-            } else {
-              if (p[2][0] - p[1][0] != 0.f) yi1 = (p[2][1] - p[1][1]) / (p[2][0] - p[1][0]) * (xf - p[1][0]) + p[1][1];
-              else yi1 = p[1][1];
-            }
-            const float yi2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * (xf - p[0][0]) + p[0][1];
+            if (xf <= r.x1) yi1 = (r.flags & 1) ? r.s01 * (xf - r.x0) + r.y0 : r.y1;
+            else yi1 = (r.flags & 2) ? r.s12 * (xf - r.x1) + r.y1 : r.y1;
+            const float yi2 = r.s02 * (xf - r.x0) + r.y0;
             const int yi_min = m_cvt_rz_sat(fmaxf(0.f, ceilf(fminf(yi1, yi2))));
             const int yi_max = m_cvt_rz_sat(fminf(fmaxf(yi1, yi2), (float)src - 1.f));
-            // (only the output rows whose slots can fall inside the column's span)
-            const int ry_lo = yi_min > yi_max ? 1 : max(dy_lo, out_lo(yi_min, ty0));
-            const int ry_hi = yi_min > yi_max ? 0 : min(dy_hi, out_hi(yi_max, ty0));
+            // (only the output rows whose slots can fall inside the column's span; SL == 1: exactly the rows that
+            // sample it, by the closed form -- the span lies inside the face's rows)
+            const int ry_lo = yi_min > yi_max ? 1 : (SL == 1 ? first_out(yi_min, ty0) : max(dy_lo, out_lo(yi_min, ty0)));
+            const int ry_hi = yi_min > yi_max ? 0 : (SL == 1 ? last_out(yi_max, ty0) : min(dy_hi, out_hi(yi_max, ty0)));
             for (int dy = ry_lo; dy <= ry_hi; dy++) {
-              const Lin ly = lin_index(dy, scale, src);
+              Lin ly;
+              if (SL == 1) { ly.i0 = ly.i1 = ratio * dy + half_r; ly.l0 = 1.f; ly.l1 = 0.f; }
+              else ly = lin_index(dy, scale, src);
 #pragma unroll
               for (int sy = 0; sy < SL; sy++) {
                 const int yi = sy ? ly.i1 : ly.i0;
-                if ((sy ? ly.l1 : ly.l0) == 0.f || yi < yi_min || yi > yi_max) continue;
+                if (SL != 1 && ((sy ? ly.l1 : ly.l0) == 0.f || yi < yi_min || yi > yi_max)) continue;
                 // ---- pixel (.cu:97-110) ----------------------------------------------------
                 const float yf = (float)yi;
                 float w[3], w_sum = 0.f;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                  w[k] = (fi[3 * k] * xf + fi[3 * k + 1] * yf) + fi[3 * k + 2];
+                  w[k] = (r.fi[3 * k] * xf + r.fi[3 * k + 1] * yf) + r.fi[3 * k + 2];
                   w[k] = fminf(fmaxf(w[k], 0.f), 1.f);
                   w_sum += w[k];
                 }
 #pragma unroll
                 for (int k = 0; k < 3; k++) w[k] = w[k] / w_sum;
-                const float zp = 1.0f / ((w[0] / p[0][2] + w[1] / p[1][2]) + w[2] / p[2][2]);
+                const float zp = 1.0f / ((w[0] / r.z0 + w[1] / r.z1) + w[2] / r.z2);
                 if (zp == zp) atomicMin(&s_z[SL * (dy - ty0) + sy][SL * (dx - tx0) + sx], mkey(zp));
               }
             }
@@ -293,6 +383,21 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
 
   // ---- clamp + bilinear (mesh/render.py:286, :311; ATen upsample_bilinear2d) ---------------
   float *out = depth + (size_t)b * S * S;
+  if (SL == 1 && (S & 3) == 0 && (TO & 3) == 0) {
+    // four pixels per thread, one 16-byte write-through store (the map is read next by another kernel: left dirty in
+    // the L2 it would be flushed by the end-of-kernel write-back, sphere_zbuf.h)
+    typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+    for (int i = tid; i < TO * TO / 4; i += blockDim.x) {
+      const int oy = i / (TO / 4), ox = (i - oy * (TO / 4)) * 4;
+      const int y = ty0 + oy, x = tx0 + ox;
+      if (y >= S || x >= S) continue;
+      v4u_t v;
+#pragma unroll
+      for (int c = 0; c < 4; c++) v[c] = __float_as_uint(fminf(mkey_inv(s_z[oy][ox + c]), clamp_max));
+      float *dst = out + (size_t)y * S + x;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+    }
+  } else
   for (int i = tid; i < TO * TO; i += blockDim.x) {
     const int oy = i / TO, ox = i - oy * TO;
     const int y = ty0 + oy, x = tx0 + ox;
@@ -320,8 +425,8 @@ extern "C" int shr_mesh_depth_fwd(const float *vertices, const int32_t *faces, i
   if (!vertices || (!faces && F > 0) || !depth || B < 0 || NV <= 0 || F < 0 || src_size <= 0 || S <= 0)
     return SHR_EINVAL;
   if (((uintptr_t)vertices & 15u) != 0) return SHR_EINVAL;
-  if (B > 65535 || S > 16384 || src_size > (1 << 20) || S > src_size || F > (1 << 24))
-    return SHR_ETOOLARGE;  // no up-sampling; work items pack the face index in 25 bits
+  if (B > 65535 || S > 16384 || src_size > 32767 || S > src_size || F > (1 << 24))
+    return SHR_ETOOLARGE;  // no up-sampling; work items pack the face index in 24 bits, the face rows pixel ranges in 16
   hipStream_t s = (hipStream_t)stream;
   const float4 *v4 = reinterpret_cast<const float4 *>(vertices);
   // odd integer ratio: src = ratio * d + (ratio - 1) / 2 exactly, bilinear weights (1, 0)
