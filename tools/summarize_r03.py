@@ -1,7 +1,7 @@
-"""gpurun_out/r02 (tools/collect_profiles_r02.sh) -> profiles/r02_*: python tools/summarize_r02.py"""
+"""gpurun_out/r03 (tools/collect_profiles_r03.sh) -> profiles/r03_*: python tools/summarize_r03.py"""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-O = os.path.join(ROOT, "gpurun_out", "r02")
+O = os.path.join(ROOT, "gpurun_out", "r03")
 P = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 
@@ -15,12 +15,36 @@ def shr_rows(src, dst, keep=lambda name: True):
                 w.writerow([r[0].split("(")[0][:120]] + r[1:])
 
 ours = lambda n: "shr::" in n or "group_norm" in n
-shr_rows(os.path.join(O, "stats_headline", "bench_kernel_stats.csv"), os.path.join(P, "r02_bench_kernel_stats.csv"))
-shr_rows(os.path.join(O, "stats", "bench_kernel_stats.csv"), os.path.join(P, "r02_secondary_kernel_stats.csv"), ours)
-for n in ("bench_line.json", "bench_line_graph.json"):
-    shutil.copy(os.path.join(O, n), os.path.join(P, "r02_" + n))
+shr_rows(os.path.join(O, "stats_headline", "bench_kernel_stats.csv"), os.path.join(P, "r03_bench_kernel_stats.csv"))
+shr_rows(os.path.join(O, "stats", "bench_kernel_stats.csv"), os.path.join(P, "r03_secondary_kernel_stats.csv"), ours)
+for n in ("bench_line.json", "bench_line_graph.json", "bench_line_steps20.json"):
+    shutil.copy(os.path.join(O, n), os.path.join(P, "r03_" + n))
+# per-launch durations of the headline kernels from the trace: mean, median, quartiles (>= 2000 launches each)
+import statistics
+dur = collections.defaultdict(list)
+for f in glob.glob(os.path.join(O, "stats_headline", "*kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "sphere_zbuf" in k:
+            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+med = {}
+for k, v in dur.items():
+    v.sort()
+    med[k] = {"launches": len(v), "mean_us": round(statistics.mean(v), 3), "median_us": round(statistics.median(v), 3),
+              "p25_us": round(v[len(v) // 4], 3), "p75_us": round(v[3 * len(v) // 4], 3), "min_us": round(v[0], 3)}
+med["_note"] = ("rocprofv3 --kernel-trace --stats -- python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-secondary: "
+                "End - Start of every launch of the two headline kernels (the traced process's own HIP-event means are in "
+                "its JSON line, gpurun_out/r03/stats_headline.log)")
+try:
+    line = [l for l in open(os.path.join(O, "stats_headline.log")) if l.startswith("{")][-1]
+    med["traced_process_hip_event_us"] = json.loads(line)["roofline"]["launch_us"]
+except Exception as e:      # noqa
+    med["traced_process_hip_event_us"] = None
+json.dump(med, open(os.path.join(P, "r03_headline_launch_durations.json"), "w"), indent=1)
+if os.path.exists(os.path.join(O, "fuzz.log")):
+    shutil.copy(os.path.join(O, "fuzz.log"), os.path.join(P, "r03_fuzz_summary.txt"))
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), os.path.join(O, "pmc_fetch"),
-                       os.path.join(O, "pmc_write"), os.path.join(P, "r02_pmc_traffic.json"), "sphere_zbuf_fwd_kernel",
+                       os.path.join(O, "pmc_write"), os.path.join(P, "r03_pmc_traffic.json"), "sphere_zbuf_fwd_kernel",
                        "sphere_zbuf_bwd_kernel"], stdout=subprocess.DEVNULL)
 # SQ counters: per kernel, mean per launch over every launch of every pass that saw it
 sq = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -50,12 +74,16 @@ for k, cs in sorted(sq.items()):
                              "SALU_instructions": round(m.get("SQ_INSTS_SALU", 0) / m["SQ_WAVES"], 1),
                              "LDS_instructions": round(m.get("SQ_INSTS_LDS", 0) / m["SQ_WAVES"], 1),
                              "lifetime_cycles (4 x WAVE_CYCLES / WAVES)": round(4 * wc / m["SQ_WAVES"], 0)}
+    if m.get("SQ_ACTIVE_INST_LDS"):
+        d["lds_bank_conflict / active_inst_lds"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0) / m["SQ_ACTIVE_INST_LDS"], 3)
+        if "SQ_WAIT_INST_LDS" in m and "SQ_WAVE_CYCLES" in m and m["SQ_WAVE_CYCLES"]:
+            d["wait_inst_lds / wave_cycles"] = round(m["SQ_WAIT_INST_LDS"] / m["SQ_WAVE_CYCLES"], 4)
     if "FETCH_SIZE" in m:
         d["hbm_read_bytes_per_launch (2 x FETCH_SIZE KB, gfx950 half-count)"] = int(2 * m["FETCH_SIZE"] * 1024)
     out[k] = d
-out["_note"] = ("rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes, sets A and B of tools/collect_profiles_r02.sh) on "
+out["_note"] = ("rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes, sets A and B of tools/collect_profiles_r03.sh) on "
                 "bench.py (--no-secondary: the headline kernels at batch 256; with the secondary set: every other kernel) and on "
                 "tools/prof_d2m.py (1152 crops, S = 128 / 256).  SQ_*_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles "
                 "summed over all waves; a kernel seen at several problem sizes is split by grid size.")
-json.dump(out, open(os.path.join(P, "r02_sq_counters.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(P, "r03_sq_counters.json"), "w"), indent=1)
 print(json.dumps({k: v.get("share_of_wave_cycles") for k, v in out.items() if isinstance(v, dict)}, indent=1))
