@@ -163,13 +163,7 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
         best[i] = lt ? a : best[i];
       }
     };
-#ifdef EXP_NOSEARCH
-#pragma unroll
-    for (int i = 0; i < K; i++) { best[i] = px[i] + py[i] + pz[i]; bj[i] = 0; }
-    if (J < 0) {
-#else
     if (!table_odd && __ballot(zbad) == 0ull) {
-#endif
       // All inputs finite: no NaN can arise (an overflowing distance is +inf).  Strip bounds with
       // lanes = spheres: rows of the first / last entry (pixel order inside a band).
       const int v_lo = __builtin_amdgcn_readfirstlane((int)(ring[d2m_slot(head)].x >> 16));
@@ -179,9 +173,6 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
       const float lb = fmaxf(fmaxf(y_lo - cj.y, cj.y - y_hi), 0.f) - cj.w;
       unsigned long long m1 = __ballot(!(lb > 1e-3f)) & all;     // the sphere's y extent meets the strip (or nearly)
       if (m1 == 0ull) m1 = all;
-#ifdef EXP_BRUTE
-      m1 = all;
-#endif
 #pragma unroll
       for (int i = 0; i < K; i++) { best[i] = __builtin_inff(); bj[i] = 0; }
       // stage 1, ascending j, strict '<': ties keep the first index (torch.min's convention).
@@ -206,9 +197,6 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
       // stage 2: what could still win or tie.  A point whose minimum stays above 50 is worth exactly 50
       // with no gradient whatever the owner, so 50 caps the reach.
       unsigned long long m2 = all & ~m1;
-#ifdef EXP_STAGE1ONLY
-      m2 = 0;
-#endif
       if (m2) {
         float wmax = -__builtin_inff();
 #pragma unroll
@@ -231,11 +219,7 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
         }
       }
     }
-#ifdef EXP_NOSEARCH
-    else if (J < 0) {
-#else
     else {
-#endif
       // a NaN / infinity somewhere: every sphere in index order with torch.min's NaN rule
       for (int j = 0; j < J; j++) {
         const float4 c = s_c[j];
@@ -284,15 +268,9 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
       for (int i = 0; i < K; i++) {
         if (live[i]) {
           unsigned long long *row = s_acc + (lane & (kD2mTables - 1)) * kD2mTableStride + bj[i] * 4;
-#ifdef EXP_NOATOMIC
-          s_acc[tid & 255] = (unsigned long long)(g[i][0] + g[i][1] + g[i][2]);
-          if (J < 0)
-#endif
-          {
-            atomicAdd(row + 0, (unsigned long long)(long long)g[i][0]);
-            atomicAdd(row + 1, (unsigned long long)(long long)g[i][1]);
-            atomicAdd(row + 2, (unsigned long long)(long long)g[i][2]);
-          }
+          atomicAdd(row + 0, (unsigned long long)(long long)g[i][0]);
+          atomicAdd(row + 1, (unsigned long long)(long long)g[i][1]);
+          atomicAdd(row + 2, (unsigned long long)(long long)g[i][2]);
         }
       }
     }

@@ -175,7 +175,8 @@ class Engine:
         if opts.synthesize and dev.type == 'cuda':
             self.hand_synthesizer = HandSynthesizer(c.mesh, S, c.heatmap_size, c.uv_hm_scale, c.depth_scale).to(dev)
         # network/engine.py:71-73: the frozen palm re-predictor the Eval metric goes through
-        self.pose_denoiser = (pose_denoiser if pose_denoiser is not None else default_pose_denoiser()).to(dev).eval()
+        # (loaded on the first evaluation step: a training-only run needs neither the module nor its weight file)
+        self._pose_denoiser = pose_denoiser.to(dev).eval() if pose_denoiser is not None else None
         self.depth_sampler = DepthResample(0.95, opts.depth_resample).to(dev) if getattr(opts, 'depth_resample', 0) else None
         self.num_stacks = opts.num_stacks
         self.temporal_smooth = opts.temporal
@@ -225,6 +226,12 @@ class Engine:
         self.with_synt = bool(opts.synthesize) and self.hand_synthesizer is not None
         self.with_real = any([opts.mv_projection, opts.mv_consistency, opts.temporal, opts.prior, opts.collision,
                               opts.bone_length]) and real_train_dataset is not None
+
+    @property
+    def pose_denoiser(self):
+        if self._pose_denoiser is None:
+            self._pose_denoiser = default_pose_denoiser().to(self.env.device).eval()
+        return self._pose_denoiser
 
     # ------------------------------------------------------------------ utilities
     def log(self, msg):

@@ -266,6 +266,13 @@ class MutualProjectionLossFused(torch.autograd.Function):
         lib = _lib.lib()
         Rm = lib.shr_sphere_raster_mse_regions(int(H), int(W))
         dev = joints.device
+        if N == 0 or J == 0:     # (the entry points return at once on an empty batch: nothing would write the outputs)
+            if ctx.needs_input_grad[2]:
+                ctx.save_for_backward(torch.zeros((B, V, J, 3), dtype=torch.float32, device=dev))
+            depth = torch.full((N, H, W), 100.0, dtype=torch.float32, device=dev)
+            ctx.mark_non_differentiable(depth)
+            ctx.set_materialize_grads(False)
+            return torch.zeros((), dtype=torch.float32, device=dev), depth
         with _on(dev):
             spheres = torch.empty((N, J, 4), dtype=torch.float32, device=dev)
             _lib.check(lib.shr_mutual_project_fwd(_ptr(cam), _ptr(inv_cam), _ptr(joints), _ptr(radii), B, V, J, _ptr(spheres),
@@ -536,7 +543,12 @@ def group_norm_relu(x, gn, pre_bias=None):
 def conv_then_group_norm_relu(x, conv, gn):
     """relu(gn(conv(x))) with the convolution's bias folded into the normalisation kernel when that kernel will
     take conv's output (NHWC fp32 on the GPU, supported channel counts): conv runs bias-free."""
-    if (FUSED_GROUP_NORM_RELU and gn.affine and conv.bias is not None and x.is_cuda and x.dtype == torch.float32
+    # (F.conv2d below bypasses conv.forward: only for a plain zero-padded convolution without hooks or
+    # parametrizations; the kernel reads the bias 16 bytes at a time)
+    plain = (conv.padding_mode == 'zeros' and not conv._forward_hooks and not conv._forward_pre_hooks
+             and not getattr(conv, 'parametrizations', None) and conv.bias is not None
+             and conv.bias.data_ptr() % 16 == 0 and conv.bias.is_contiguous())
+    if (FUSED_GROUP_NORM_RELU and gn.affine and plain and x.is_cuda and x.dtype == torch.float32
             and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
             and bool(_lib.lib().shr_group_norm_relu_supported(int(conv.out_channels), int(gn.num_groups)))):
         y = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)

@@ -47,6 +47,14 @@ class RecoverXYZCoordinateFromHeatmap(nn.Module):
         self.register_buffer('u_grid', u.contiguous())
         self.register_buffer('v_grid', v.contiguous())
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # checkpoints written by this repository before round 2 hold the grids as [1,1,1,W] / [1,1,H,1]: same values
+        for name in ('u_grid', 'v_grid'):
+            t = state_dict.get(prefix + name)
+            if t is not None and t.shape != getattr(self, name).shape and t.numel() in (self.u_grid.shape[-1], self.u_grid.shape[-2]):
+                state_dict[prefix + name] = t.expand_as(getattr(self, name)).contiguous()
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def from_output(self, hm):
         """xyz from the network's raw output hm [N,2J,h,w] (uv maps | depth maps): one kernel per direction on
         the GPU, the torch formulation (forward()) otherwise."""
@@ -101,7 +109,16 @@ class DepthResample(nn.Module):
         if dm.ndimension() == 3:
             dm = dm.unsqueeze(1)
         if dm.is_cuda and dm.dtype == torch.float32 and dm.shape[1] == 1 and not (torch.is_grad_enabled() and dm.requires_grad):
-            # one torch.rand + one launch (drop-out and the fixed Gaussian fused; same draws -> same result)
+            # one torch.rand + one launch (drop-out and the FIXED 3x3 / 5x5 Gaussian of the reference fused: the kernel
+            # carries those tables -- a changed self.gaussian_filter.weight takes the torch path below)
+            w = self.gaussian_filter.weight
+            if w.requires_grad or getattr(self, '_fixed_kernel_checked', None) is not w._version:
+                k = torch.tensor(self._K5 if w.shape[-1] == 5 else self._K3, dtype=w.dtype, device=w.device)
+                self._fixed = bool(torch.equal(w.reshape(-1), k / k.sum()))
+                self._fixed_kernel_checked = w._version
+            if not self._fixed:
+                dm = torch.where(torch.rand_like(dm) > self.sample_ratio, torch.ones_like(dm), dm)
+                return self.gaussian_filter(dm)
             return ops.depth_resample(dm.reshape(dm.shape[0], dm.shape[2], dm.shape[3]).contiguous(), self.sample_ratio,
                                       self.gaussian_filter.kernel_size[0])
         dm = torch.where(torch.rand_like(dm) > self.sample_ratio, torch.ones_like(dm), dm)

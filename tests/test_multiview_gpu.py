@@ -373,3 +373,17 @@ def test_depth_resample_kernel_matches_the_module_ops(ksize):
     with torch.no_grad():
         z = mod(dm)                                           # the module takes the kernel on CUDA tensors
     assert z.shape == (5, 1, 48, 40) and 0.0 < (z - dm.unsqueeze(1)).abs().max().item() < 1.3
+
+
+def test_mutual_projection_loss_on_an_empty_batch():
+    """B = 0: the entry points return at once, so the wrapper must not hand out uninitialised memory: loss 0, an empty
+    projection, a zero gradient."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    crit = MutualProjectionLoss(64, hand_model.load_mesh()).cuda()
+    cam = torch.zeros(0, 3, 4, 4, device="cuda")
+    joints = torch.zeros(0, 3, 41, 3, device="cuda", requires_grad=True)
+    loss, proj = crit(cam, cam, joints, torch.zeros(0, 3, 64, 64, device="cuda"), True)
+    assert loss.item() == 0.0 and proj.shape == (0, 3, 3, 64, 64)
+    loss.backward()
+    assert joints.grad is not None and joints.grad.shape == joints.shape

@@ -182,3 +182,19 @@ def test_batched_pose_sampler_has_the_sequential_samplers_distribution():
     # same generator, same draws
     g1, g2 = torch.Generator().manual_seed(3), torch.Generator().manual_seed(3)
     assert torch.equal(sample_poses_batched(48, g1), sample_poses_batched(48, g2))
+
+
+def test_legacy_shaped_soft_argmax_grids_load():
+    """Checkpoints this repository wrote before round 2 hold xyz_recover.u_grid / v_grid as [1,1,1,W] / [1,1,H,1]; the
+    reference's (and today's) are full [1,1,H,W] grids: both load strictly, with the same values."""
+    from spherehand_amd.util_modules import RecoverXYZCoordinateFromHeatmap
+    m = RecoverXYZCoordinateFromHeatmap(16, 16, 0.01)
+    sd = m.state_dict()
+    legacy = {"u_grid": sd["u_grid"][:, :, :1, :].clone(), "v_grid": sd["v_grid"][:, :, :, :1].clone()}
+    m2 = RecoverXYZCoordinateFromHeatmap(16, 16, 0.01)
+    m2.u_grid.zero_(); m2.v_grid.zero_()
+    m2.load_state_dict(legacy, strict=True)
+    assert torch.equal(m2.u_grid, sd["u_grid"]) and torch.equal(m2.v_grid, sd["v_grid"])
+    m2.load_state_dict(sd, strict=True)
+    with pytest.raises(RuntimeError):
+        m2.load_state_dict({"u_grid": torch.zeros(1, 1, 3, 3), "v_grid": sd["v_grid"]}, strict=True)
