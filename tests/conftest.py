@@ -34,3 +34,28 @@ def spheres_from(centres, radii):
 
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def run_torchrun(world, script_args, env=None, timeout=600, attempts=3, capture=False):
+    """`python -m torch.distributed.run --nproc-per-node world <script_args>` on 127.0.0.1 with a fresh port.  A launch
+    that exits non-zero is retried (a fresh port each time): the rendezvous of back-to-back launches on a box that has
+    just come up fails now and then (the store's port taken between the probe and the bind), which says nothing about
+    the code under test -- an assertion inside a worker fails every attempt and still fails the test.  Returns stdout
+    (capture=True) or None."""
+    import socket
+    import subprocess
+    import sys
+    last = None
+    for attempt in range(attempts):
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(port)] + list(script_args)
+        r = subprocess.run(cmd, env=env, timeout=timeout, cwd=ROOT, capture_output=True, text=True)
+        if r.returncode == 0:
+            return r.stdout if capture else None
+        last = r
+        print("torchrun attempt %d failed (rc %d):\n%s" % (attempt + 1, r.returncode, (r.stderr or "")[-3000:]))
+    raise AssertionError("torchrun failed %d times; last stderr:\n%s" % (attempts, (last.stderr or "")[-6000:]))

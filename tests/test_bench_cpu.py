@@ -10,10 +10,9 @@ from test_ddp_cpu import free_port
 
 def test_timed_steps_is_max_over_ranks(tmp_path):
     out = str(tmp_path / "o.json")
-    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                    "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-                    os.path.join(ROOT, "tests", "bench_worker.py"), out], check=True, timeout=300, cwd=ROOT,
-                   env=dict(os.environ, OMP_NUM_THREADS="1"))
+    from conftest import run_torchrun
+    run_torchrun(2, [os.path.join(ROOT, "tests", "bench_worker.py"), out], env=dict(os.environ, OMP_NUM_THREADS="1"),
+                 timeout=300)
     res = json.load(open(out))
     assert [r["calls"] for r in res] == [23, 23]                       # 3 warm-up + exactly 20 timed
     assert res[0]["elapsed"] == res[1]["elapsed"]                       # every rank reports the max

@@ -19,9 +19,9 @@ pytestmark = pytest.mark.gpu
 def test_bench_two_ranks_one_gpu():
     env = dict(os.environ, SHR_BENCH_BACKEND="gloo", SHR_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
                SHR_BENCH_DDP_STEPS="3")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "10"]
-    out = subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT, capture_output=True, text=True).stdout
+    from conftest import run_torchrun
+    out = run_torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "10"], env=env,
+                       timeout=600, capture=True)
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out                               # rank 0 prints ONE line
     d = json.loads(lines[0])

@@ -21,11 +21,9 @@ def free_port():
 
 
 def launch(world, out, model_dir):
+    from conftest import run_torchrun
     env = dict(os.environ, OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "tests", "ddp_worker.py"), out, model_dir]
-    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
+    run_torchrun(world, [os.path.join(ROOT, "tests", "ddp_worker.py"), out, model_dir], env=env, timeout=600)
     return torch.load(out)
 
 

@@ -14,11 +14,9 @@ pytestmark = pytest.mark.gpu
 
 
 def launch(world, out, model_dir):
+    from conftest import run_torchrun
     env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), out, model_dir]
-    subprocess.run(cmd, check=True, env=env, timeout=900, cwd=ROOT)
+    run_torchrun(world, [os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), out, model_dir], env=env, timeout=900)
     return torch.load(out)
 
 
