@@ -491,10 +491,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SHR_BENCH_BACKEND", "nccl")
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("SHR_BENCH_PG_TIMEOUT_S", "300")))   # a lost rank must not hang the node for the default 10 min
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
         # the launcher's world size, --gpus and what RCCL actually connected must agree
         assert dist.get_world_size() == world == args.gpus, \
             "launched %d ranks (RCCL sees %d) but --gpus %d" % (world, dist.get_world_size(), args.gpus)
@@ -574,7 +576,10 @@ def main():
 
     coll = None
     if dist is not None and not args.no_secondary:
-        coll = collective_secondary(dist, rank, world, dev)   # every rank takes part; rank 0 prints
+        try:                                                  # (the headline line is printed whatever happens here)
+            coll = collective_secondary(dist, rank, world, dev)   # every rank takes part; rank 0 prints
+        except Exception as e:                                # noqa: BLE001
+            coll = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank == 0:
         # algorithmic bytes ("u8 argmin saved" variant: 165 808 B/crop fwd+bwd @128):
         #   fwd writes depth f32 + owner u8, reads the spheres; bwd reads grad f32 + owner u8 +

@@ -436,10 +436,10 @@ int launch_d2m(const float *depth, const int32_t *depth_index, const float *cent
   const long long wgs = (long long)N * parts;
   const int waves = g_d2m_waves ? g_d2m_waves : (wgs >= 1024 ? 4 : (wgs >= 384 ? 8 : 16));
   // bands of consecutive units, handed out dynamically: small enough to balance the waves, large enough that the
-  // remainder search at the end of every band stays a small share (measured best: 2 units at 128 x 128 with four
-  // waves, 4-8 at 256 x 256)
+  // remainder search at the end of every band stays a small share (tools/exp_d2m_parts.py, round 3: 3 units at
+  // 128 x 128 with four waves -- 52.5 us against 55-58 with 2 and 57 with 4 for 1152 crops --, 4-8 at 256 x 256)
   const int units = (int)(((long long)H * W + 255) >> 8);
-  int band_units = units / (8 * waves * parts);
+  int band_units = units / (5 * waves * parts);
   if (band_units > 8) band_units = 8;
   if (g_d2m_band) band_units = g_d2m_band;
   if (band_units < 1) band_units = 1;

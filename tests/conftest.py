@@ -57,5 +57,14 @@ def run_torchrun(world, script_args, env=None, timeout=600, attempts=3, capture=
         if r.returncode == 0:
             return r.stdout if capture else None
         last = r
-        print("torchrun attempt %d failed (rc %d):\n%s" % (attempt + 1, r.returncode, (r.stderr or "")[-3000:]))
+        msg = "torchrun attempt %d failed (rc %d): %s\n%s" % (attempt + 1, r.returncode, " ".join(script_args)[-200:],
+                                                            (r.stderr or "")[-3000:])
+        print(msg)
+        try:      # kept where the GPU box's scratch output is collected, if there is such a place
+            d = os.path.join(ROOT, "gpurun_out")
+            if os.path.isdir(d):
+                with open(os.path.join(d, "torchrun_retries.log"), "a") as f:
+                    f.write(msg + "\n----\n")
+        except OSError:
+            pass
     raise AssertionError("torchrun failed %d times; last stderr:\n%s" % (attempts, (last.stderr or "")[-6000:]))

@@ -12,9 +12,10 @@ with torch.cuda.stream(stream):
     for B, S in ((128, 128), (128, 256), (1024, 128)):
         obs, index, cen, rad = inputs(B, S)
         N, J = B * 9, 41
-        for parts in (1, 2, 4):
-            line = "%5d crops @%d, %d part(s):" % (N, S, parts)
-            for waves in (4, 8, 16):
+        for parts, band in [(p_, b_) for p_ in (1, 2, 4) for b_ in [int(x) for x in os.environ.get("BANDS", "0").split(",")]]:
+            ops.set_tuning(ops.TUNE_D2M_BAND_UNITS, band)
+            line = "%5d crops @%d, %d part(s), band %d:" % (N, S, parts, band)
+            for waves in [int(x) for x in os.environ.get("WAVES", "4,8,16").split(",")]:
                 ops.set_tuning(ops.TUNE_D2M_WAVES, waves)
                 ls = torch.empty(N * parts, device="cuda"); gr = torch.empty(N * parts, J, 3, device="cuda")
                 a = [t.data_ptr() for t in (obs, index, cen, rad, ls, gr)]
@@ -23,3 +24,4 @@ with torch.cuda.stream(stream):
                 line += "  %2d waves %.1f us" % (waves, t)
             print(line)
         ops.set_tuning(ops.TUNE_D2M_WAVES, 0)
+        ops.set_tuning(ops.TUNE_D2M_BAND_UNITS, 0)
