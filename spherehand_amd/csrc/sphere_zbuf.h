@@ -48,7 +48,10 @@
 namespace shr {
 
 constexpr int kZWaves = 16;   // 1024 threads
-constexpr int kRowPad = 8;    // LDS row padding (elements): chunk rows start in different banks (no lane writes there)
+#ifndef SHR_ROW_PAD
+#define SHR_ROW_PAD 8
+#endif
+constexpr int kRowPad = SHR_ROW_PAD;    // LDS row padding (elements): chunk rows start in different banks (no lane writes there)
 constexpr int kPadRows = 0;   // rows after the region's last (none: a chunk never overhangs its box)
 #ifndef SHR_BG_WAVES
 #define SHR_BG_WAVES 7
