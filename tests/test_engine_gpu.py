@@ -62,6 +62,60 @@ def test_hand_synthesizer():
     assert clean(sample_poses(2, seed=4).cuda()).shape == (2, 64, 64)
 
 
+@pytest.mark.parametrize("S", [64, 128])
+def test_hand_synthesizer_values_against_the_oracle_chain(S):
+    """HandSynthesizer.forward (network/util_modules.py:104-122) VALUES, not shapes: under one seed the module's outputs
+    equal the chain assembled by hand from pieces that are pinned elsewhere -- the random scale and focal jitter drawn in
+    the module's order, the ORACLE's skinning + camera + triangle raster at 640 x 640 + clamp + bilinear resize
+    (bit-exact: the fused kernel rasterizes the same arithmetic), x depth_scale, DepthNoise's torch formula on the same
+    draws (1e-6: the fused noise kernel consumes one randn of three planes), and the heat-map renderer's torch ops
+    (6e-6 / 4e-4, its bars in tools/fuzz.py)."""
+    from oracle import oracle
+    from spherehand_amd import hand_model
+    from spherehand_amd.joint_angle import sample_poses
+    from spherehand_amd.util_modules import HandSynthesizer
+    oracle.build()
+    mesh = hand_model.load_mesh()
+    B = 6
+    pose = sample_poses(B, seed=5).cuda()
+    syn = HandSynthesizer(mesh, S, 16, 1.0, 0.01, add_noise=False).cuda()
+    torch.manual_seed(11)
+    depth, uv, dh, xyz = syn(pose)
+    # the same draws, by hand: RandScale's three CPU draws, then the focal jitter on the device
+    torch.manual_seed(11)
+    T = syn.rand_scale(syn.hand_skeleton_transform(pose))
+    rand_f = torch.rand(B, device="cuda") * 0.2 + 0.9
+    start, bone, wv = hand_model.sparse_skin(mesh)
+    verts = oracle.lbs_project(T.cpu().numpy(), start, bone, wv, True, syn.dm_render.camera, rand_f.cpu().numpy())
+    faces = syn.dm_render.rasterizer.faces_i32.cpu().numpy().astype(np.int64)                  # [F,3], winding as rasterized
+    fv = np.ascontiguousarray(verts[:, faces, 0:3], np.float32)                     # [B,F,3,3]
+    raw = oracle.tri_raster_fwd(fv, 640, 640)
+    ref = oracle.clamp_bilinear(raw, S, S, 100.0) * np.float32(0.01)
+    assert np.array_equal(depth.cpu().numpy().view(np.uint32), ref.astype(np.float32).view(np.uint32))
+    assert 0.03 < float((depth < 0.99).float().mean()) < 0.5
+    # heat-maps and key-points: the module's torch formulation on the same transforms
+    with torch.enable_grad():
+        uv_t, dh_t, xyz_t = syn.hm_render(T, rand_f, 1.0, 0.01)
+    for a, b, tol in ((uv, uv_t, 6e-6), (xyz, xyz_t, 4e-4)):
+        assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
+    gate = (uv_t - 0.05).abs() > 1e-5                      # (depth maps are gated by uv_hm > 0.05: skip pixels on the gate)
+    assert ((dh - dh_t) * gate).abs().max().item() <= 1e-6 * max(1.0, dh_t.abs().max().item())
+    # with the noise: DepthNoise's torch formula on the draws the fused kernel consumes (one randn of three planes:
+    # x shift, y shift, z noise)
+    noisy = HandSynthesizer(mesh, S, 16, 1.0, 0.01, add_noise=True, out_heatmap=False).cuda()
+    torch.manual_seed(11)
+    out = noisy(pose)
+    torch.manual_seed(11)
+    noisy.rand_scale(noisy.hand_skeleton_transform(pose)); torch.rand(B, device="cuda")
+    rn = torch.randn(3, B, S, S, device="cuda")
+    u = torch.arange(S, device="cuda").view(1, 1, S); v = torch.arange(S, device="cuda").view(1, S, 1)
+    sx = torch.clamp((rn[0] * 0.5 + 0.5).long() + u, 0, S - 1)
+    sy = torch.clamp((rn[1] * 0.5 + 0.5).long() + v, 0, S - 1)
+    g = torch.gather(depth.reshape(B, S * S), 1, (sy * S + sx).reshape(B, S * S)).view(B, S, S)
+    expect = torch.where(g < 1.0, g + rn[2] * 0.05, g)
+    assert (out - expect).abs().max().item() <= 1e-6
+
+
 def test_engine_train_eval_checkpoint(tmp_path):
     from spherehand_amd import hand_model
     from spherehand_amd.datasets import SyntheticMultiviewDataset
