@@ -160,7 +160,10 @@ __device__ __forceinline__ FaceRow face_row(const FaceSetup &fs) {
 //      instructions per wave, the union of the 64 lanes' nested loops);
 //   B. lanes = work items: the expensive part (9 IEEE divisions per face, 3 per column, 7 per
 //      pixel) with every lane busy and bounded work per lane.
-template <int TO, int SL>
+// EXACT: the resize ratio R = src / S is an integer -- odd (SL = 1: output d samples source R d + (R - 1) / 2 with weight
+// 1) or even (SL = 2: sources R d + R / 2 - 1 and the next one, weights 1/2 each; lin_index's fma is exact in both
+// cases) -- and "the output pixels with a sample inside [lo, hi]" is a closed form instead of a loop over candidates.
+template <int TO, int SL, bool EXACT>
 __global__ void __launch_bounds__(1024)
 mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ faces, int NV, int F, int src,
                   int S, float clamp_max, float *__restrict__ depth) {
@@ -200,11 +203,14 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
   // (lin_index's fma is exact there), so "the output pixels whose sample falls in [lo, hi]" is a closed form instead of
   // a loop over candidates: d in [ceil((lo - h) / R), floor((hi - h) / R)].  (x + 0.5) * (1 / R) is at least 0.5 / R
   // from an integer and the product's error below 1e-4 for |x| < 2^15: the floor is exact.
-  const int ratio = src / S, half_r = (ratio - 1) >> 1;
+  // (even R, SL = 2: first slot R d + R / 2 - 1; a d counts when EITHER slot lies in [lo, hi] -- the slots' own
+  // membership is still tested where they are rasterized)
+  const int ratio = src / S, half_r = SL == 1 ? (ratio - 1) >> 1 : (ratio >> 1) - 1;
   const float rcp_r = 1.0f / (float)ratio;
   auto fdiv = [&](int x) { return (int)floorf(((float)x + 0.5f) * rcp_r); };   // floor(x / R), x may be negative
-  auto first_out = [&](int lo, int t0) { return max(t0, fdiv(lo - half_r + ratio - 1)); };
+  auto first_out = [&](int lo, int t0) { return max(t0, fdiv(lo - (SL - 1) - half_r + ratio - 1)); };
   auto last_out = [&](int hi, int t0) { return min(min(t0 + TO, S) - 1, fdiv(hi - half_r)); };
+  auto exact_lin = [&](int d) { Lin l; l.i0 = ratio * d + half_r; l.i1 = l.i0 + (SL - 1); l.l0 = SL == 1 ? 1.f : 0.5f; l.l1 = SL == 1 ? 0.f : 0.5f; return l; };
 
   for (int f0 = 0; f0 < F; f0 += 1024 * kMeshFaces) {
     // ---- A. cull, count work items, block scan ---------------------------------------------
@@ -218,7 +224,7 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
       if (f < F) {
         const FaceSetup fs = face_setup_sorted(verts, faces, f, src);
         if (fs.live && !(fs.xi_max < tlx.i0 || fs.xi_min > thx.i1 || fs.r_hi < tly.i0 || fs.r_lo > thy.i1)) {
-          if (SL == 1) {   // closed forms: every output column / row in the range samples the box
+          if (EXACT) {   // closed forms: every output column / row in the range samples the box
             const int dx_lo = first_out(fs.xi_min, tx0), dx_hi = last_out(fs.xi_max, tx0);
             if (dx_lo <= dx_hi && first_out(fs.r_lo, ty0) <= last_out(fs.r_hi, ty0)) {
               dx0[k] = dx_lo;
@@ -302,9 +308,9 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
             if (slot >= 0 && slot < kMeshQueue) s_queue[slot] = tag | (dx0[k] + __builtin_ctz(m) - tx0);
           if (nk[k] > __builtin_popcount(colmask[k])) {   // a face wider than 32 output columns: the rest by re-enumeration
             const FaceSetup fs = face_setup_sorted(verts, faces, f, src);
-            const int dx_hi = SL == 1 ? last_out(fs.xi_max, tx0) : out_hi(fs.xi_max, tx0);
+            const int dx_hi = EXACT ? last_out(fs.xi_max, tx0) : out_hi(fs.xi_max, tx0);
             for (int dx = dx0[k] + 32; dx <= dx_hi; dx++)
-              if (SL == 1 || column_slots(dx, fs.xi_min, fs.xi_max)) {
+              if (EXACT || column_slots(dx, fs.xi_min, fs.xi_max)) {
                 if (slot >= 0 && slot < kMeshQueue) s_queue[slot] = tag | (dx - tx0);
                 slot++;
               }
@@ -333,12 +339,12 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
         {
           const int dx = tx0 + (item & 127);
           Lin lx;
-          if (SL == 1) { lx.i0 = lx.i1 = ratio * dx + half_r; lx.l0 = 1.f; lx.l1 = 0.f; }
+          if (EXACT) lx = exact_lin(dx);
           else lx = lin_index(dx, scale, src);
 #pragma unroll
           for (int sx = 0; sx < SL; sx++) {
             const int xi = sx ? lx.i1 : lx.i0;
-            if (SL != 1 && ((sx ? lx.l1 : lx.l0) == 0.f || xi < xi_min || xi > xi_max)) continue;
+            if (SL != 1 && ((!EXACT && (sx ? lx.l1 : lx.l0) == 0.f) || xi < xi_min || xi > xi_max)) continue;
             // ---- column span (.cu:72-90; the slopes are the face's) --------------------------
             const float xf = (float)xi;
             float yi1;
@@ -349,16 +355,16 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
             const int yi_max = m_cvt_rz_sat(fminf(fmaxf(yi1, yi2), (float)src - 1.f));
             // (only the output rows whose slots can fall inside the column's span; SL == 1: exactly the rows that
             // sample it, by the closed form -- the span lies inside the face's rows)
-            const int ry_lo = yi_min > yi_max ? 1 : (SL == 1 ? first_out(yi_min, ty0) : max(dy_lo, out_lo(yi_min, ty0)));
-            const int ry_hi = yi_min > yi_max ? 0 : (SL == 1 ? last_out(yi_max, ty0) : min(dy_hi, out_hi(yi_max, ty0)));
+            const int ry_lo = yi_min > yi_max ? 1 : (EXACT ? first_out(yi_min, ty0) : max(dy_lo, out_lo(yi_min, ty0)));
+            const int ry_hi = yi_min > yi_max ? 0 : (EXACT ? last_out(yi_max, ty0) : min(dy_hi, out_hi(yi_max, ty0)));
             for (int dy = ry_lo; dy <= ry_hi; dy++) {
               Lin ly;
-              if (SL == 1) { ly.i0 = ly.i1 = ratio * dy + half_r; ly.l0 = 1.f; ly.l1 = 0.f; }
+              if (EXACT) ly = exact_lin(dy);
               else ly = lin_index(dy, scale, src);
 #pragma unroll
               for (int sy = 0; sy < SL; sy++) {
                 const int yi = sy ? ly.i1 : ly.i0;
-                if (SL != 1 && ((sy ? ly.l1 : ly.l0) == 0.f || yi < yi_min || yi > yi_max)) continue;
+                if (SL != 1 && ((!EXACT && (sy ? ly.l1 : ly.l0) == 0.f) || yi < yi_min || yi > yi_max)) continue;
                 // ---- pixel (.cu:97-110) ----------------------------------------------------
                 const float yf = (float)yi;
                 float w[3], w_sum = 0.f;
@@ -431,16 +437,19 @@ extern "C" int shr_mesh_depth_fwd(const float *vertices, const int32_t *faces, i
   const float4 *v4 = reinterpret_cast<const float4 *>(vertices);
   // odd integer ratio: src = ratio * d + (ratio - 1) / 2 exactly, bilinear weights (1, 0)
   const bool single = (src_size % S == 0) && (((src_size / S) & 1) == 1);
-#define MESH_LAUNCH(TO, SL)                                                                                      \
+  const bool even = (src_size % S == 0) && (((src_size / S) & 1) == 0);   // even integer ratio: two slots, closed forms
+#define MESH_LAUNCH(TO, SL, EX)                                                                                  \
   do {                                                                                                           \
     const int t = (S + (TO) - 1) / (TO);                                                                         \
-    hipLaunchKernelGGL((mesh_depth_kernel<TO, SL>), dim3((unsigned)(t * t), (unsigned)B), dim3(1024), 0, s, v4,  \
-                       faces, NV, F, src_size, S, clamp_max, depth);                                             \
+    hipLaunchKernelGGL((mesh_depth_kernel<TO, SL, EX>), dim3((unsigned)(t * t), (unsigned)B), dim3(1024), 0, s,  \
+                       v4, faces, NV, F, src_size, S, clamp_max, depth);                                         \
   } while (0)
   if (single) {
-    if (S > 64) MESH_LAUNCH(128, 1); else MESH_LAUNCH(64, 1);
+    if (S > 64) MESH_LAUNCH(128, 1, true); else MESH_LAUNCH(64, 1, true);
+  } else if (even) {
+    if (S > 32) MESH_LAUNCH(64, 2, true); else MESH_LAUNCH(32, 2, true);
   } else {
-    if (S > 32) MESH_LAUNCH(64, 2); else MESH_LAUNCH(32, 2);
+    if (S > 32) MESH_LAUNCH(64, 2, false); else MESH_LAUNCH(32, 2, false);
   }
 #undef MESH_LAUNCH
   return (int)hipGetLastError();

@@ -111,9 +111,22 @@ def d2m_case():
         fg = depth[n] <= 99
         P = np.stack([X[fg], Y[fg], depth[n][fg]], -1).astype(np.float64)
         if len(P):
-            m = np.abs(np.linalg.norm(P[:, None, :] - cen[n][None].astype(np.float64), axis=-1) - rad[None].astype(np.float64)).min(1)
+            D = np.abs(np.linalg.norm(P[:, None, :] - cen[n][None].astype(np.float64), axis=-1) - rad[None].astype(np.float64))
+            m = D.min(1)
             if (np.abs(m - 50.0) < 2e-4).any() or (m < 2e-4).any():
                 return
+            # a point equidistant from two DIFFERENT spheres to within a few fp32 ulps: which of them owns it (and gets
+            # its unit vector) is decided by the last bit of the root -- v_sqrt_f32 here, sqrtf in the oracle, whatever
+            # the reference's platform computes -- while the loss is the same: not a comparable case either (the long
+            # run of round 3 met one in 3590: gap 7e-6 on 45.7, two gradient rows off by one unit vector)
+            if J > 1:
+                part = np.partition(D, 1, axis=1)
+                close = (part[:, 1] - part[:, 0]) < 6e-7 * np.maximum(part[:, 1], 1.0)
+                if close.any():
+                    order = np.argsort(D[close], axis=1)[:, :2]
+                    same_record = np.all(cen[n][order[:, 0]] == cen[n][order[:, 1]], axis=1) & (rad[order[:, 0]] == rad[order[:, 1]])
+                    if (~same_record).any():     # (duplicated spheres tie EXACTLY: the first index must win, that is checked)
+                        return
     loss, grad = ops.data_to_model(dev(depth), dev(cen), dev(rad), want_grad=True)
     # any launch shape gives the same bits (the sums are integers)
     ops.set_tuning(ops.TUNE_D2M_WAVES, int(rs.choice([4, 8, 16]))); ops.set_tuning(ops.TUNE_D2M_BAND_UNITS, int(rs.choice([1, 2, 3, 8])))

@@ -1,6 +1,6 @@
 """Generate tools/exp_mesh.hip: mesh_depth_kernel with per-phase clock64 accumulators."""
 src = open('spherehand_amd/csrc/mesh_depth.hip').read()
-a = src.index('template <int TO, int SL>\n__global__')
+a = src.index('template <int TO, int SL, bool EXACT>\n__global__')
 b = src.index('}  // namespace shr')
 k = src[a:b]
 k = k.replace('mesh_depth_kernel(', 'exp_mesh(')
@@ -39,8 +39,8 @@ exp = '#include "../spherehand_amd/csrc/common.h"\nnamespace shr {\n' + src[src.
 extern "C" int exp_mesh_launch(const float *vertices, const int *faces, int B, int NV, int F, int src, int S, float *depth,
                                long long *tb, void *stream) {
   using namespace shr;
-  if (S == 128) hipLaunchKernelGGL((exp_mesh<128, 1>), dim3(1, B), dim3(1024), 0, (hipStream_t)stream, (const float4 *)vertices, faces, NV, F, src, S, 100.f, depth, tb);
-  else hipLaunchKernelGGL((exp_mesh<64, 2>), dim3(((S + 63) / 64) * ((S + 63) / 64), B), dim3(1024), 0, (hipStream_t)stream, (const float4 *)vertices, faces, NV, F, src, S, 100.f, depth, tb);
+  if (S == 128) hipLaunchKernelGGL((exp_mesh<128, 1, true>), dim3(1, B), dim3(1024), 0, (hipStream_t)stream, (const float4 *)vertices, faces, NV, F, src, S, 100.f, depth, tb);
+  else hipLaunchKernelGGL((exp_mesh<64, 2, true>), dim3(((S + 63) / 64) * ((S + 63) / 64), B), dim3(1024), 0, (hipStream_t)stream, (const float4 *)vertices, faces, NV, F, src, S, 100.f, depth, tb);
   return (int)hipGetLastError();
 }
 '''
