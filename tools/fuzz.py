@@ -399,17 +399,20 @@ def reset_tuning():
 
 
 def run(families=None, cases=None, seconds=None, seed=0, log=print):
-    """Each family until `cases` cases or `seconds` seconds (whichever comes first; None = unbounded by that measure).
+    """Each family until `cases` cases (an int, or {family: int, "*": default}) or `seconds` seconds (whichever comes
+    first; None = unbounded by that measure).
     Returns {family: (cases run, mismatches)}."""
     global rs, fails
     rs = np.random.RandomState(seed)
+    torch.manual_seed(seed)      # (the module paths under test draw from torch's generators: same draws per seed)
     out = {}
     try:
         for name, fn in FAMILIES:
             if families and name not in families:
                 continue
             before, t0, n = fails, time.time(), 0
-            while (cases is None or n < cases) and (seconds is None or time.time() - t0 < seconds):
+            ncase = cases.get(name, cases.get("*")) if isinstance(cases, dict) else cases
+            while (ncase is None or n < ncase) and (seconds is None or time.time() - t0 < seconds):
                 fn(); n += 1
             out[name] = (n, fails - before)
             log("%s: %d cases in %.1f s, %d mismatches" % (name, n, time.time() - t0, fails - before))
