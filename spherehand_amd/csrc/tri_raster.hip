@@ -34,6 +34,10 @@ __device__ __forceinline__ int cvt_rz_sat(float d) {
 struct FaceSetup {
   float p[3][3];   // vertices sorted by x
   float fi[9];     // inverse barycentric matrix / denominator
+  // the three edge slopes (.cu:75-85): the reference divides per COLUMN, but the quotients depend on the face only --
+  // one IEEE division each here, in the set-up (lanes = faces), instead of two per box pixel in the span test
+  float s01, s12, s02;
+  int sflags;      // bit 0: x1 - x0 != 0, bit 1: x2 - x1 != 0 (else the span end is y1, .cu:77, :83)
   int xi_min, xi_max, r_lo, r_hi;
   int live;
 };
@@ -72,6 +76,13 @@ __device__ __forceinline__ FaceSetup face_setup(const float f[9], int width, int
   const float den = (p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1])) + p[1][0] * (p[2][1] - p[0][1]);
 #pragma unroll
   for (int k = 0; k < 9; k++) s.fi[k] = s.fi[k] / den;
+  {
+    const bool d01 = p[1][0] - p[0][0] != 0.f, d12 = p[2][0] - p[1][0] != 0.f;
+    s.s01 = d01 ? (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) : 0.f;
+    s.s12 = d12 ? (p[2][1] - p[1][1]) / (p[2][0] - p[1][0]) : 0.f;
+    s.s02 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]);
+    s.sflags = (d01 ? 1 : 0) | (d12 ? 2 : 0);
+  }
   // :68-69  max(ceil(x0), 0.) / min(x2, width - 1.)  (fmax/fmin drop a NaN operand)
   s.xi_min = cvt_rz_sat(fmaxf(ceilf(p[0][0]), 0.f));
   s.xi_max = cvt_rz_sat(fminf(p[2][0], (float)width - 1.f));
@@ -103,18 +114,15 @@ __device__ __forceinline__ void zmin(float *cell, float v) {
   else atomicMin(reinterpret_cast<int *>(cell), (int)b);
 }
 
-// .cu:72-90: is row yi inside column xi's span of the face?  pxy = (x0, y0, x1, y1, x2, y2), sorted by x.
-__device__ __forceinline__ bool span_inside(const float pxy[6], int xi, int yi, int height) {
+// .cu:72-90: is row yi inside column xi's span of the face?  (x0, y0), (x1, y1): the first two vertices sorted by
+// x; the slopes and their flags from face_setup.
+__device__ __forceinline__ bool span_inside(float x0, float y0, float x1, float y1, float s01, float s12, float s02,
+                                            int sflags, int xi, int yi, int height) {
   const float xf = (float)xi;
   float yi1;
-  if (xf <= pxy[2]) {
-    if (pxy[2] - pxy[0] != 0.f) yi1 = (pxy[3] - pxy[1]) / (pxy[2] - pxy[0]) * (xf - pxy[0]) + pxy[1];
-    else yi1 = pxy[3];
-  } else {
-    if (pxy[4] - pxy[2] != 0.f) yi1 = (pxy[5] - pxy[3]) / (pxy[4] - pxy[2]) * (xf - pxy[2]) + pxy[3];
-    else yi1 = pxy[3];
-  }
-  const float yi2 = (pxy[5] - pxy[1]) / (pxy[4] - pxy[0]) * (xf - pxy[0]) + pxy[1];
+  if (xf <= x1) yi1 = (sflags & 1) ? s01 * (xf - x0) + y0 : y1;
+  else yi1 = (sflags & 2) ? s12 * (xf - x1) + y1 : y1;
+  const float yi2 = s02 * (xf - x0) + y0;
   const int yi_min = cvt_rz_sat(fmaxf(0.f, ceilf(fminf(yi1, yi2))));
   const int yi_max = cvt_rz_sat(fminf(fmaxf(yi1, yi2), (float)height - 1.f));
   return yi >= yi_min && yi <= yi_max;
@@ -146,7 +154,7 @@ __device__ __forceinline__ void span_pixel(const float pz[3], const float fi[9],
 //     (3 of the 10 IEEE divisions) and queues (face, x, y) in LDS if its pixel is inside;
 //   pass B, lanes = queued pixels, 64 at a time, every lane busy: the 7 divisions of the
 //     barycentric weights and the perspective depth, then the atomic.
-constexpr int kFaceRow = 28;          // x0 y0 x1 y1 x2 y2 - - | z0 z1 z2 fi[9] | box x0, r_lo, bw, area, first group, 2^20 / bw, - -
+constexpr int kFaceRow = 28;          // x0 y0 x1 y1 x2 y2 s01 s12 | z0 z1 z2 fi[9] | box x0, r_lo, bw, area, first group, 2^20 / bw, s02, slope flags
 constexpr int kGroupsPerFace = 16;    // faces with a box above 256 pixels are visited alone
 constexpr int kFacesPerWave = 32;     // 5 KB of LDS per wave (rows, group table, queue): eight waves per SIMD fit
 
@@ -214,6 +222,7 @@ tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, 
     r[20] = __int_as_float(s.xi_min); r[21] = __int_as_float(s.r_lo); r[22] = __int_as_float(bw);
     r[23] = __int_as_float(area); r[24] = __int_as_float(first);
     r[25] = __int_as_float(bw > 0 ? (int)(((1u << 20) + (unsigned)bw - 1u) / (unsigned)bw) : 0);
+    r[6] = s.s01; r[7] = s.s12; r[26] = s.s02; r[27] = __int_as_float(s.sflags);
   }
   {
     const int ngmax = (int)wave_minmax_all<false>((float)ng);
@@ -254,7 +263,6 @@ tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, 
       face = s_gface[wv][g];
       const float4 *r4 = reinterpret_cast<const float4 *>(s_face[wv][face]);
       const float4 a0 = r4[0], a1 = r4[1], i0 = r4[5], i1 = r4[6];
-      const float pxy[6] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y};
       const int x0 = __float_as_int(i0.x), y0 = __float_as_int(i0.y), fbw = __float_as_int(i0.z);
       const int farea = __float_as_int(i0.w), ffirst = __float_as_int(i1.x);
       const unsigned inv = (unsigned)__float_as_int(i1.y);
@@ -263,7 +271,7 @@ tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, 
         const int ly = (int)(((unsigned)t * inv) >> 20);   // t / bw: exact for t <= 1024, bw <= 1024
         xi = x0 + (t - ly * fbw);
         yi = y0 + ly;
-        inside = span_inside(pxy, xi, yi, height);
+        inside = span_inside(a0.x, a0.y, a0.z, a0.w, a1.z, a1.w, i1.z, __float_as_int(i1.w), xi, yi, height);
       }
     }
     push(inside, face, xi, yi);
@@ -274,15 +282,16 @@ tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, 
   while (live) {
     const int src_lane = __builtin_amdgcn_readfirstlane(__builtin_ctzll(live));
     live &= live - 1;
-    float pxy[6];
-#pragma unroll
-    for (int a = 0; a < 3; a++) { pxy[2 * a] = readlane_f(s.p[a][0], src_lane); pxy[2 * a + 1] = readlane_f(s.p[a][1], src_lane); }
+    const float fx0 = readlane_f(s.p[0][0], src_lane), fy0 = readlane_f(s.p[0][1], src_lane);
+    const float fx1 = readlane_f(s.p[1][0], src_lane), fy1 = readlane_f(s.p[1][1], src_lane);
+    const float f01 = readlane_f(s.s01, src_lane), f12 = readlane_f(s.s12, src_lane), f02 = readlane_f(s.s02, src_lane);
+    const int ffl = __builtin_amdgcn_readlane(s.sflags, src_lane);
     const int x0 = __builtin_amdgcn_readlane(s.xi_min, src_lane), x1 = __builtin_amdgcn_readlane(s.xi_max, src_lane);
     const int r0 = __builtin_amdgcn_readlane(s.r_lo, src_lane), r1 = __builtin_amdgcn_readlane(s.r_hi, src_lane);
     for (int oy = 0; oy <= r1 - r0; oy += 8)
       for (int ox = 0; ox <= x1 - x0; ox += 8) {
         const int xi = x0 + ox + (lane & 7), yi = r0 + oy + (lane >> 3);
-        push(xi <= x1 && yi <= r1 && span_inside(pxy, xi, yi, height), src_lane, xi, yi);
+        push(xi <= x1 && yi <= r1 && span_inside(fx0, fy0, fx1, fy1, f01, f12, f02, ffl, xi, yi, height), src_lane, xi, yi);
       }
   }
   if (qn > 0) drain(qn);
