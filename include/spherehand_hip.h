@@ -69,6 +69,9 @@ int shr_device_info(char *name_host, int name_len, int *num_cu_host);
 #define SHR_TUNE_FWD_ZBUF_BYTES 11  /* forward z-buffer bytes per workgroup: 0 = by launch size (half of a CU's LDS when the
                                     * launch has two workgroups per CU, else one pass for any box); a box that exceeds
                                     * it is rasterized in passes over row bands */
+#define SHR_TUNE_FWD_RUN_TABLE 14   /* forward, whole-crop workgroups on power-of-two images: runs on a sphere start from a
+                                    * per-(sphere, lane) LDS table built by the idle waves: -1 = when it fits (default),
+                                    * 0 = never, 1 = same as -1 */
 int shr_set_tuning(int key, int value);
 /* Self-test: adds to *mismatches (device, caller-zeroed u64) the number of fp32
  * bit patterns in [lo_bits, hi_bits) where the rasterizer's internal square root

@@ -21,6 +21,7 @@ struct Tuning {
   int bwd_waves = 0;                    // waves per backward workgroup: 0 = by launch size, 8 or 16
   int fwd_zbuf_bytes = 0;               // forward z-buffer bytes per workgroup; 0 = by launch size (launch_zbuf_fwd_t)
   int persistent = 1;                   // 0: one workgroup per crop; 1: persistent workgroups when N exceeds the device; > 1: that many
+  int run_table = -1;                   // whole-crop workgroups start their runs from an LDS table: -1 = when it fits, 0 = never
 } g_tune;
 
 constexpr int kMaxLds = 160 * 1024;
@@ -97,11 +98,11 @@ int persistent_grid(int N, int regions, size_t lds, int nwaves) {
   return N >= 4 * cap ? (int)cap : N;
 }
 
-template <bool OWNER, bool VEC4, bool POW2, bool PERSIST, bool BOX>
+template <bool OWNER, bool VEC4, bool POW2, bool PERSIST, bool BOX, bool TABLE = false>
 int launch_zbuf_fwd_p(const float4 *sp, int N, int J, int H, int W, float *depth, uint8_t *argmin, int rows, size_t lds,
                       int zcells, dim3 grid, int flags, hipStream_t s) {
   static AttrDone attr_done;
-  auto k = sphere_zbuf_fwd_kernel<OWNER, VEC4, POW2, PERSIST, BOX>;
+  auto k = sphere_zbuf_fwd_kernel<OWNER, VEC4, POW2, PERSIST, BOX, TABLE>;
   const hipError_t e = allow_big_lds(k, &attr_done);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k, grid, dim3(64 * g_tune.fwd_waves), lds, s, sp, N, J, H, W, depth, argmin, rows,
@@ -137,6 +138,16 @@ int launch_zbuf_fwd_t(const float4 *sp, int N, int J, int H, int W, float *depth
     return (int)grid.x < N
                ? launch_zbuf_fwd_p<OWNER, VEC4, POW2, true, true>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, flags, s)
                : launch_zbuf_fwd_p<OWNER, VEC4, POW2, false, true>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, flags, s);
+  // Whole-region z-buffer: when the run table (J x 64 entries of 8 bytes, sphere_zbuf.h build_run_table) fits behind it
+  // and the workgroup has a wave to spare for it, the runs start from LDS
+  if constexpr (VEC4 && POW2) {
+    const size_t tab = (size_t)J * kWave * sizeof(uint2);
+    static_assert(kZWaves == 16 && kBgWaves == 7, "the table kernel's wave roles");
+    if (g_tune.run_table != 0 && (int)grid.x >= N && g_tune.fwd_waves == kZWaves && lds + tab <= (size_t)kMaxLds &&
+        ((size_t)zcells * key) % 16 == 0 && rows < 4096 && (long long)H * (W + kRowPad) < (1LL << 24))
+      return launch_zbuf_fwd_p<OWNER, true, true, false, false, true>(sp, N, J, H, W, depth, argmin, rows, lds + tab, zcells, grid,
+                                                                      flags, s);
+  }
   return (int)grid.x < N
              ? launch_zbuf_fwd_p<OWNER, VEC4, POW2, true, false>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, flags, s)
              : launch_zbuf_fwd_p<OWNER, VEC4, POW2, false, false>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, flags, s);
@@ -211,6 +222,7 @@ extern "C" int shr_set_tuning(int key, int value) {
     case SHR_TUNE_BWD_WAVES: if (value != 0 && value != 8 && value != 16) return SHR_EINVAL; g_tune.bwd_waves = value; return SHR_OK;
     case SHR_TUNE_FWD_ZBUF_BYTES: if (value < 0) return SHR_EINVAL; g_tune.fwd_zbuf_bytes = value; return SHR_OK;
     case SHR_TUNE_PERSISTENT: if (value < 0) return SHR_EINVAL; g_tune.persistent = value; return SHR_OK;
+    case SHR_TUNE_FWD_RUN_TABLE: if (value < -1 || value > 1) return SHR_EINVAL; g_tune.run_table = value; return SHR_OK;
     case SHR_TUNE_D2M_WAVES: return d2m_set_waves(value);
     case SHR_TUNE_D2M_BAND_UNITS: return d2m_set_band_units(value);
     case SHR_TUNE_FWD_SHARES:

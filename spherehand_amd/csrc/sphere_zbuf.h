@@ -180,10 +180,15 @@ constexpr int kSphereCostBwd = 36;   // ... plus four wave reductions when a run
 // kSphereCost + nchunks * kChunkCost (nothing when it touches no pixel).  Returns the total
 // weight (valid in every lane of wave 0).  Field widths: the launcher keeps W <= 8192 and
 // H <= 32768.
+template <bool POW2>
+__device__ __forceinline__ float axis_coord_t(const Axis &a, int u);
+
+// (s_run, RUN TABLE kernels only: lane j also leaves what a run on sphere j needs as VECTOR values -- y, z, the row
+// coordinate of the box's first row and the row limit -- for one uniform-address ds_read_b128; see build_run_table)
 template <int kSphereCost>
 __device__ __forceinline__ int build_work_list(const float4 s, bool valid, const Axis &ax, const Axis &ay,
                                                float kx, float ky, int W, int r0, int r1, int4 *s_items,
-                                               int *s_ends, int lane, bool *too_big) {
+                                               int *s_ends, int lane, bool *too_big, float4 *s_run = nullptr) {
   const Item it = sphere_item(s, ax, ay, kx, ky, W, r0, r1);
   const int nchunks = valid ? it.nchunks : 0;
   const int cost = nchunks > 0 ? kSphereCost + nchunks * kChunkCost : 0;
@@ -203,6 +208,8 @@ __device__ __forceinline__ int build_work_list(const float4 s, bool valid, const
   s_items[lane] = make_int4(it.u0 | (it.v0 << 16), (int)((unsigned)(it.v1 & 0xffff) | ((unsigned)inv15 << 16)),
                             it.pw | (it.ncx << 8) | ((it.u1 & 0xffff) << 16), incl - cost);
   s_ends[lane] = incl;
+  if (s_run)
+    s_run[lane] = make_float4(s.y, s.z, axis_coord_t<true>(ay, it.v0), axis_coord_t<true>(ay, it.v1) + 0.5f * ay.mul);
   *too_big = __ballot(valid && nchunks > 0 && (it.ncx > 255 || it.u1 > 65535 || it.v1 > 65535 ||
                                                nchunks > (1 << 24))) != 0ull;
   return rl(incl, 63);
@@ -225,8 +232,123 @@ __device__ __forceinline__ WaveList load_wave_list(const float4 *s_sph, const in
   return w;
 }
 
+// RUN TABLE (whole-crop workgroups on power-of-two images; round 3).  What the start of a run on a sphere computes per
+// LANE -- the lane layout lane -> (lx, ly), the column term r*r - dx*dx, the cell, the row -- depends on (sphere,
+// lane) only, and its ~42 VALU instructions hang on a chain of v_readlane -> scalar arithmetic -> branch: measured
+// (tools/exp_walkclk.py) 750 cycles from the top of a run to its first chunk, 47 runs per hand crop, a third of a
+// wave's scan time -- latency, not issue slots.  The waves that idle in front of the first barrier (neither list
+// wave nor background waves) therefore compute it ONCE per sphere into LDS,
+//     tab[j * 64 + lane] = (bits(ca or -1 outside the packing), ly << 24 | ((v0 + ly) * LW + u)),
+// with the same operations as walk_slice (bit-identical values).  A run then starts from ONE v_readlane (its
+// chunk range, packed per (wave, sphere) by a vector pass at the walk's entry), the lane's table entry and the
+// sphere's run record (build_work_list), both requested one run ahead.  Spheres wider than a wave (ncx > 1) keep
+// the arithmetic path.
+struct RunTab {
+  const uint2 *tab;    // [J][64]
+  const float4 *run;   // [64]: (y, z, yg(v0), yg(v1) + half a pixel)
+};
+
+// The table's entries of the spheres in `mine` (wave-uniform mask), lanes = the chunk's lanes; the sphere's box origin
+// and packing come from a lanes = spheres prologue (the same axis_box calls as sphere_item) through v_readlane.
 template <bool POW2>
-__device__ __forceinline__ float axis_coord_t(const Axis &a, int u);
+__device__ __forceinline__ void build_run_table(const float4 s, bool valid, const Axis &ax, const Axis &ay, float kx,
+                                                float ky, int W, int r0, int r1, int LW, uint2 *tab, int lane,
+                                                unsigned long long mine) {
+  int u0 = 0, u1 = W - 1, v0 = r0, v1 = r1 - 1;
+  if (sphere_is_tame(s)) {
+    const float ar = fabsf(s.w);
+    axis_box(s.x, ar, kx, ax.half, (float)W + 2.f, 0, W - 1, u0, u1);
+    axis_box(s.y, ar, ky, ay.half, (float)r1 + 2.f, r0, r1 - 1, v0, v1);
+  }
+  const int pw = min(max(u1 - u0 + 1, 1), kWave);
+  const int inv15 = (int)((32768.0f + (float)pw - 0.5f) * __builtin_amdgcn_rcpf((float)pw));   // as build_work_list
+  const int cell00 = __mul24(v0, LW) + u0;
+  const int pwinv = pw | (inv15 << 8);             // (pw <= 64, inv15 <= 32768)
+  const float rr = s.w * s.w;
+  auto entry = [&](int j) {
+    const int pk = rl(pwinv, j), u0j = rl(u0, j), c00 = rl(cell00, j);
+    const float sx = readlane_f(s.x, j), rrj = readlane_f(rr, j);
+    const int pwj = pk & 0xff, invj = (int)((unsigned)pk >> 8), ph = (invj << 6) >> 15;
+    const int ly = __mul24(lane, invj) >> 15;
+    const int lx = lane - __mul24(ly, pwj);
+    const float dx = axis_coord_t<POW2>(ax, u0j + lx) - sx;
+    const float ca = rrj - dx * dx;
+    return make_uint2(__float_as_uint(ly < ph ? ca : -1.f), (unsigned)(c00 + __mul24(ly, LW) + lx) | ((unsigned)ly << 24));
+  };
+  // two spheres per iteration: a single wave issues a DEPENDENT vector instruction every ~8 cycles, and these waves
+  // have their SIMD almost to themselves while the others wait for memory
+  while (mine) {
+    const int ja = __builtin_ctzll(mine);
+    mine &= mine - 1;
+    if (!mine) { tab[ja * kWave + lane] = entry(ja); break; }
+    const int jb = __builtin_ctzll(mine);
+    mine &= mine - 1;
+    const uint2 ea = entry(ja), eb = entry(jb);
+    tab[ja * kWave + lane] = ea;
+    tab[jb * kWave + lane] = eb;
+  }
+}
+
+template <bool POW2, int kSphereCost, bool ROWFREE, typename Body, typename EndSphere>
+__device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int hi, int lane, const Axis &ax,
+                                           const Axis &ay, int r0, int r1, int LW, Body &&body,
+                                           EndSphere &&end_sphere, unsigned long long only = ~0ull);
+
+// The table walk of slice [lo, hi): same chunks, same body calls as walk_slice (the order of the spheres differs only
+// where wide ones are deferred; the forward's minima do not depend on it).
+template <int kSphereCost, bool ROWFREE, typename Body, typename EndSphere>
+__device__ __forceinline__ void walk_slice_table(const WaveList &w, int J, int lo, int hi, int lane, const Axis &ax,
+                                                 const Axis &ay, int r0, int r1, int LW, const RunTab rt, Body &&body,
+                                                 EndSphere &&end_sphere) {
+  // lanes = spheres: this slice's chunk range of every sphere, packed for one v_readlane per run
+  const int wstart = w.item.w, wend = w.end, base = wstart + kSphereCost;
+  const int cb = lo <= base ? 0 : (lo - base + kChunkCost - 1) >> kChunkShift;
+  const int ce = min((wend - base) >> kChunkShift, (hi - base + kChunkCost - 1) >> kChunkShift);
+  const int v1 = w.item.y & 0xffff, inv15 = (int)((unsigned)w.item.y >> 16), ph = (inv15 << 6) >> 15;
+  const bool active = lane < J && wend > wstart && cb < ce;
+  const bool narrow = ((w.item.z >> 8) & 0xff) == 1;
+  // (cb, ce < 4096: the launcher keeps the regions of a table kernel below that many rows)
+  const int pk = cb | (ce << 12) | (ph << 24) | ((ROWFREE && v1 < r1 - 1) ? (int)0x80000000u : 0);
+  unsigned long long m = __ballot(active && narrow);
+  const unsigned long long wide = __ballot(active && !narrow);
+  if (m) {
+    const uint2 *tl = rt.tab + lane;
+    int j = __builtin_ctzll(m);
+    uint2 t = tl[j * kWave];
+    float4 rn = rt.run[j];                       // uniform address: an LDS broadcast
+    while (true) {
+      m &= m - 1;
+      const int jn = m ? __builtin_ctzll(m) : j;
+      const int pkj = rl(pk, j);
+      const uint2 tn = tl[jn * kWave];           // the next run's entry and record, requested a run ahead
+      const float4 rnn = rt.run[jn];
+      int c = pkj & 0xfff;
+      const int c_end = (pkj >> 12) & 0xfff, phj = (pkj >> 24) & 0x7f;
+      const int cph = c * phj, dcell = phj * LW;
+      int cell = (int)(t.y & 0xffffffu) + (cph - r0) * LW;
+      const float cav = __uint_as_float(t.x);
+      // row coordinates are multiples of 300 / S below 2^24: the products and sums are exact, the fused form gives
+      // axis_coord_t(ay, v0 + c * ph + ly) to the bit
+      float yg = __builtin_fmaf((float)((int)(t.y >> 24) + cph), ay.mul, rn.z);
+      const float dyg = (float)phj * ay.mul;
+      const float4 s = make_float4(0.f, rn.x, rn.y, 0.f);   // (the bodies of the table kernels use y and z)
+      if (ROWFREE && pkj < 0) {
+        for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell)
+          body(j, s, cell, cell + dcell, 0.f, cav, yg, yg + dyg, true, true, c + 1 < c_end, std::false_type());
+      } else {
+        const float ylim = rn.w;                 // (a lane outside the packing never hits: its column term is -1)
+        for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell) {
+          const float ygb = yg + dyg;
+          body(j, s, cell, cell + dcell, 0.f, cav, yg, ygb, yg <= ylim, ygb <= ylim, c + 1 < c_end, std::true_type());
+        }
+      }
+      end_sphere(j);
+      if (!m) break;
+      j = jn; t = tn; rn = rnn;
+    }
+  }
+  if (wide) walk_slice<true, kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere, wide);
+}
 
 // Walk the chunks whose weight position lies in [lo, hi) (wave-uniform), sphere by
 // sphere.  Per sphere the lane layout (lx, ly) and the column term c = r*r - dx*dx are
@@ -240,14 +362,16 @@ __device__ __forceinline__ float axis_coord_t(const Axis &a, int u);
 // forms q = ca - (yg - y)^2 -- the reference's association -- when it needs it (the backward
 // only for pixels the sphere owns).
 // `end_sphere(j)` closes a run on sphere j.
+// (`only`: the spheres to visit -- all of them, or the wide ones a table walk has left)
 template <bool POW2, int kSphereCost, bool ROWFREE, typename Body, typename EndSphere>
 __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int hi, int lane, const Axis &ax,
                                            const Axis &ay, int r0, int r1, int LW, Body &&body,
-                                           EndSphere &&end_sphere) {
+                                           EndSphere &&end_sphere, unsigned long long only) {
   int j = __popcll(__ballot(lane < J && w.end <= lo));   // prefixes are non-decreasing
   while (j < J) {
     const int wstart = rl(w.item.w, j);
     if (wstart >= hi) break;
+    if (!((only >> j) & 1ull)) { ++j; continue; }
     const int wend = rl(w.end, j);
     const int base = wstart + kSphereCost;
     // chunk c sits at base + c * kChunkCost and belongs to the slice that holds that position
@@ -322,10 +446,11 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
 // `shares` gives the four age groups (waves 4g..4g+3) their part of the list, one byte per
 // group, oldest first, summing to 256 (the launcher normalises).  Other workgroup sizes
 // split equally.
-template <bool POW2, int kSphereCost, bool ROWFREE, typename Body, typename EndSphere>
+template <bool POW2, int kSphereCost, bool ROWFREE, bool TABLE = false, typename Body, typename EndSphere>
 __device__ __forceinline__ void walk_my_slice(const WaveList &w, int J, int total, int wave, int nwaves, int shares,
                                               int lane, const Axis &ax, const Axis &ay, int r0, int r1, int LW,
-                                              Body &&body, EndSphere &&end_sphere) {
+                                              Body &&body, EndSphere &&end_sphere,
+                                              const RunTab rt = RunTab{nullptr, nullptr}) {
   wave = rfl(wave);   // everything that steers the loops is wave-uniform: keep it in SGPRs
   total = rfl(total);
   int lo, hi;
@@ -340,7 +465,13 @@ __device__ __forceinline__ void walk_my_slice(const WaveList &w, int J, int tota
     lo = (int)(((long long)wave * total) / nwaves);
     hi = (int)(((long long)(wave + 1) * total) / nwaves);
   }
-  if (lo < hi) walk_slice<POW2, kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere);
+  if (lo >= hi) return;
+  if constexpr (TABLE) {
+    static_assert(POW2, "the run table carries exact power-of-two coordinates");
+    walk_slice_table<kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, rt, body, end_sphere);
+  } else {
+    walk_slice<POW2, kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere);
+  }
 }
 
 // image axis coordinate with the power-of-two case resolved at compile time
@@ -493,7 +624,7 @@ __host__ __device__ __forceinline__ int max_box_pitch(int W) { return ((W + 3) &
 // other waves fill that time with the z-buffer initialisation and then with the
 // BACKGROUND ROWS: rows no sphere's box touches (half of a hand crop) are stored straight
 // from registers before the first barrier and never pass through LDS or the decode.
-template <bool OWNER, bool VEC4, bool POW2, bool PERSIST, bool BOX>
+template <bool OWNER, bool VEC4, bool POW2, bool PERSIST, bool BOX, bool TABLE = false>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_,
                        float *__restrict__ depth, uint8_t *__restrict__ argmin, int rows_per_region_,
@@ -506,6 +637,11 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   int *s_flag = reinterpret_cast<int *>(smem + kOffFlags);
   float4 *s_next = reinterpret_cast<float4 *>(smem + kOffNext);
   Key *zbuf = reinterpret_cast<Key *>(smem + kHdrBytes);
+  // TABLE (whole-region z-buffer, one workgroup per CU, not persistent): the run table follows the z-buffer, the
+  // spheres' run records take the place of the next crop's records (build_run_table)
+  static_assert(!TABLE || (POW2 && VEC4 && !BOX && !PERSIST), "run table: whole-crop workgroups on power-of-two images");
+  uint2 *s_tab = reinterpret_cast<uint2 *>(smem + kHdrBytes + (size_t)zcells_ * sizeof(Key));
+  float4 *s_run = s_next;
 
   // PERSISTENT workgroups: with more crops than the launch has workgroups (gridDim.x < N) a workgroup takes crops
   // blockIdx.x, blockIdx.x + gridDim.x, ...  The youngest wave requests the NEXT crop's records right after the
@@ -541,12 +677,22 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   // wave 0's LDS copy after the barrier (their requests would only lengthen the memory queue)
   const int wave_s = rfl(wave);
   const bool list_wave = wave_s == 0;
-  const int nbgw = min(kBgWaves, nwaves - 1);
-  const bool bg_wave = nwaves == 1 || (wave_s >= 1 && wave_s <= nbgw);
+  // TABLE (16 waves): one job per wave in front of the first barrier, the vector arithmetic on the OLD waves (a
+  // young wave gets an instruction through every ~12 cycles there, tools/exp_ztime.py: six of them took 3-3.9 k
+  // cycles over the table): wave 0 the work list and then a seventh of the run table, waves 1 .. 3 the rest of
+  // it, waves 4 .. 7 the z-buffer initialisation, the YOUNG waves 8 .. 15 the background rows -- without LDS
+  // traffic of their own in front of the request their records are there ~0.7 k cycles after the wave's start.
+  // (Measured and not kept on this split: the storing waves at raised priority, +0.1 us; the initialisation of the
+  // touched rows only, once the records are in, +0.2 us; other work-list shares.)
+  const int nbgw = TABLE ? 8 : min(kBgWaves, nwaves - 1);
+  const int bg_first = TABLE ? 8 : 1;
+  const bool bg_wave = nwaves == 1 || (wave_s >= bg_first && wave_s < bg_first + nbgw);
   const bool valid = lane < J;
   const bool pf_wave = wave_s == nwaves - 1 && !list_wave && !bg_wave;
+  const bool tab_wave = TABLE && wave_s >= 1 && wave_s <= 3;
+  const bool init_wave = TABLE && wave_s >= 4 && wave_s <= 7;
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid && (list_wave || bg_wave)) sph = crop_it == 0 ? spheres[(size_t)n * J + lane] : s_next[lane];
+  if (valid && (list_wave || bg_wave || tab_wave)) sph = crop_it == 0 ? spheres[(size_t)n * J + lane] : s_next[lane];
   // (the box variant sits at gfx950's occupancy limit of 80 SGPRs: its axis constants live in vector registers;
   // they are not among the preloaded arguments -- touched here, behind the records' request, not in front of it)
   if (BOX) asm volatile("" : "+v"(ax.mul), "+v"(ay.mul), "+v"(ax.half), "+v"(ay.half));
@@ -568,7 +714,16 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   // in round 3 and dropped, tools/exp_ztime.py: the idle waves 8 .. 15 alone -- the young waves' LDS stores take
   // until 3.0-3.8 k cycles and hold the barrier; whole-crop z-buffers on the central half of the rows first and the
   // touched rows outside it by the storing waves -- their stores start later than the initialisation saves)
-  init_zbuf(BOX ? min(zcells, rh * max_box_pitch(W)) : rh * (W + kRowPad));
+  if (!TABLE) init_zbuf(BOX ? min(zcells, rh * max_box_pitch(W)) : rh * (W + kRowPad));
+  if (init_wave) {   // TABLE: the whole z-buffer by waves 4 .. 7
+    constexpr int per16 = 16 / sizeof(Key);
+    const ulonglong2 v2 = make_ulonglong2((unsigned long long)bg, (unsigned long long)bg);
+    const uint4 v4 = make_uint4((uint32_t)bg, (uint32_t)bg, (uint32_t)bg, (uint32_t)bg);
+    for (int i = tid - 256; i < rh * (W + kRowPad) / per16; i += 256) {   // (pitch and key size: whole 16-byte pieces)
+      if (OWNER) reinterpret_cast<ulonglong2 *>(zbuf)[i] = v2;
+      else reinterpret_cast<uint4 *>(zbuf)[i] = v4;
+    }
+  }
 
   // Waves 1..kBgWaves store the background rows while wave 0 builds the list: they are the
   // first to finish the z-buffer initialisation (the SIMD arbitration favours old waves) and
@@ -585,12 +740,23 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     const unsigned long long low = __ballot(valid && sph.z <= kBackground);
     const unsigned long long behind = __ballot(valid && sph.z > kBackground);
     bool too_big;   // excluded by the launcher (W <= kMaxFastWidth, H <= 32768)
-    const int total = build_work_list<kSphereCostFwd>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
+    const int total = build_work_list<kSphereCostFwd>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big,
+                                                      TABLE ? s_run : nullptr);
     if (lane == 0) {
       s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
       s_flag[1] = total;
       s_flag[12] = behind != 0ull;   // only a sphere centred behind the background can hit at exactly 100.0 (tie_owner)
     }
+  }
+
+  if (TABLE && wave_s <= 3) {
+    // sphere j belongs to slot j mod 7: slots 0-1 -> wave 1, 2-3 -> wave 2, 4-5 -> wave 3, slot 6 -> the list wave,
+    // which has a third of its time in front of the barrier left when the list stands
+    const unsigned long long every7 = 0x8102040810204081ull;   // bits 0, 7, 14, ..., 63
+    const unsigned long long all = J >= 64 ? ~0ull : ((1ull << J) - 1ull);
+    const int sl = wave_s == 0 ? 6 : 2 * (wave_s - 1);
+    const unsigned long long mine = ((every7 << sl) | (wave_s == 0 ? 0ull : every7 << (sl + 1))) & all;
+    build_run_table<POW2>(sph, valid, ax, ay, kx, ky, W, r0, r1, W + kRowPad, s_tab, lane, mine);
   }
 
   float *out = depth + (size_t)n * H * W;
@@ -651,10 +817,10 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
       }
     }
   };
-  if (VEC4 && bg_wave) store_background(nwaves == 1 ? 0 : wave_s - 1, nwaves == 1 ? 1 : nbgw);
+  if (VEC4 && bg_wave) store_background(nwaves == 1 ? 0 : wave_s - bg_first, nwaves == 1 ? 1 : nbgw);
   if (!BOX) {
-    if (VEC4 && wave_s == (nwaves == 1 ? 0 : 1) && lane == 0) { s_flag[2] = ua; s_flag[3] = ub; }   // for the other waves
-  } else if (wave_s == (nwaves == 1 ? 0 : 1) && lane == 0) {
+    if (VEC4 && wave_s == (nwaves == 1 ? 0 : bg_first) && lane == 0) { s_flag[2] = ua; s_flag[3] = ub; }   // for the other waves
+  } else if (wave_s == (nwaves == 1 ? 0 : bg_first) && lane == 0) {
     // Everything the other waves derive from the box, computed ONCE (the stores above drain meanwhile): sixteen
     // waves repeating this scalar arithmetic -- a division among it -- after the barrier cost 2 k cycles per crop.
     const int cv0 = bx.x, cv1 = bx.y;
@@ -680,7 +846,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     s_flag[11] = over ? min(r1, (r0 + (out_hi + row_len - 1) / row_len + kTileH - 1) & ~(kTileH - 1)) : r1;
   }
   __syncthreads();
-  if (!(list_wave || bg_wave)) sph = s_sph[lane];
+  if (!(list_wave || bg_wave || tab_wave)) sph = s_sph[lane];
   const bool has_next = PERSIST && n + crop_step < N;   // (the launcher keeps a prefetch wave whenever gridDim.x < N)
   float4 sph_next = make_float4(0.f, 0.f, 0.f, 0.f);
   if (pf_wave && has_next && valid) sph_next = spheres[(size_t)(n + crop_step) * J + lane];
@@ -709,7 +875,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
       wl.item = s_items[lane];
       wl.end = s_ends[lane];
       Key *zb = zbuf - (p0 * pitch + cu0);   // cell of pixel (v, u) = zb[v * pitch + u]
-      walk_my_slice<POW2, kSphereCostFwd, true>(
+      walk_my_slice<POW2, kSphereCostFwd, true, TABLE>(
           wl, J, s_flag[1], wave, nwaves, shares, lane, ax, ay, 0, clip, pitch,
           [&](int j, const float4 s, int cell_a, int cell_b, float, float ca, float yga, float ygb, bool ok_a,
               bool ok_b, bool has_b, auto row_test) {
@@ -737,7 +903,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
               put(zb + cell_a, s.z - sqrt_rn(qa));
             }
           },
-          [](int) {});
+          [](int) {}, RunTab{s_tab, s_run});
     }
     if (pf_wave && has_next) s_next[lane] = sph_next;   // (arrived long ago: the wave's own scan slice lies in between)
     __syncthreads();

@@ -13,13 +13,15 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["zbuf", "general", "zbuf-small-lds", "zbuf-4-waves", "zbuf-bands"])
+@pytest.fixture(scope="module", params=["zbuf", "general", "zbuf-small-lds", "zbuf-4-waves", "zbuf-bands",
+                                        "zbuf-no-run-table"])
 def ops(request):
     """Every test runs on the fast LDS z-buffer kernels, on the general tile
     kernels, on the z-buffer kernels squeezed into 16 KB of LDS (many row regions
     per crop, several passes over the touched rows in the backward), with 4-wave forward /
     8-wave backward workgroups, and with a 12-KB forward z-buffer (the rows of a crop's
-    touched box beyond it go through the tile code)."""
+    touched box beyond it go through the tile code), and with the forward's run table off (whole-crop
+    workgroups start their runs from it by default, i.e. under "zbuf")."""
     from spherehand_amd import ops as o
     assert torch.cuda.is_available()
     o.set_tuning(o.TUNE_FORCE_GENERAL, 1 if request.param == "general" else 0)
@@ -34,8 +36,10 @@ def ops(request):
     # the fused kernel's box variant: with half of a CU's LDS, and squeezed into 28 KB (rows of a box beyond that go
     # through the tile code)
     o.set_tuning(o.TUNE_MSE_BOX, {"zbuf-4-waves": 1, "zbuf-bands": 28 * 1024}.get(request.param, -1))
+    o.set_tuning(o.TUNE_FWD_RUN_TABLE, 0 if request.param == "zbuf-no-run-table" else -1)
     yield o
     o._shr_test_general = False
+    o.set_tuning(o.TUNE_FWD_RUN_TABLE, -1)
     o.set_tuning(o.TUNE_FWD_ZBUF_BYTES, 0)
     o.set_tuning(o.TUNE_MSE_BOX, -1)
     o.set_tuning(o.TUNE_BWD_WAVES, 0)
@@ -388,3 +392,41 @@ def test_persistent_workgroups_equal_one_workgroup_per_crop(oracle, S, wgs):
     ok = ~np.isnan(ref)                                  # (a NaN's payload is not part of the contract)
     assert np.array_equal(np.isnan(res[wgs][0]), ~ok)
     assert np.array_equal(res[wgs][0][ok].view(np.uint32), ref[ok].view(np.uint32))
+
+
+@pytest.mark.parametrize("S,J", [(128, 41), (128, 64), (64, 41), (256, 41), (32, 5)])
+def test_run_table_equals_the_arithmetic_run_start(oracle, S, J):
+    """Whole-crop forward workgroups start a run on a sphere from an LDS table (built once per sphere by the idle
+    waves) instead of recomputing the lane layout, column term, cell and row coordinate per run: same operations,
+    so depth and owner map are bit-identical with the table on and off, and equal to the oracle's.  Hand crops, random
+    spheres (boxes clipped by the last row: the row-test path), spheres wider than a wave (arithmetic path inside
+    the table kernel) and J = 64 (the table does not fit behind a 64-bit 128 x 128 z-buffer: launcher falls back)."""
+    from spherehand_amd import ops
+    rs = np.random.RandomState(S + J)
+    g = golden("g3_batch256.npz")
+    hand = spheres_from(g["centres"], g["radii"])[:24]
+    if J != 41:
+        hand = np.concatenate([hand, hand], 1)[:, :J] if J > 41 else hand[:, :J]
+    rnd = np.concatenate([rs.uniform(-160, 160, (24, J, 2)), rs.uniform(-60, 120, (24, J, 1)),
+                          rs.uniform(0.05, 45, (24, J, 1))], -1).astype(np.float32)
+    wide = rnd.copy()
+    wide[:, : J // 2, 3] = rs.uniform(80, 140, (24, J // 2))       # boxes wider than 64 lanes at S >= 128
+    sp = np.ascontiguousarray(np.concatenate([hand, rnd, wide], 0).astype(np.float32))
+    out = {}
+    try:
+        for mode in (0, -1):
+            ops.set_tuning(ops.TUNE_FWD_RUN_TABLE, mode)
+            for flags in (0, 1):
+                d, a = ops.sphere_raster_fwd(dev(sp), S, S, want_argmin=True, flags=flags)
+                out[mode, flags] = (d.cpu().numpy(), a.cpu().numpy())
+            out[mode, "depth"] = ops.sphere_raster_fwd(dev(sp), S, S).cpu().numpy()
+    finally:
+        ops.set_tuning(ops.TUNE_FWD_RUN_TABLE, -1)
+    od, oa = oracle.sphere_raster_fwd(sp, S, S)
+    for mode in (0, -1):
+        assert np.array_equal(bits(out[mode, 0][0]), bits(od)), mode
+        assert np.array_equal(out[mode, 0][1], oa), mode
+        assert np.array_equal(bits(out[mode, 1][0]), bits(od)), mode
+        assert np.array_equal(bits(out[mode, "depth"]), bits(od)), mode
+        fg = od < 100                                        # (touched-rows mode: untouched rows stay unwritten)
+        assert np.array_equal(out[mode, 1][1][fg], oa[fg]), mode
