@@ -350,6 +350,65 @@ __device__ __forceinline__ void walk_slice_table(const WaveList &w, int J, int l
   if (wide) walk_slice<true, kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere, wide);
 }
 
+// The same entry without a table (any power-of-two kernel): the slice's chunk ranges packed by one vector pass, the
+// spheres with work iterated over a mask, and a run's broadcasts -- ONE for its chunk range, the item's three words,
+// the record -- issued back to back with no branch between them; the per-lane set-up is walk_slice's, operation for
+// operation.  walk_slice reads a sphere's weight range, branches, reads its end, branches, reads the item, branches:
+// every step waits for a v_readlane to reach the scalar unit and for a branch to refill (tools/exp_walkclk.py: ~750
+// cycles from the top of a run to its first chunk, 47 runs per hand crop).
+template <int kSphereCost, bool ROWFREE, typename Body, typename EndSphere>
+__device__ __forceinline__ void walk_slice_packed(const WaveList &w, int J, int lo, int hi, int lane, const Axis &ax,
+                                                  const Axis &ay, int r0, int r1, int LW, Body &&body,
+                                                  EndSphere &&end_sphere) {
+  const int wstart = w.item.w, wend = w.end, base = wstart + kSphereCost;
+  const int cb = lo <= base ? 0 : (lo - base + kChunkCost - 1) >> kChunkShift;
+  const int ce = min((wend - base) >> kChunkShift, (hi - base + kChunkCost - 1) >> kChunkShift);
+  const int v1l = w.item.y & 0xffff, inv15l = (int)((unsigned)w.item.y >> 16), phl = (inv15l << 6) >> 15;
+  const bool active = lane < J && wend > wstart && cb < ce;
+  const bool narrow = ((w.item.z >> 8) & 0xff) == 1;
+  // (cb, ce < 4096: the caller sends taller regions through walk_slice)
+  const int pk = cb | (ce << 12) | (phl << 24) | ((ROWFREE && v1l < r1 - 1) ? (int)0x80000000u : 0);
+  unsigned long long m = __ballot(active && narrow);
+  const unsigned long long wide = __ballot(active && !narrow);
+  while (m) {
+    const int j = __builtin_ctzll(m);
+    m &= m - 1;
+    const int pkj = rl(pk, j), geom = rl(w.item.x, j), rows = rl(w.item.y, j), cols = rl(w.item.z, j);
+    const float4 s = make_float4(readlane_f(w.sph.x, j), readlane_f(w.sph.y, j), readlane_f(w.sph.z, j),
+                                 readlane_f(w.sph.w, j));
+    int c = pkj & 0xfff;
+    const int c_end = (pkj >> 12) & 0xfff, ph = (pkj >> 24) & 0x7f;
+    const int u0 = geom & 0xffff, v0 = (int)((unsigned)geom >> 16);
+    const int v1 = rows & 0xffff, inv15 = (int)((unsigned)rows >> 16);
+    const int v1c = min(v1, r1 - 1), pw = cols & 0xff;
+    const float rr = s.w * s.w;
+    const int ly = __mul24(lane, inv15) >> 15;
+    const int lx = lane - __mul24(ly, pw);
+    const bool packed = ly < ph;
+    const int u = u0 + lx;
+    const float dx = axis_coord_t<true>(ax, u) - s.x;
+    const float ca = rr - dx * dx;
+    const int v = v0 + c * ph + ly;
+    int cell = __mul24(v - r0, LW) + u;
+    const int dcell = ph * LW;
+    const float cav = packed ? ca : -1.f;
+    float yg = axis_coord_t<true>(ay, v);
+    const float dyg = (float)ph * ay.mul;
+    if (ROWFREE && pkj < 0) {
+      for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell)
+        body(j, s, cell, cell + dcell, dx, cav, yg, yg + dyg, packed, packed, c + 1 < c_end, std::false_type());
+    } else {
+      const float ylim = packed ? axis_coord_t<true>(ay, v1c) + 0.5f * ay.mul : -3.0e38f;
+      for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell) {
+        const float ygb = yg + dyg;
+        body(j, s, cell, cell + dcell, dx, cav, yg, ygb, yg <= ylim, ygb <= ylim, c + 1 < c_end, std::true_type());
+      }
+    }
+    end_sphere(j);
+  }
+  if (wide) walk_slice<true, kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere, wide);
+}
+
 // Walk the chunks whose weight position lies in [lo, hi) (wave-uniform), sphere by
 // sphere.  Per sphere the lane layout (lx, ly) and the column term c = r*r - dx*dx are
 // set up once; a chunk then costs its row coordinate, dy*dy and one subtraction before
@@ -469,6 +528,9 @@ __device__ __forceinline__ void walk_my_slice(const WaveList &w, int J, int tota
   if constexpr (TABLE) {
     static_assert(POW2, "the run table carries exact power-of-two coordinates");
     walk_slice_table<kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, rt, body, end_sphere);
+  } else if constexpr (POW2) {
+    if (r1 - r0 < 4096) walk_slice_packed<kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere);
+    else walk_slice<POW2, kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere);
   } else {
     walk_slice<POW2, kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere);
   }
