@@ -1,3 +1,9 @@
+#!/bin/bash
+# A/B of two builds of the library on ONE box, alternating, each once under rocprofv3 --kernel-trace --stats and once
+# unprofiled (-> profiles/r03_ab_rocprof.txt).  tools/libshr_round_start.so = the library of the commit to compare with:
+#   git worktree add /tmp/old <commit> && (cd /tmp/old && python -m spherehand_amd.build) &&
+#   cp /tmp/old/spherehand_amd/libspherehand_hip.so tools/libshr_round_start.so && git worktree remove --force /tmp/old
+# (tools/*.so is git-ignored and travels with gpurun).  Run on the GPU box from the repo root: bash tools/ab_rocprof.sh
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/ab; rm -rf $O; mkdir -p $O
 cp spherehand_amd/libspherehand_hip.so /tmp/new.so
