@@ -147,20 +147,6 @@ int shr_data_to_model_partial(const float *depth, const int32_t *depth_index,
                               int N, int J, int H, int W, int parts, float *loss_parts,
                               float *grad_parts, void *stream);
 
-/* The same through a device-side BAND QUEUE (round 3): every resident wave draws bands of 256-pixel units -- of any
- * crop -- from a counter in `workspace`, adds a band's fixed-point sums to the crop's 64-bit accumulators there, and
- * the wave that completes a crop's last band writes loss_sum[n] / grad_centres[n] (one result per crop; the same
- * integers as the per-crop kernel: bit-identical results).  workspace: at least shr_data_to_model_ws_bytes(N, J)
- * bytes of device memory, 8-byte aligned, ZEROED ONCE by the caller; every completed launch leaves it ready for the
- * next one (launches that share a workspace must be ordered on one stream; after a failed launch zero it again).
- * Why: one workgroup per crop makes every workgroup resident at once and the kernel ends with its most loaded CU
- * (DESIGN.md 4.3). */
-long long shr_data_to_model_ws_bytes(int N, int J);
-int shr_data_to_model_queued(const float *depth, const int32_t *depth_index,
-                             const float *centres, int centre_stride, const float *radii,
-                             int N, int J, int H, int W, float *loss_sum, float *grad_centres,
-                             void *workspace, long long workspace_bytes, void *stream);
-
 /* Fused render-and-compare: the model->data term of mesh/multiview_utility.py:98-101 and
  * :107-113 (MSELoss(BallRender(...).min(), observed)) with its whole backward, one
  * launch: e = raster(spheres[n]) - target[target_index ? target_index[n] : n],

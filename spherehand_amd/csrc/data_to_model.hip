@@ -398,447 +398,6 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
   }
 }
 
-// QUEUED variant (round 3): the bands of ALL crops form one queue in a caller-provided workspace and every resident
-// WAVE draws from it with one device-scope atomic per band -- a wave carries its own sphere table, gradient table and
-// ring in LDS, switches crop when its next band belongs to another one, and adds a band's fixed-point sums to the
-// crop's 64-bit accumulators in the workspace; the wave that completes a crop's LAST band converts them (integer
-// sums: the result is the per-crop kernel's, bit for bit, whatever the schedule) and leaves the workspace zeroed.
-// Why: with one workgroup per crop every workgroup is resident at once (1152 crops = 4.5 per CU) and a CU that holds
-// five crops, or heavier ones, finishes 20 us after the average one (a wave lives 35-38 of the kernel's 55 us);
-// fewer resident workgroups pulling whole crops lose more than they balance.
-// ONE counter for the whole launch does not work on this part: a device-scope atomic on one address costs ~31 ns
-// whoever issues it (eight XCDs, eight L2s: it is resolved at the memory side) -- 24 k bands = 755 us.  The crops
-// are therefore dealt to `groups` <= 64 GROUPS of consecutive crops with a counter each, and workgroup i draws from
-// group i mod groups: ~400 draws per counter, spread over the kernel's lifetime, and a group's 18 crops average
-// the crop-to-crop variation out.  Ordering needs no cache maintenance: every sum and flag in the workspace is
-// only ever touched by device-scope atomics, so "my sums, then my completion" is a wait for the sums' acknowledgements.
-// Workspace (64-bit words; zeroed once by the caller, left zero by every launch except the band counters it drew
-// from): [g] group g's two band counters (low / high 32 bits) -- a launch draws from the one its `phase` argument
-// names (the library alternates it per workspace) and zeroes the other, which the previous launch used --, then per
-// crop kD2mWsStride words: gradient rows [J][3], loss, bands done | NaN count << 32.
-constexpr int kD2mGroups = 64;                                    // band counters (a power of two)
-constexpr int kD2mWsHeader = kD2mGroups;                          // words: two 32-bit counters per group
-constexpr int kD2mWsStride = SHR_MAX_SPHERES * 3 + 2;             // words per crop
-
-template <bool WANT_GRAD>
-__global__ void __launch_bounds__(256)
-data_to_model_queue_kernel(const float *__restrict__ depth, const int *__restrict__ depth_index,
-                           const float *__restrict__ centres, int centre_stride, const float *__restrict__ radii, int N,
-                           int J, int H, int W, int band_units, float *__restrict__ loss_sum,
-                           float *__restrict__ grad_centres, unsigned long long *__restrict__ ws, unsigned int phase,
-                           int groups) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
-  // per wave: ring | table (cx, cy, cz, r) [64] | gradient rows [J][3] + loss (64-bit) | drawn bands [8]
-  const int acc_words = J * 3 + 1;
-  const int wave_bytes = 4 * kD2mRingPitch * 8 + SHR_MAX_SPHERES * 16 + ((acc_words * 8 + 15) & ~15) + 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  unsigned char *wbase = q_smem + wave * wave_bytes;
-  uint2 *ring = reinterpret_cast<uint2 *>(wbase);
-  float4 *s_c = reinterpret_cast<float4 *>(wbase + 4 * kD2mRingPitch * 8);
-  unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(wbase + 4 * kD2mRingPitch * 8 + SHR_MAX_SPHERES * 16);
-  int *bandq = reinterpret_cast<int *>(wbase + wave_bytes - 32);
-
-  unsigned int *hdr = reinterpret_cast<unsigned int *>(ws);
-  // group g: crops [g N / groups, (g + 1) N / groups), band ids [id_lo, id_hi)
-  const int grp = blockIdx.x & (groups - 1);
-  unsigned int *counter = hdr + 2 * grp + (phase & 1u);
-  if ((int)blockIdx.x < groups && tid == 0) hdr[2 * grp + ((phase & 1u) ^ 1u)] = 0u;   // the other counter is idle during this launch
-  unsigned long long *wcrop = ws + kD2mWsHeader;
-
-  for (int i = lane; i < acc_words; i += 64) s_acc[i] = 0ull;
-  const float rj = lane < J ? radii[lane] : 0.f;
-  const unsigned long long all = J >= 64 ? ~0ull : ((1ull << J) - 1ull);
-  const Axis ax = make_axis(W), ay = make_axis(H);
-  const int P = H * W;
-  const bool vec4 = (W % 4 == 0) && is_aligned16(depth) && (P % 4 == 0);
-  const int units = (P + 255) >> 8, nbands = (units + band_units - 1) / band_units;
-  const int id_lo = (int)(((long long)grp * N) / groups) * nbands;   // (< 2^31: the launcher)
-  const int total = (int)(((long long)(grp + 1) * N) / groups) * nbands;
-  const int wshift = (W & (W - 1)) == 0 ? __builtin_ctz(W) : -1;
-  long long loss_fx = 0;
-  // the crop whose table this wave holds (process side)
-  int cur_n = -1;
-  bool table_odd = false, dirty = false, nan_seen = false;
-  float4 cj = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float *dm = depth;                                        // the LOAD side's image
-
-  // a sphere's record by an explicit LDS read whose wait is placed by hand (see stage 1 below)
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const unsigned table_base = (unsigned)(size_t)s_c;
-  auto lds_request = [&](int j) {
-    f4 r;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(table_base + 16u * (unsigned)j));
-    return r;
-  };
-  auto lds_arrived = [&](f4 &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)); };
-
-  // ---- the search over `count` (<= 64 K) ring entries starting at `head`; lane l takes the K
-  // consecutive entries K l .. K l + K - 1 (neighbouring pixels: mostly one owner) -------------------
-  auto search = [&](auto kc, int head, int count) {
-    constexpr int K = decltype(kc)::value;
-    float px[K], py[K], pz[K], best[K];
-    int bj[K];
-    bool valid[K];
-    bool zbad = false;
-#pragma unroll
-    for (int i = 0; i < K; i++) {
-      const int idx = K * lane + i;
-      valid[i] = idx < count;
-      const uint2 e = ring[d2m_slot(head + (valid[i] ? idx : 0))];
-      px[i] = axis_coord(ax, (int)(e.x & 0xffffu));
-      py[i] = axis_coord(ay, (int)(e.x >> 16));
-      pz[i] = __uint_as_float(e.y);
-      zbad |= !(fabsf(pz[i]) < __builtin_inff());
-    }
-    auto eval = [&](const float4 c, int j, bool tie_rule) {
-#pragma unroll
-      for (int i = 0; i < K; i++) {
-        const float dx = px[i] - c.x, dy = py[i] - c.y, dz = pz[i] - c.z;
-        const float t = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        const float a = fabsf(__builtin_amdgcn_sqrtf(t) - c.w);   // <= 1 ulp root: the loss is continuous
-        const bool lt = tie_rule ? (a < best[i] || (a == best[i] && j < bj[i])) : (a < best[i]);
-        bj[i] = lt ? j : bj[i];
-        best[i] = lt ? a : best[i];
-      }
-    };
-    if (!table_odd && __ballot(zbad) == 0ull) {
-      // All inputs finite: no NaN can arise (an overflowing distance is +inf).  Strip bounds with
-      // lanes = spheres: rows of the first / last entry (pixel order inside a band).
-      const int v_lo = __builtin_amdgcn_readfirstlane((int)(ring[d2m_slot(head)].x >> 16));
-      const int v_hi = __builtin_amdgcn_readfirstlane((int)(ring[d2m_slot(head + count - 1)].x >> 16));
-      const float y_lo = axis_coord(ay, v_lo), y_hi = axis_coord(ay, v_hi);
-      // <= | ||p - c_j|| - r_j | for every point of the strip, up to the rounding the margins below cover
-      const float lb = fmaxf(fmaxf(y_lo - cj.y, cj.y - y_hi), 0.f) - cj.w;
-      unsigned long long m1 = __ballot(!(lb > 1e-3f)) & all;     // the sphere's y extent meets the strip (or nearly)
-      if (m1 == 0ull) m1 = all;
-#pragma unroll
-      for (int i = 0; i < K; i++) { best[i] = __builtin_inff(); bj[i] = 0; }
-      // stage 1, ascending j, strict '<': ties keep the first index (torch.min's convention).
-      // The NEXT sphere's record is requested before the current one is evaluated (explicit ds_read_b128 +
-      // s_waitcnt: left to itself hipcc reads the record at the top of the iteration and waits for it at once,
-      // one exposed LDS round trip per sphere).
-      {
-        unsigned long long m = m1;
-        int j = __builtin_ctzll(m);
-        f4 c = lds_request(j);
-        lds_arrived(c);
-        while (true) {
-          m &= m - 1;
-          const int jn = m ? __builtin_ctzll(m) : j;
-          f4 cn = lds_request(jn);
-          eval(make_float4(c.x, c.y, c.z, c.w), j, false);
-          lds_arrived(cn);
-          if (!m) break;
-          j = jn; c = cn;
-        }
-      }
-      // stage 2: what could still win or tie.  A point whose minimum stays above 50 is worth exactly 50
-      // with no gradient whatever the owner, so 50 caps the reach.
-      unsigned long long m2 = all & ~m1;
-      if (m2) {
-        float wmax = -__builtin_inff();
-#pragma unroll
-        for (int i = 0; i < K; i++) wmax = fmaxf(wmax, valid[i] ? best[i] : -__builtin_inff());
-        const float reach = fminf(wave_minmax_all<false>(wmax), 50.f) * 1.00001f + 1e-3f;
-        m2 &= __ballot(!(lb * 0.99999f > reach));
-        if (m2) {
-          int j = __builtin_ctzll(m2);
-          f4 c = lds_request(j);
-          lds_arrived(c);
-          while (true) {
-            m2 &= m2 - 1;
-            const int jn = m2 ? __builtin_ctzll(m2) : j;
-            f4 cn = lds_request(jn);
-            eval(make_float4(c.x, c.y, c.z, c.w), j, true);
-            lds_arrived(cn);
-            if (!m2) break;
-            j = jn; c = cn;
-          }
-        }
-      }
-    }
-    else {
-      // a NaN / infinity somewhere: every sphere in index order with torch.min's NaN rule
-      for (int j = 0; j < J; j++) {
-        const float4 c = s_c[j];
-#pragma unroll
-        for (int i = 0; i < K; i++) {
-          const float dx = px[i] - c.x, dy = py[i] - c.y, dz = pz[i] - c.z;
-          const float a = fabsf(__builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) - c.w);
-          if (j == 0 || ((best[i] == best[i]) && (a < best[i] || a != a))) { best[i] = a; bj[i] = j; }
-        }
-      }
-    }
-    bool nan = false;
-#pragma unroll
-    for (int i = 0; i < K; i++) {
-      if (valid[i]) {
-        if (best[i] != best[i]) nan = true;           // torch.clamp keeps NaN: the crop's loss is NaN
-        else loss_fx += (long long)__float2int_rn(fminf(fmaxf(best[i], 0.f), 50.f) * kLossScale);
-      }
-    }
-    if (__ballot(nan) != 0ull) nan_seen = true;
-    dirty = true;
-    if (WANT_GRAD) {
-      int g[K][3];
-      bool live[K];
-#pragma unroll
-      for (int i = 0; i < K; i++) {
-        const float4 c = s_c[bj[i]];
-        const float dx = px[i] - c.x, dy = py[i] - c.y, dz = pz[i] - c.z;
-        const float t2 = (dx * dx + dy * dy) + dz * dz;
-        // the sign decides the gradient's direction: correctly rounded root, as a host sqrtf
-        const float dist = (t2 >= 0.01f && t2 <= 1e12f) ? sqrt_rn(t2) : __builtin_sqrtf(t2);
-        const float t = dist - c.w;
-        live[i] = valid[i] && best[i] <= 50.f && dist != 0.f && t != 0.f && dist < __builtin_inff();
-        const float k = (t > 0.f ? -kGradScale : kGradScale) * __builtin_amdgcn_rcpf(dist);
-        g[i][0] = live[i] ? __float2int_rn(k * dx) : 0;
-        g[i][1] = live[i] ? __float2int_rn(k * dy) : 0;
-        g[i][2] = live[i] ? __float2int_rn(k * dz) : 0;
-      }
-      // a lane's K points are neighbouring pixels: those sharing point 0's owner go with it
-#pragma unroll
-      for (int i = 1; i < K; i++) {
-        const bool same = live[i] && live[0] && bj[i] == bj[0];
-        g[0][0] += same ? g[i][0] : 0; g[0][1] += same ? g[i][1] : 0; g[0][2] += same ? g[i][2] : 0;
-        live[i] = live[i] && !same;
-      }
-#pragma unroll
-      for (int i = 0; i < K; i++) {
-        if (live[i]) {
-          unsigned long long *row = s_acc + bj[i] * 3;
-          atomicAdd(row + 0, (unsigned long long)(long long)g[i][0]);
-          atomicAdd(row + 1, (unsigned long long)(long long)g[i][1]);
-          atomicAdd(row + 2, (unsigned long long)(long long)g[i][2]);
-        }
-      }
-    }
-  };
-
-  // ---- this wave's units: three loads in flight, compact, search ------------------------------
-  auto load_unit = [&](const D2mUnitIter &it, float z[4]) {
-    z[0] = z[1] = z[2] = z[3] = 100.f;
-    if (it.done) return;
-    const int p = it.unit * 256 + lane * 4;   // (dm: the load side's current image)
-    if (vec4) {
-      if (p < P) {
-        const float4 t = *reinterpret_cast<const float4 *>(dm + p);
-        z[0] = t.x; z[1] = t.y; z[2] = t.z; z[3] = t.w;
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; c++)
-        if (p + c < P) z[c] = dm[p + c];
-    }
-  };
-  // the LOAD iterator draws the bands (it runs three units ahead and may be up to three bands ahead: the drawn
-  // bands wait in a 4-entry queue), the PROCESS iterator follows the same sequence
-  // A drawn band: global id = crop * nbands + band.  The draw for the band AFTER the next one is in flight while the
-  // current one is loaded (its answer is needed a band later); the next band's crop is resolved -- image number,
-  // sphere records requested -- when the load side enters it, two units ahead of the process side.
-  int static_k = 0;
-  auto draw = [&]() {
-    int v = 0;
-#ifdef D2M_STATIC_DRAW   // (experiment: no atomics -- wave w of the group's waves takes bands w, w + waves, ...)
-    v = id_lo + (int)((blockIdx.x / groups) * 4 + wave) + static_k * (int)((gridDim.x / groups) * 4);
-    static_k++;
-    return v;
-#endif
-    if (lane == 0) v = id_lo + (int)atomicAdd(counter, 1u);
-    return v;
-  };
-  auto seek_global = [&](D2mUnitIter &it, int id, int &n_out) {
-    it.band = id;
-    it.done = id >= total;
-    const int n = it.done ? 0 : id / nbands;
-    const int b = id - n * nbands;
-    n_out = n;
-    it.unit = b * band_units;
-    it.unit_end = min(units, it.unit + band_units);
-  };
-  int q_put = 0, q_get = 0;
-  int v_next;                                       // the following draw, in flight (lane 0)
-  int load_n = -1, rec_n = -1;                      // the load side's crop; the crop whose records are pending
-  float rec_x = 0.f, rec_y = 0.f, rec_z = 0.f;      // ... lanes = spheres
-  auto enter_band_load = [&](D2mUnitIter &it, int id) {
-    int n;
-    seek_global(it, id, n);
-    if (lane == 0) bandq[q_put & 7] = id;
-    q_put++;
-    if (!it.done && n != load_n) {
-      load_n = n;
-      dm = depth + (size_t)(depth_index ? depth_index[n] : n) * P;
-      if (lane < J) {                               // the crop's records, for the process side to pick up
-        const float *p = centres + ((size_t)n * J + lane) * centre_stride;
-        rec_x = p[0]; rec_y = p[1]; rec_z = p[2];
-      }
-      rec_n = n;
-    }
-  };
-  auto advance_load = [&](D2mUnitIter &it) {
-    if (it.done) return;
-    if (++it.unit >= it.unit_end) {
-      const int id = __builtin_amdgcn_readfirstlane(v_next);
-      v_next = draw();
-      enter_band_load(it, id);
-    }
-  };
-  // the process side: crop switch, band end (flush + completion)
-  auto enter_crop = [&](int n) {
-    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < J) {
-      if (rec_n == n) c = make_float4(rec_x, rec_y, rec_z, rj);
-      else {
-        const float *p = centres + ((size_t)n * J + lane) * centre_stride;
-        c = make_float4(p[0], p[1], p[2], rj);
-      }
-      s_c[lane] = c;
-    }
-    const float inf = __builtin_inff();
-    const bool bad = !(fabsf(c.x) < inf) || !(fabsf(c.y) < inf) || !(fabsf(c.z) < inf) || !(fabsf(c.w) < inf);
-    table_odd = __ballot(bad) != 0ull;
-    cj = c;
-    cur_n = n;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  };
-  // A band's completion: its sums go to the crop's accumulators (device-scope atomics, acknowledged before the
-  // completion counts), the crop's band count goes up by one -- and the answer "was that the last band?" is read when
-  // the NEXT band completes (a returning device-scope atomic takes microseconds here; nothing else waits for it).
-  unsigned long long pend_old = 0ull;
-  int pend_n = -1;
-  auto resolve_pending = [&]() {
-    if (pend_n < 0) return;
-    const int n = pend_n;
-    pend_n = -1;
-    const unsigned int done_lo = __builtin_amdgcn_readfirstlane((unsigned int)pend_old);
-    if ((int)(done_lo + 1u) != nbands) return;
-    // the crop's last band: convert, and leave the workspace zeroed
-    unsigned long long *wc = wcrop + (size_t)n * kD2mWsStride;
-    if (WANT_GRAD)
-      for (int i = lane; i < J * 3; i += 64) {
-        const long long t = (long long)atomicExch(wc + i, 0ull);
-        grad_centres[(size_t)n * J * 3 + i] = (float)((double)t * (1.0 / (double)kGradScale));
-      }
-    if (lane == 0) {
-      const long long l = (long long)atomicExch(wc + SHR_MAX_SPHERES * 3, 0ull);
-      const unsigned long long st = atomicExch(wc + SHR_MAX_SPHERES * 3 + 1, 0ull);
-      loss_sum[n] = (st >> 32) ? __builtin_nanf("") : (float)((double)l * (1.0 / (double)kLossScale));
-    }
-  };
-  auto finish_band = [&](int n) {
-    resolve_pending();
-    unsigned long long *wc = wcrop + (size_t)n * kD2mWsStride;
-    if (dirty) {
-      if (loss_fx) atomicAdd(s_acc + J * 3, (unsigned long long)loss_fx);
-      loss_fx = 0;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      for (int i = lane; i < acc_words; i += 64) {
-        const unsigned long long v = s_acc[i];
-        if (v) {
-          atomicAdd(wc + (i < J * 3 ? i : SHR_MAX_SPHERES * 3), v);
-          s_acc[i] = 0ull;
-        }
-      }
-      dirty = false;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sums are acknowledged before the completion counts
-    }
-    pend_old = 0ull;
-    if (lane == 0) pend_old = atomicAdd(wc + SHR_MAX_SPHERES * 3 + 1, 1ull | (nan_seen ? (1ull << 32) : 0ull));
-    pend_n = n;
-    nan_seen = false;
-  };
-  auto advance_proc = [&](D2mUnitIter &it) {
-    if (it.done) return;
-    if (++it.unit >= it.unit_end) {
-      finish_band(cur_n);
-      const int id = __builtin_amdgcn_readfirstlane(bandq[q_get & 7]);
-      q_get++;
-      int n;
-      seek_global(it, id, n);
-      if (!it.done && n != cur_n) enter_crop(n);
-    }
-  };
-  D2mUnitIter itp, itl;
-  {
-    const int id0 = __builtin_amdgcn_readfirstlane(draw());
-    v_next = draw();
-    enter_band_load(itl, id0);
-    q_get = 1;
-    int n0;
-    seek_global(itp, id0, n0);
-    if (!itp.done) enter_crop(n0);
-  }
-#ifndef D2M_DEPTH
-#define D2M_DEPTH 2      // units in flight per wave (2: 55 us, 3: 59, 4: 58, 6: 69 for 1152 crops @128^2 -- registers)
-#endif
-  float zq[D2M_DEPTH][4];
-#pragma unroll
-  for (int d = 0; d < D2M_DEPTH; d++) { load_unit(itl, zq[d]); advance_load(itl); }
-  float (&z0)[4] = zq[0];
-  int head = 0, tail = 0;                         // ring positions (monotonic; masked on use)
-  while (!itp.done) {
-    const int p0 = itp.unit * 256 + lane * 4;
-    // foreground flags (mesh/render.py:138: background = d > 99), exclusive prefix in pixel order
-    bool fg[4];
-    int before = 0, total = 0;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      fg[c] = (p0 + c < P) && !(z0[c] > 99.0f);
-      const unsigned long long m = __ballot(fg[c]);
-      before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, before));
-      total += __builtin_popcountll(m);
-    }
-    if (total) {
-      // `before` = flagged pixels of LOWER lanes over all four components: this lane's entries start there
-      // (a lane's four pixels are consecutive: pixel order)
-      int pos = tail + before;
-      int vc, uc;
-      if (wshift >= 0) { vc = p0 >> wshift; uc = p0 & (W - 1); }
-      else { vc = p0 / W; uc = p0 - vc * W; }
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        while (uc >= W) { uc -= W; vc++; }      // never taken when W % 4 == 0
-        if (fg[c]) {
-          ring[d2m_slot(pos)] = make_uint2(((unsigned)vc << 16) | (unsigned)uc, __float_as_uint(z0[c]));
-          pos++;
-        }
-        uc++;
-      }
-      tail += total;
-    }
-    const bool band_end = itp.unit + 1 >= itp.unit_end;
-    if (tail - head >= kD2mGroup || (band_end && tail > head)) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // full searches; at the end of a band also what is left (a search never spans two bands)
-      while (true) {
-        const int avail = tail - head;
-        const int take = avail >= kD2mGroup ? kD2mGroup : ((band_end && avail > 192) ? avail : 0);
-        if (!take) break;
-        search(std::integral_constant<int, 4>(), head, take);
-        head += take;
-      }
-      if (band_end && tail > head) {
-        if (tail - head > 128) search(std::integral_constant<int, 3>(), head, tail - head);
-        else if (tail - head > 64) search(std::integral_constant<int, 2>(), head, tail - head);
-        else search(std::integral_constant<int, 1>(), head, tail - head);
-        head = tail;
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-#pragma unroll
-      for (int d = 0; d + 1 < D2M_DEPTH; d++) zq[d][c] = zq[d + 1][c];
-    }
-    load_unit(itl, zq[D2M_DEPTH - 1]); advance_load(itl);
-    advance_proc(itp);
-  }
-  resolve_pending();
-}
-
 }  // namespace shr
 
 namespace {
@@ -893,83 +452,6 @@ int launch_d2m(const float *depth, const int32_t *depth_index, const float *cent
   return (int)hipGetLastError();
 }
 }  // namespace
-
-// ---- queued variant: launcher ------------------------------------------------------------------------------------
-namespace {
-constexpr int kD2mMaxLds = 160 * 1024;
-int d2m_num_cus() {
-  int d = 0, v = 0;
-  if (hipGetDevice(&d) != hipSuccess) return 256;
-  return (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && v > 0) ? v : 256;
-}
-// The band counter a launch draws from alternates per workspace (the kernel zeroes the other one): a small
-// process-wide table keyed by the workspace pointer -- like the tuning hooks, not thread-safe.
-struct WsPhase { const void *ws; unsigned phase; };
-WsPhase g_ws_phase[32] = {};
-int g_ws_next = 0;
-unsigned next_phase(const void *ws) {
-  for (auto &e : g_ws_phase)
-    if (e.ws == ws) return e.phase++;
-  WsPhase &e = g_ws_phase[g_ws_next];
-  g_ws_next = (g_ws_next + 1) % 32;
-  e.ws = ws;
-  e.phase = 1;
-  return 0;   // (a workspace new to the table: both of its counters are zero -- it is zeroed, or at rest)
-}
-}  // namespace
-
-extern "C" long long shr_data_to_model_ws_bytes(int N, int J) {
-  (void)J;
-  if (N < 0) return 0;
-  return ((long long)shr::kD2mWsHeader + (long long)N * shr::kD2mWsStride) * 8;
-}
-
-extern "C" int shr_data_to_model_queued(const float *depth, const int32_t *depth_index, const float *centres,
-                                        int centre_stride, const float *radii, int N, int J, int H, int W,
-                                        float *loss_sum, float *grad_centres, void *workspace, long long workspace_bytes,
-                                        void *stream) {
-  using namespace shr;
-  if (N == 0) return SHR_OK;
-  if (!depth || !centres || !radii || !loss_sum || !workspace || N < 0 || J <= 0 || H <= 0 || W <= 0) return SHR_EINVAL;
-  if ((centre_stride != 3 && centre_stride != 4) || ((uintptr_t)workspace & 7u) != 0) return SHR_EINVAL;
-  if (workspace_bytes < shr_data_to_model_ws_bytes(N, J)) return SHR_EINVAL;
-  if (J > SHR_MAX_SPHERES || (long long)H * W > (1LL << 30) || H > 65535 || W > 65535) return SHR_ETOOLARGE;
-  const int units = (int)(((long long)H * W + 255) >> 8);
-  // bands: small enough that most of them are still in the queue when the first ones end, large enough that the
-  // remainder search at a band's end stays a small share (and at least D2M_DEPTH units, so that a wave's loads
-  // never run more than one band ahead of its searches)
-  int band_units = units / 20;
-  if (band_units > 8) band_units = 8;
-  if (g_d2m_band) band_units = g_d2m_band;
-  if (band_units < 2) band_units = 2;
-  const long long nbands = (units + band_units - 1) / band_units;
-  if ((long long)N * nbands > 0x7fffffffLL - 65536) return SHR_ETOOLARGE;
-  const int acc_words = J * 3 + 1;
-  const size_t wave_bytes = 4 * kD2mRingPitch * 8 + SHR_MAX_SPHERES * 16 + ((acc_words * 8 + 15) & ~15) + 32;
-  const size_t lds = 4 * wave_bytes;
-  int per_cu = (int)(kD2mMaxLds / lds);
-  if (per_cu > 5) per_cu = 5;                     // (92 VGPRs: five waves per SIMD)
-  if (per_cu < 1) per_cu = 1;
-  long long grid = (long long)d2m_num_cus() * per_cu;
-  const long long want = ((long long)N * nbands + 7) / 8;   // at least two bands per wave
-  if (grid > want) grid = want;
-  if (grid < 1) grid = 1;
-  // groups of >= 8 crops with >= 4 workgroups each (a power of two, <= 64)
-  int groups = kD2mGroups;
-  while (groups > 1 && (groups * 8 > N || groups * 4 > grid)) groups >>= 1;
-  grid -= grid % groups;
-  const unsigned phase = next_phase(workspace);
-  hipStream_t s = (hipStream_t)stream;
-  if (grad_centres)
-    hipLaunchKernelGGL((data_to_model_queue_kernel<true>), dim3((unsigned)grid), dim3(256), lds, s, depth, depth_index, centres,
-                       centre_stride, radii, N, J, H, W, band_units, loss_sum, grad_centres,
-                       reinterpret_cast<unsigned long long *>(workspace), phase, groups);
-  else
-    hipLaunchKernelGGL((data_to_model_queue_kernel<false>), dim3((unsigned)grid), dim3(256), lds, s, depth, depth_index, centres,
-                       centre_stride, radii, N, J, H, W, band_units, loss_sum, grad_centres,
-                       reinterpret_cast<unsigned long long *>(workspace), phase, groups);
-  return (int)hipGetLastError();
-}
 
 // launch-shape hooks behind shr_set_tuning (results never depend on them: the sums are integers)
 int shr::d2m_set_waves(int waves) {

@@ -188,23 +188,6 @@ class SphereRasterSSE(torch.autograd.Function):
         return grad * grad_sse.view(-1, 1, 1), None, None
 
 
-# The data->model kernels draw their bands from a device-side queue in a workspace (shr_data_to_model_queued): one
-# zeroed int64 tensor per (device, stream), grown when a call needs more; D2M_QUEUE = False keeps the
-# one-workgroup-per-crop kernels (tests compare the two: bit-identical).
-D2M_QUEUE = False
-_d2m_ws = {}
-
-
-def _d2m_workspace(device, N, J):
-    need = int(_lib.lib().shr_data_to_model_ws_bytes(int(N), int(J)))
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    t = _d2m_ws.get(key)
-    if t is None or t.numel() * 8 < need:
-        t = torch.zeros((max(need, 1 << 16) * 3 // 2 + 7) // 8, dtype=torch.int64, device=device)
-        _d2m_ws[key] = t
-    return t
-
-
 def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
     """depth [N,H,W], centres [N,J,3], radii [J] -> loss_sum [N] (and the unit
     gradient d loss_sum[n]/d centres [N,J,3]).  With depth_index [N] int32, depth is
@@ -223,15 +206,6 @@ def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
     if depth_index is not None:
         _check_index(depth_index, N, depth.shape[0], "depth_index")
     lib = _lib.lib()
-    if D2M_QUEUE and N > 0:
-        with _on(depth.device):
-            ws = _d2m_workspace(depth.device, N, J)
-            loss_sum = torch.empty((N,), dtype=torch.float32, device=depth.device)
-            grad = torch.empty((N, J, 3), dtype=torch.float32, device=depth.device) if want_grad else None
-            _lib.check(lib.shr_data_to_model_queued(_ptr(depth), _ptr(depth_index), _ptr(centres), 3, _ptr(radii), N, J, H, W,
-                                                    _ptr(loss_sum), _ptr(grad), _ptr(ws), ws.numel() * 8, _stream()),
-                       "shr_data_to_model_queued")
-        return (loss_sum, grad) if want_grad else loss_sum
     R = lib.shr_data_to_model_parts(N, int(H), int(W))     # large crops: R partial results per crop, added here
     with _on(depth.device):
         loss_sum = torch.empty((N, R), dtype=torch.float32, device=depth.device)
@@ -314,17 +288,11 @@ class MutualProjectionLossFused(torch.autograd.Function):
                 E = B * V
                 cen = spheres.index_select(0, diag_index)
                 cidx = index.index_select(0, diag_index)
-            Rd = 1 if D2M_QUEUE else lib.shr_data_to_model_parts(E, int(H), int(W))
+            Rd = lib.shr_data_to_model_parts(E, int(H), int(W))
             d2m = torch.empty((E, Rd), dtype=torch.float32, device=dev)
             gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
-            if D2M_QUEUE:
-                ws = _d2m_workspace(dev, E, J)
-                _lib.check(lib.shr_data_to_model_queued(_ptr(observed), _ptr(cidx), _ptr(cen), 4, _ptr(radii), E, J, H, W,
-                                                        _ptr(d2m), _ptr(gd2m), _ptr(ws), ws.numel() * 8, _stream()),
-                           "shr_data_to_model_queued")
-            else:
-                _lib.check(lib.shr_data_to_model_partial(_ptr(observed), _ptr(cidx), _ptr(cen), 4, _ptr(radii), E, J, H, W, Rd,
-                                                         _ptr(d2m), _ptr(gd2m), _stream()), "shr_data_to_model_partial")
+            _lib.check(lib.shr_data_to_model_partial(_ptr(observed), _ptr(cidx), _ptr(cen), 4, _ptr(radii), E, J, H, W, Rd,
+                                                     _ptr(d2m), _ptr(gd2m), _stream()), "shr_data_to_model_partial")
             loss = torch.empty(1, dtype=torch.float32, device=dev)
             want = ctx.needs_input_grad[2]
             gj = torch.empty((B, V, J, 3), dtype=torch.float32, device=dev) if want else None

@@ -138,54 +138,3 @@ def test_pair_losses_kernel_matches_the_modules():
     assert ref[0] > 0 and ref[1] > 0
     assert (b.grad - ref[2]).abs().max().item() <= 1e-5 * max(1.0, ref[2].abs().max().item())
     assert b.grad[:, 1:].abs().max().item() == 0          # the other views are not looked at
-
-
-@pytest.mark.parametrize("N,J,H,W", [(1152, 41, 128, 128), (96, 41, 256, 256), (225, 41, 64, 64), (7, 64, 130, 70),
-                                       (3, 1, 8, 8), (40, 5, 37, 53), (1, 41, 16, 16)])
-def test_data_to_model_band_queue_equals_the_per_crop_kernels(N, J, H, W):
-    """shr_data_to_model_queued (every resident wave draws bands of any crop from a counter in a workspace, 64-bit
-    fixed-point sums per crop, the wave that completes a crop's last band converts them) against the
-    one-workgroup-per-crop kernels: the same integers, hence BIT-IDENTICAL loss sums and gradients, with and without the
-    image index, on repeated launches through one workspace (the kernel leaves it ready: every accumulator zero),
-    for hand-like crops, ragged sizes, all-background crops and crops whose loss is NaN."""
-    from spherehand_amd import ops
-    rs = np.random.RandomState(N + H)
-    M = max(1, N // 3)
-    depth = np.where(rs.uniform(size=(M, H, W)) < 0.15, rs.uniform(-60, 60, (M, H, W)), 100.0).astype(np.float32)
-    depth[0] = 100.0                                              # an all-background image
-    if M > 2:
-        depth[2, H // 2, W // 2] = np.nan                         # a NaN depth value: that crop's loss is NaN
-    index = rs.randint(0, M, N).astype(np.int32)
-    centres = rs.uniform(-120, 120, (N, J, 3)).astype(np.float32)
-    if N > 4:
-        centres[4, 0, 1] = np.inf                                 # a non-finite record: the index-order path
-    radii = rs.uniform(5, 25, J).astype(np.float32)
-    d, c, r, ix = dev(depth), dev(centres), dev(radii), dev(index)
-    from spherehand_amd import _lib
-
-    def per_crop(index_t):                                        # one workgroup per crop, ONE part: one integer total per crop
-        lib = _lib.lib()
-        ls = torch.empty(N, device="cuda")
-        gr = torch.empty(N, J, 3, device="cuda")
-        _lib.check(lib.shr_data_to_model_partial(d.data_ptr(), index_t.data_ptr() if index_t is not None else None, c.data_ptr(), 3,
-                                                 r.data_ptr(), N, J, H, W, 1, ls.data_ptr(), gr.data_ptr(),
-                                                 torch.cuda.current_stream().cuda_stream), "partial")
-        return ls, gr
-    try:
-        ref = per_crop(ix)
-        ref_loss_only = ref[0]
-        ops.D2M_QUEUE = True
-        for rep in range(3):
-            got = ops.data_to_model(d, c, r, want_grad=True, depth_index=ix)
-            for a, b in zip(got, ref):
-                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), rep
-            assert torch.equal(ops.data_to_model(d, c, r, depth_index=ix).view(torch.int32), ref_loss_only.view(torch.int32))
-        torch.cuda.synchronize()
-        ws = ops._d2m_workspace(d.device, N, J)
-        assert int(ws[64:].abs().sum()) == 0                      # only the band counters (the first 64 words) may be non-zero
-        if N == M:                                               # without the index: crop n reads image n
-            ref2 = per_crop(None)
-            got2 = ops.data_to_model(d, c, r, want_grad=True)
-            assert torch.equal(got2[0].view(torch.int32), ref2[0].view(torch.int32)) and torch.equal(got2[1].view(torch.int32), ref2[1].view(torch.int32))
-    finally:
-        ops.D2M_QUEUE = True
