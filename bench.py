@@ -139,6 +139,19 @@ def rocprof_avg_us():
                     out[key + "_calls"] = int(r["Calls"])
     except (KeyError, ValueError):
         return None
+    # the same two launches from a C loop (tools/prof_cloop.py): the tracer's averages with the host out of the way
+    cl = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cloop_kernel_stats.csv")))
+    if cl:
+        try:
+            c = {"source": os.path.relpath(cl[-1], ROOT)}
+            for r in csv.DictReader(open(cl[-1])):
+                for key, name in (("fwd", "sphere_zbuf_fwd_kernel"), ("bwd", "sphere_zbuf_bwd_kernel")):
+                    if name in r["Name"] and key not in c:
+                        c[key] = round(float(r["AverageNs"]) / 1e3, 3)
+            if "fwd" in c and "bwd" in c:
+                out["launched_from_c"] = c
+        except (KeyError, ValueError):
+            pass
     return out if "fwd" in out and "bwd" in out else None
 
 
@@ -625,8 +638,10 @@ def main():
                          "launch_us": {"fwd": round(fwd_us, 3), "bwd": round(bwd_us, 3)},
                          "launch_us_is": "mean of 1000 back-to-back launches (HIP events on the launching stream, this "
                                          "process); `frac` uses it.  rocprof_avg_us = AverageNs of the committed "
-                                         "rocprofv3 --kernel-trace --stats run of this command (tracing adds the "
-                                         "difference: profiles/README.md)",
+                                         "rocprofv3 --kernel-trace --stats run of this command (the tracer "
+                                         "serialises the dispatches and, from Python, the host then costs more per "
+                                         "launch than the kernel takes; launched_from_c = the same launches from a C "
+                                         "loop under the tracer: profiles/README.md)",
                          "rocprof_avg_us": rocprof_avg_us(),
                          "owner_map": "touched rows only (SHR_RASTER_OWNER_TOUCHED_ROWS): %.1f %% of the owner bytes"
                                       % (100 * owner_written),
