@@ -1304,12 +1304,13 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
         wl, J, s_flag[1], wave, NW, shares, lane, ax, ay, r0, r1, LW,
         [&](int j, const float4 s, int cell_a, int cell_b, float dx, float ca, float yga, float ygb, bool ok_a,
             bool ok_b, bool has_b, auto) {
-          auto take = [&](int cell, float yg, bool ok) {
-            // lanes without a pixel may point past the pass: clamped, and never counted.  Most
-            // chunks own nothing: only the owner byte is looked at, dy and q are formed for owned
-            // pixels (a branch-free form with all four LDS reads in flight measured slower)
-            cell = min(cell, cell_max);
-            if (obuf[cell] == (uint8_t)j && ok) {
+          // lanes without a pixel may point past the pass: clamped, and never counted.  Most chunks own nothing: only
+          // the owner byte is looked at -- BOTH chunks' bytes requested together --, dy and q are formed for owned
+          // pixels (a branch-free form with all four LDS reads in flight measured slower)
+          const int ca_ = min(cell_a, cell_max), cb_ = min(cell_b, cell_max);
+          const uint8_t oa = obuf[ca_], ob = obuf[cb_];
+          auto take = [&](int cell, uint8_t o, float yg, bool ok) {
+            if (o == (uint8_t)j && ok) {
               const float dy = yg - s.y, q = ca - dy * dy;
               const float g = gbuf[cell];
               const float w = g * __builtin_amdgcn_rsqf(q);  // g / sqrt(q), ~1e-7 rel.
@@ -1319,8 +1320,8 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
               a3 -= w;
             }
           };
-          take(cell_a, yga, ok_a);
-          if (has_b) take(cell_b, ygb, ok_b);
+          take(ca_, oa, yga, ok_a);
+          if (has_b) take(cb_, ob, ygb, ok_b);
         },
         [&](int j) {
           // (the slot belongs to this wave: ds_add_f32 in program order, no read-back to wait for;
