@@ -366,22 +366,26 @@ __device__ __forceinline__ void walk_slice_packed(const WaveList &w, int J, int 
   const int v1l = w.item.y & 0xffff, inv15l = (int)((unsigned)w.item.y >> 16), phl = (inv15l << 6) >> 15;
   const bool active = lane < J && wend > wstart && cb < ce;
   const bool narrow = ((w.item.z >> 8) & 0xff) == 1;
-  // (cb, ce < 4096: the caller sends taller regions through walk_slice)
-  const int pk = cb | (ce << 12) | (phl << 24) | ((ROWFREE && v1l < r1 - 1) ? (int)0x80000000u : 0);
+  // (cb, ce < 4096: the caller sends taller regions through walk_slice; pw <= 64)
+  const int pk = cb | (ce << 12) | ((w.item.z & 0x7f) << 24) | ((ROWFREE && v1l < r1 - 1) ? (int)0x80000000u : 0);
+  // what a run needs of its sphere beyond the record, formed ONCE here with lanes = spheres -- a run broadcasts the
+  // result instead of repeating the arithmetic on a uniform value: r * r, the chunk's height in millimetres, the
+  // row limit of a box that reaches the region's last row
+  const float rrl = w.sph.w * w.sph.w;
+  const float dygl = (float)phl * ay.mul;
+  const float yliml = axis_coord_t<true>(ay, min(v1l, r1 - 1)) + 0.5f * ay.mul;
   unsigned long long m = __ballot(active && narrow);
   const unsigned long long wide = __ballot(active && !narrow);
   while (m) {
     const int j = __builtin_ctzll(m);
     m &= m - 1;
-    const int pkj = rl(pk, j), geom = rl(w.item.x, j), rows = rl(w.item.y, j), cols = rl(w.item.z, j);
-    const float4 s = make_float4(readlane_f(w.sph.x, j), readlane_f(w.sph.y, j), readlane_f(w.sph.z, j),
-                                 readlane_f(w.sph.w, j));
+    const int pkj = rl(pk, j), geom = rl(w.item.x, j), rows = rl(w.item.y, j);
+    const float4 s = make_float4(readlane_f(w.sph.x, j), readlane_f(w.sph.y, j), readlane_f(w.sph.z, j), 0.f);
+    const float rr = readlane_f(rrl, j);
     int c = pkj & 0xfff;
-    const int c_end = (pkj >> 12) & 0xfff, ph = (pkj >> 24) & 0x7f;
+    const int c_end = (pkj >> 12) & 0xfff, pw = (pkj >> 24) & 0x7f;
     const int u0 = geom & 0xffff, v0 = (int)((unsigned)geom >> 16);
-    const int v1 = rows & 0xffff, inv15 = (int)((unsigned)rows >> 16);
-    const int v1c = min(v1, r1 - 1), pw = cols & 0xff;
-    const float rr = s.w * s.w;
+    const int inv15 = (int)((unsigned)rows >> 16), ph = (inv15 << 6) >> 15;
     const int ly = __mul24(lane, inv15) >> 15;
     const int lx = lane - __mul24(ly, pw);
     const bool packed = ly < ph;
@@ -393,12 +397,12 @@ __device__ __forceinline__ void walk_slice_packed(const WaveList &w, int J, int 
     const int dcell = ph * LW;
     const float cav = packed ? ca : -1.f;
     float yg = axis_coord_t<true>(ay, v);
-    const float dyg = (float)ph * ay.mul;
+    const float dyg = readlane_f(dygl, j);
     if (ROWFREE && pkj < 0) {
       for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell)
         body(j, s, cell, cell + dcell, dx, cav, yg, yg + dyg, packed, packed, c + 1 < c_end, std::false_type());
     } else {
-      const float ylim = packed ? axis_coord_t<true>(ay, v1c) + 0.5f * ay.mul : -3.0e38f;
+      const float ylim = packed ? readlane_f(yliml, j) : -3.0e38f;
       for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell) {
         const float ygb = yg + dyg;
         body(j, s, cell, cell + dcell, dx, cav, yg, ygb, yg <= ylim, ygb <= ylim, c + 1 < c_end, std::true_type());
