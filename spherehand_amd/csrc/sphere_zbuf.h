@@ -235,9 +235,9 @@ __device__ __forceinline__ WaveList load_wave_list(const float4 *s_sph, const in
 // RUN TABLE (whole-crop workgroups on power-of-two images; round 3).  What the start of a run on a sphere computes per
 // LANE -- the lane layout lane -> (lx, ly), the column term r*r - dx*dx, the cell, the row -- depends on (sphere,
 // lane) only, and its ~42 VALU instructions hang on a chain of v_readlane -> scalar arithmetic -> branch: measured
-// (tools/exp_walkclk.py) 750 cycles from the top of a run to its first chunk, 47 runs per hand crop, a third of a
-// wave's scan time -- latency, not issue slots.  The waves that idle in front of the first barrier (neither list
-// wave nor background waves) therefore compute it ONCE per sphere into LDS,
+// (clock64 stamps inside walk_slice) 750 cycles from the top of a run to its first chunk, 47 runs per
+// hand crop, a third of a wave's scan time -- latency, not issue slots.  Four waves therefore compute it ONCE per
+// sphere into LDS in front of the first barrier (which ones: see the kernel),
 //     tab[j * 64 + lane] = (bits(ca or -1 outside the packing), ly << 24 | ((v0 + ly) * LW + u)),
 // with the same operations as walk_slice (bit-identical values).  A run then starts from ONE v_readlane (its
 // chunk range, packed per (wave, sphere) by a vector pass at the walk's entry), the lane's table entry and the
@@ -354,8 +354,8 @@ __device__ __forceinline__ void walk_slice_table(const WaveList &w, int J, int l
 // spheres with work iterated over a mask, and a run's broadcasts -- ONE for its chunk range, the item's three words,
 // the record -- issued back to back with no branch between them; the per-lane set-up is walk_slice's, operation for
 // operation.  walk_slice reads a sphere's weight range, branches, reads its end, branches, reads the item, branches:
-// every step waits for a v_readlane to reach the scalar unit and for a branch to refill (tools/exp_walkclk.py: ~750
-// cycles from the top of a run to its first chunk, 47 runs per hand crop).
+// every step waits for a v_readlane to reach the scalar unit and for a branch to refill (~750 cycles from the top
+// of a run to its first chunk, 47 runs per hand crop: DESIGN 4.1).
 template <int kSphereCost, bool ROWFREE, typename Body, typename EndSphere>
 __device__ __forceinline__ void walk_slice_packed(const WaveList &w, int J, int lo, int hi, int lane, const Axis &ax,
                                                   const Axis &ay, int r0, int r1, int LW, Body &&body,
