@@ -506,7 +506,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # SHR_BENCH_FORCE_DIST=1 (tests/test_bench_gpu.py): the multi-rank branch with however many ranks were launched --
+    # one rank under `torchrun --nproc-per-node 1` forms a real RCCL group on the one GPU of a test box
+    force_dist = os.environ.get("SHR_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ["SHR_FORCE_DIST"] = "1"      # engine.DistEnv: DDP-wrap even at world 1 (collective_secondary)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SHR_BENCH_BACKEND", "nccl")
@@ -583,7 +588,7 @@ def main():
         # ceiling of any kernel that has to write a 256-crop batch per launch
         fill_us = kernel_us(lambda _s: depth.fill_(100.0))
         big = sec = None
-        if rank == 0 and world == 1 and not args.no_secondary:
+        if rank == 0 and world == 1 and dist is None and not args.no_secondary:
             # one hipGraph replay of the headline step (forward + backward as one graph launch)
             g2 = torch.cuda.CUDAGraph()
             fwd(sh); bwd(sh); stream.synchronize()
@@ -630,7 +635,7 @@ def main():
                        "crops_per_gpu": BATCH, "image": [S, S], "spheres_per_crop": J,
                        "launch": args.launch, "clock_warmup_ms": CLOCK_WARMUP_MS,
                        "parallelism": "batch-sharded x%d, no data-path collective" % world,
-                       "rccl_ranks": rccl_ranks, "backend": os.environ.get("SHR_BENCH_BACKEND", "nccl") if world > 1 else None},
+                       "rccl_ranks": rccl_ranks, "backend": dist.get_backend() if dist is not None else None},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
@@ -655,7 +660,7 @@ def main():
             out["secondary"] = sec
         if coll is not None:
             out["secondary"] = coll
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and dist is None and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spheres.cpu().numpy(), grad.cpu().numpy())
         print(json.dumps(out), flush=True)
     if dist is not None:

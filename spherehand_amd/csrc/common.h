@@ -158,6 +158,14 @@ __device__ __forceinline__ float wave_min4_transposed(float a0, float a1, float 
 // sqrt(x) < s - u/2  <=>  r <= -t,  with t = s * u formed on the bit pattern (exponent field of s added to itself).
 // Eight VALU instructions where the two-neighbour form (two increments, two residuals, two selects) takes nine;
 // the carry forms of the integer add / subtract take the comparison's result directly.
+// NOT covered by the argument above: s an exact power of two, 2^k.  The ulp BELOW s is u / 2 there, so for
+// x = prev(4^k) (23 inputs in the range) an estimate of 2^k would leave r = -4^k 2^-24 > -t and 2^k would be
+// returned where the correctly rounded root is prev(2^k).  gfx950's v_sqrt_f32 returns prev(2^k) for those inputs
+// (it never rounds the estimate UP across a binade boundary), which is what
+// tests/test_sphere_raster_gpu.py::test_sqrt_rn_exhaustive establishes on the hardware, every fp32 value of the
+// range, in the default GPU selection: the function is exact on gfx950, by measurement at those 23 points and by
+// the argument everywhere else.  Another target needs the test re-run (or t halved for the lower test when s's
+// mantissa is zero).  The s_nop counts below are gfx950's VALU-writes-vcc -> VALU-reads-vcc-as-carry wait states.
 __device__ __forceinline__ float sqrt_rn(float x) {
   const float s = __builtin_amdgcn_sqrtf(x);
   const float r = __builtin_fmaf(-s, s, x);

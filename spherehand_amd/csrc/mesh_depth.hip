@@ -169,7 +169,7 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
                   int S, float clamp_max, float *__restrict__ depth) {
   __shared__ uint32_t s_z[SL * TO][SL * TO + 1];   // [SL*dy + sy][SL*dx + sx], +1: bank spread
   __shared__ int s_queue[kMeshQueue];
-  __shared__ int s_wave_cnt[16], s_next_item;
+  __shared__ int s_wave_cnt[16], s_wave_rows[16], s_next_item;
   __shared__ FaceRow s_rows[kMeshRows];
   const int b = blockIdx.y;
   const int tiles = (S + TO - 1) / TO;
@@ -250,36 +250,35 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
       n += nk[k];
       nrow += nk[k] > 0;
     }
-    // (work items and surviving faces share one scan: the face count rides in the upper half)
-    n |= nrow << 20;
-    int incl = n;   // inclusive scan over the workgroup: DPP inside rows of 16, SGPR row totals, LDS wave totals
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
-    {
+    // inclusive scans over the workgroup (work items, surviving faces): DPP inside rows of 16, SGPR row totals, LDS
+    // wave totals.  Two separate counters: up to 4096 faces x 128 columns of items and up to 4096 surviving faces per
+    // round do not fit one packed 32-bit word (a dense front-facing mesh has > 2048 survivors in one tile).
+    auto wave_scan = [&](int v) {
+      int incl = v;
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
       const int r0s = __builtin_amdgcn_readlane(incl, 15), r1s = __builtin_amdgcn_readlane(incl, 31);
       const int r2s = __builtin_amdgcn_readlane(incl, 47);
       const int row = lane >> 4;
-      incl += (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
-    }
+      return incl + (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
+    };
+    const int incl = wave_scan(n), incl_rows = wave_scan(nrow);
     __syncthreads();   // the previous round's queue is consumed, s_wave_cnt is free
-    if (lane == 63) s_wave_cnt[wave] = incl;
+    if (lane == 63) { s_wave_cnt[wave] = incl; s_wave_rows[wave] = incl_rows; }
     __syncthreads();
     int off = incl - n, total = 0;
+    int row = incl_rows - nrow, total_rows = 0;   // this thread's first row in the face table
     for (int w = 0; w < 16; w++) {
-      const int c = s_wave_cnt[w];
-      if (w < wave) off += c;
+      const int c = s_wave_cnt[w], cr = s_wave_rows[w];
+      if (w < wave) { off += c; row += cr; }
       total += c;
+      total_rows += cr;
     }
-    int row = off >> 20;                       // this thread's first row in the face table
-    off &= 0xfffff; total &= 0xfffff; n &= 0xfffff;
     // ---- the surviving faces' rows: lanes = SURVIVORS (a quarter of the faces: computed where they were found, every
     // wave would run the divisions for each of its four face slots at a quarter of its lanes) -------------------
     int rowk[kMeshFaces];
-    const int nrows = min(kMeshRows, (int)((unsigned)s_wave_cnt[15] >> 20) + 0 * row);
-    int total_rows = 0;
-    for (int w = 0; w < 16; w++) total_rows += (int)((unsigned)s_wave_cnt[w] >> 20);
 #pragma unroll
     for (int k = 0; k < kMeshFaces; k++) {
       rowk[k] = -1;
@@ -291,7 +290,6 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
       row++;
     }
     __syncthreads();
-    (void)nrows;
     for (int r = tid; r < min(kMeshRows, total_rows); r += blockDim.x)
       s_rows[r] = face_row(face_setup_sorted(verts, faces, s_rows[r].pad[0], src));
     for (int w0 = 0; w0 < total; w0 += kMeshQueue) {

@@ -101,10 +101,16 @@ class DistEnv:
         if self.device.type == 'cuda':
             torch.cuda.set_device(self.device)
         self.owns_group = False
-        if self.world > 1 and not dist.is_initialized():
+        # SHR_FORCE_DIST=1: a single rank still forms a process group and wraps the network in DDP -- the RCCL code
+        # path of a multi-GPU job exercised on the one GPU a test box has (tests/test_ddp_gpu.py)
+        self.distributed = self.world > 1 or os.environ.get('SHR_FORCE_DIST') == '1'
+        if self.distributed and not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
-            dist.init_process_group('nccl' if self.device.type == 'cuda' else 'gloo')
+            if self.device.type == 'cuda':
+                dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.device)
+            else:
+                dist.init_process_group('gloo', rank=self.rank, world_size=self.world)
             self.owns_group = True
 
     @property
@@ -112,7 +118,7 @@ class DistEnv:
         return self.rank == 0
 
     def wrap(self, module):
-        if self.world == 1:
+        if not self.distributed:
             return module
         kw = dict(bucket_cap_mb=32, gradient_as_bucket_view=True)   # one bucket: 9.24 MB of fp32 grads
         if self.device.type == 'cuda':
@@ -121,7 +127,7 @@ class DistEnv:
 
     def mean_scalars(self, values):
         """All-reduce a dict of python floats (log intervals only)."""
-        if self.world == 1 or not values:
+        if not self.distributed or not values:
             return values
         keys = sorted(values)
         t = torch.tensor([values[k] for k in keys], dtype=torch.float64, device=self.device)
@@ -202,7 +208,7 @@ class Engine:
         else:
             name = [getattr(opts, 'tag', '') + ''.join(random.choice(string.ascii_letters + string.digits)
                                                        for _ in range(6))]
-            if self.env.world > 1:
+            if self.env.distributed:
                 dist.broadcast_object_list(name, src=0)
             self.model_name = name[0]
             self.model_path = os.path.join(self.model_dir, self.model_name)

@@ -112,10 +112,20 @@ class DepthResample(nn.Module):
             # one torch.rand + one launch (drop-out and the FIXED 3x3 / 5x5 Gaussian of the reference fused: the kernel
             # carries those tables -- a changed self.gaussian_filter.weight takes the torch path below)
             w = self.gaussian_filter.weight
-            if w.requires_grad or getattr(self, '_fixed_kernel_checked', None) is not w._version:
-                k = torch.tensor(self._K5 if w.shape[-1] == 5 else self._K3, dtype=w.dtype, device=w.device)
-                self._fixed = bool(torch.equal(w.reshape(-1), k / k.sum()))
-                self._fixed_kernel_checked = w._version
+            # a trainable filter always takes the torch path; a frozen one is compared with the module's table once per
+            # weight version (the table is cached on the weight's device: no host-to-device copy and no
+            # synchronising torch.equal per forward, both of which would also break a hipGraph capture).  An
+            # assignment through `weight.data = ...` does not bump the version counter: callers that swap the kernel
+            # that way must reset `_fixed_kernel_checked` (the reference never does, network/util_modules.py:10-43).
+            if w.requires_grad:
+                self._fixed = False
+            elif getattr(self, '_fixed_kernel_checked', None) != (w._version, w.device):
+                k = getattr(self, '_fixed_table', None)
+                if k is None or k.device != w.device or k.numel() != w.numel():
+                    k = torch.tensor(self._K5 if w.shape[-1] == 5 else self._K3, dtype=w.dtype, device=w.device)
+                    k = self._fixed_table = k / k.sum()
+                self._fixed = bool(torch.equal(w.reshape(-1), k))
+                self._fixed_kernel_checked = (w._version, w.device)
             if not self._fixed:
                 dm = torch.where(torch.rand_like(dm) > self.sample_ratio, torch.ones_like(dm), dm)
                 return self.gaussian_filter(dm)

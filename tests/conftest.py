@@ -36,15 +36,22 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
+# stderr of a launch that failed before any worker ran test code: the rendezvous, not the code under test
+_RENDEZVOUS_ERRORS = ("EADDRINUSE", "Address already in use", "address already in use", "RendezvousConnectionError",
+                      "RendezvousTimeoutError", "DistNetworkError", "DistStoreError", "TCPStore", "store timed out",
+                      "failed to connect", "Connection refused", "Connection reset")
+
+
 def run_torchrun(world, script_args, env=None, timeout=600, attempts=3, capture=False):
     """`python -m torch.distributed.run --nproc-per-node world <script_args>` on 127.0.0.1 with a fresh port.  A launch
-    that exits non-zero is retried (a fresh port each time): the rendezvous of back-to-back launches on a box that has
-    just come up fails now and then (the store's port taken between the probe and the bind), which says nothing about
-    the code under test -- an assertion inside a worker fails every attempt and still fails the test.  Returns stdout
-    (capture=True) or None."""
+    is retried (fresh port) ONLY when its stderr names a rendezvous / port-bind error and no worker assertion: the
+    store's port can be taken between the probe and the bind on a box that has just come up.  Anything else -- a worker
+    assertion, a mismatch, a rank timeout -- fails the test at once.  Retries are reported as a pytest warning.
+    Returns stdout (capture=True) or None."""
     import socket
     import subprocess
     import sys
+    import warnings
     last = None
     for attempt in range(attempts):
         sock = socket.socket()
@@ -55,10 +62,15 @@ def run_torchrun(world, script_args, env=None, timeout=600, attempts=3, capture=
                "--master-addr", "127.0.0.1", "--master-port", str(port)] + list(script_args)
         r = subprocess.run(cmd, env=env, timeout=timeout, cwd=ROOT, capture_output=True, text=True)
         if r.returncode == 0:
+            if attempt:
+                warnings.warn("torchrun needed %d attempts (rendezvous errors): %s" % (attempt + 1, " ".join(script_args)[-120:]))
             return r.stdout if capture else None
         last = r
-        msg = "torchrun attempt %d failed (rc %d): %s\n%s" % (attempt + 1, r.returncode, " ".join(script_args)[-200:],
-                                                            (r.stderr or "")[-3000:])
+        err = r.stderr or ""
+        rendezvous = any(k in err for k in _RENDEZVOUS_ERRORS) and "AssertionError" not in err
+        msg = "torchrun attempt %d failed (rc %d, %s): %s\n%s" % (attempt + 1, r.returncode,
+                                                                  "rendezvous: retrying" if rendezvous else "not retried",
+                                                                  " ".join(script_args)[-200:], err[-3000:])
         print(msg)
         try:      # kept where the GPU box's scratch output is collected, if there is such a place
             d = os.path.join(ROOT, "gpurun_out")
@@ -67,4 +79,6 @@ def run_torchrun(world, script_args, env=None, timeout=600, attempts=3, capture=
                     f.write(msg + "\n----\n")
         except OSError:
             pass
-    raise AssertionError("torchrun failed %d times; last stderr:\n%s" % (attempts, (last.stderr or "")[-6000:]))
+        if not rendezvous:
+            break
+    raise AssertionError("torchrun failed (attempt %d of %d); last stderr:\n%s" % (attempt + 1, attempts, (last.stderr or "")[-6000:]))

@@ -50,7 +50,10 @@ def run(out_path, model_dir):
     from spherehand_amd.engine import Engine
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    if world > 1:
+    # SHR_DDP_BACKEND=nccl + SHR_FORCE_DIST=1: ONE rank that still forms an RCCL process group and wraps the network in
+    # DDP (Engine's DistEnv does both) -- the multi-GPU job's code path on the one GPU a test box has
+    backend = os.environ.get('SHR_DDP_BACKEND', 'gloo')
+    if world > 1 and backend == 'gloo':
         dist.init_process_group('gloo')
     mesh = hand_model.load_mesh()
     torch.manual_seed(7)                                   # identical initial weights on every rank
@@ -80,8 +83,9 @@ def run(out_path, model_dir):
     metric = eng.env.mean_scalars({k: float(v) for k, v in metrics.items()})
     if eng.env.is_main:
         torch.save({'grads': grads, 'params': params, 'terms': means, 'metric': metric, 'world': eng.env.world,
-                    'ddp': type(eng.ddp_network).__name__}, out_path)
-    if world > 1:
+                    'ddp': type(eng.ddp_network).__name__,
+                    'backend': dist.get_backend() if dist.is_initialized() else None}, out_path)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -8,7 +8,9 @@ Reference entry points (file:line in /root/reference):
   network/hourglass.py:175                     create_hourglass_network
   network/util_modules.py:164-201, :204-240    RecoverXYZCoordinateFromHeatmap, HeatmapVariance
   mesh/render.py:145-206, :210-279             CollisionLoss, BoneLengthLoss, HeatmapRender, Hand3DHeatmapRender
-  network/create_network_and_criterion.py:147-263  MultiTaskLoss (prior / temporal off)
+  network/create_network_and_criterion.py:147-263  MultiTaskLoss (prior / temporal off; then, keys mtp_*, with
+                                               --temporal and --prior ON over two consecutive batches: the
+                                               TemporalSmoothnessLoss of network/util_modules.py:349-381 is stateful)
   network/utils_metric.py:7-17                 average_joint_error
 Environment accommodation: mesh/bone_length.py calls .cuda() at import time
 (:33); nn.Module.cuda is made a no-op while it is imported (there is no GPU here;
@@ -138,6 +140,39 @@ def main():
     est = torch.randn(5, 3, 41, 3) * 30
     out["metric_gt"], out["metric_est"] = gt.numpy(), est.numpy()
     out["metric"] = np.asarray(um.average_joint_error(gt, est), np.float64)
+    # ---- G7b: --temporal and --prior ON (create_network_and_criterion.py:157-158, :238-246) --------------
+    # Two consecutive batches through ONE criterion: TemporalSmoothnessLoss keeps the previous batch's last
+    # sample (util_modules.py:367-381; first call: B - 1 pairs, later calls: B pairs led by the remembered one).
+    # PoseVae's reparameterisation draw (pose_vae.py:49) is recorded and replayed.  Placed after every other draw
+    # of this script: the arrays above do not change when this block is added.
+    # (the shipped pose_vae.pth holds CUDA storages and pose_vae.py:20 loads it without map_location: no GPU here)
+    nn.Module.cuda = lambda self, *a, **k: self
+    orig_load = torch.load
+    torch.load = lambda f, *a, **k: orig_load(f, *a, **dict(k, map_location="cpu"))
+    try:
+        crit_tp = MultiTaskLoss(True, True, True, True, True, True, True, C, image_size=64)
+    finally:
+        nn.Module.cuda = orig_cuda
+        torch.load = orig_load
+    eps = torch.randn(B * V, 32)
+    out["mtp_eps"] = eps.numpy()
+    orig_randn_like = torch.randn_like
+    torch.randn_like = lambda t_, *a, **k: eps.clone() if tuple(t_.shape) == tuple(eps.shape) else orig_randn_like(t_, *a, **k)
+    try:
+        base = result["real_xyz"][0]
+        for call, xyz in enumerate((base, base * 1.02 + torch.tensor([1.5, -2.0, 0.7]))):
+            xg = xyz.clone().requires_grad_(True)
+            res = dict(result, real_xyz=[xg])
+            real_target["is_mv"] = True
+            terms, _ = crit_tp(res, synt_target=synt_target, real_target=real_target)
+            (terms["temporal_smooth"] + terms["pose_prior"]).backward()
+            out["mtp_call%d_real_xyz" % call] = xyz.numpy()
+            out["mtp_call%d_grad_temporal_plus_prior" % call] = xg.grad.numpy()
+            for k, v in terms.items():
+                out["mtp_call%d_%s" % (call, k)] = np.asarray(float(v), np.float64)
+            print("G7b call", call, {k: round(float(v), 5) for k, v in terms.items()})
+    finally:
+        torch.randn_like = orig_randn_like
     np.savez_compressed(os.path.join(HERE, "g7_network.npz"), **out)
     print("done", out["metric"])
 

@@ -36,6 +36,25 @@ def test_bench_two_ranks_one_gpu():
     assert 0 < d["roofline"]["frac"] < 1
 
 
+def test_bench_one_rank_over_rccl():
+    """bench.py's `world > 1` branch on RCCL itself: one rank under torchrun with SHR_BENCH_FORCE_DIST=1 --
+    init_process_group("nccl", device_id=...), the rank-count all-reduce, the closing barrier of the timed region, the
+    gradient-bucket all-reduce and the DDP-wrapped training step all run through RCCL on the MI355X."""
+    env = dict(os.environ, SHR_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", SHR_BENCH_DDP_STEPS="3")
+    from conftest import run_torchrun
+    out = run_torchrun(1, [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "10"], env=env,
+                       timeout=600, capture=True)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1 and d["n_gpus"] == 1
+    sec = d["secondary"]
+    assert "error" not in sec, sec
+    assert sec["grad_bucket_bytes"] == 2308946 * 4 and sec["grad_bucket_allreduce_us"] > 0
+    assert sec["ddp_training_step_25x3_real_48_synt_64x64_ms"] > 0
+    assert d["value"] > 1e6 and 0 < d["roofline"]["frac"] < 1
+
+
 def test_bench_rejects_a_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)

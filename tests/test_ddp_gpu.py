@@ -13,9 +13,9 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-def launch(world, out, model_dir):
+def launch(world, out, model_dir, **extra):
     from conftest import run_torchrun
-    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
     run_torchrun(world, [os.path.join(ROOT, "tests", "ddp_gpu_worker.py"), out, model_dir], env=env, timeout=900)
     return torch.load(out)
 
@@ -37,3 +37,47 @@ def test_two_rank_render_fit_step_equals_single_process(tmp_path):
         assert (one["grads"][k] - two["grads"][k]).abs().max().item() <= 1e-5 * gmax + 1e-8, k
     for k in one["params"]:          # after one Adam step (lr 1e-3: a step is <= 1e-3 per weight)
         assert (one["params"][k] - two["params"][k]).abs().max().item() <= 2e-5, k
+
+
+def test_one_rank_rccl_ddp_step_equals_the_plain_step(tmp_path):
+    """RCCL executed on hardware: ONE rank forms an `nccl` process group on the MI355X (Engine's DistEnv:
+    init_process_group("nccl", device_id=...)), the network is wrapped in DistributedDataParallel with the flat
+    9.24-MB bucket, the name broadcast and the scalar all-reduce run, and one Engine.step's bucket all-reduce goes
+    through RCCL (/root/reference network/engine.py:366-376 under DDP).  A one-rank all-reduce is the identity:
+    the step equals the unwrapped single-process step."""
+    plain = launch(1, str(tmp_path / "p.pt"), str(tmp_path / "mp"))
+    rccl = launch(1, str(tmp_path / "r.pt"), str(tmp_path / "mr"), SHR_FORCE_DIST="1", SHR_DDP_BACKEND="nccl")
+    assert plain["ddp"] != "DistributedDataParallel" and plain["backend"] is None
+    assert rccl["ddp"] == "DistributedDataParallel" and rccl["backend"] == "nccl" and rccl["world"] == 1
+    for k in plain["terms"]:
+        assert abs(plain["terms"][k] - rccl["terms"][k]) <= 1e-6 * max(1.0, abs(plain["terms"][k])), k
+    gmax = max(v.abs().max().item() for v in plain["grads"].values())
+    for k in plain["grads"]:
+        assert (plain["grads"][k] - rccl["grads"][k]).abs().max().item() <= 1e-6 * gmax + 1e-9, k
+    for k in plain["params"]:
+        assert (plain["params"][k] - rccl["params"][k]).abs().max().item() <= 2e-6, k
+
+
+def test_one_rank_rccl_bucket_allreduce():
+    """The bare collective of the design on RCCL: init_process_group("nccl", device_id=...) with one rank, all-reduce
+    of the flat 2 308 946-float gradient bucket, a barrier -- the calls bench.py --gpus N and
+    engine.DistEnv make."""
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(dev)\n"
+        "dist.init_process_group('nccl', device_id=dev)\n"
+        "assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1\n"
+        "b = torch.randn(2308946, device=dev); ref = b.clone()\n"
+        "dist.all_reduce(b); dist.barrier(); torch.cuda.synchronize()\n"
+        "assert torch.equal(b, ref)\n"
+        "t = torch.ones(1, device=dev); dist.all_reduce(t); assert int(t.item()) == 1\n"
+        "dist.destroy_process_group(); print('RCCL_OK')\n")
+    import tempfile
+    from conftest import run_torchrun
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code)
+    try:
+        out = run_torchrun(1, [f.name], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=600, capture=True)
+    finally:
+        os.unlink(f.name)
+    assert "RCCL_OK" in out

@@ -46,6 +46,38 @@ def test_multitask_loss_terms_vs_reference(is_mv):
     assert len(proj) == 1 and proj[0].shape == (4, 3, 3, 64, 64)
 
 
+def test_multitask_loss_temporal_and_prior_on_vs_reference():
+    """Every switch ON (--temporal, --prior included) on the device, two consecutive batches: all ten terms against the
+    imported reference (g7 keys mtp_*; network/create_network_and_criterion.py:183-263, util_modules.py:367-381)."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.criterion import MultiTaskLoss
+    from spherehand_amd.pose_vae import default_pose_vae
+    g, g4 = golden("g7_network.npz"), golden("g4_mutual_projection.npz")
+    crit = MultiTaskLoss(True, True, True, True, default_pose_vae(), True, True, hand_model.load_mesh(), image_size=64).cuda()
+    result = {k: [dev(g["mt_res_" + k])] for k in
+              ("real_uv_hms", "synt_uv_hms", "synt_xyz", "batch_synt_fea", "batch_real_fea")}
+    synt_target = {k: dev(g["mt_synt_" + k]) for k in ("uv_hms", "d_hms", "xyz_pts")}
+    real_target = {"real_dms": dev(g4["real_dms"]), "camera_poses": dev(g4["cam"]),
+                   "inv_camera_poses": dev(g4["inv_cam"]), "is_mv": True}
+    eps = dev(g["mtp_eps"])
+    orig = torch.randn_like
+    torch.randn_like = lambda a, *aa, **k: eps.clone() if tuple(a.shape) == tuple(eps.shape) else orig(a, *aa, **k)
+    try:
+        for call in (0, 1):
+            xg = dev(g["mtp_call%d_real_xyz" % call]).requires_grad_(True)
+            terms, proj = crit(dict(result, real_xyz=[xg]), synt_target=synt_target, real_target=real_target)
+            assert set(terms) == {"synt_uv", "synt_d", "mv_projection", "mv_consistency", "uv_hm_mean", "pose_prior",
+                                  "temporal_smooth", "collision", "bone_length", "domain_loss"}
+            for k, v in terms.items():
+                ref = float(g["mtp_call%d_%s" % (call, k)])
+                assert abs(float(v) - ref) <= 1e-4 * max(1.0, abs(ref)), (call, k, float(v), ref)
+            (terms["temporal_smooth"] + terms["pose_prior"]).backward()
+            gref = g["mtp_call%d_grad_temporal_plus_prior" % call]
+            assert np.abs(xg.grad.cpu().numpy() - gref).max() <= 1e-4 * np.abs(gref).max() + 1e-6, call
+    finally:
+        torch.randn_like = orig
+
+
 def test_hand_synthesizer():
     from spherehand_amd import hand_model
     from spherehand_amd.joint_angle import sample_poses

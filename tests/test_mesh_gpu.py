@@ -240,3 +240,38 @@ def test_fused_depth_render_large_and_odd_faces(S):
     assert (fused - chain).abs().max().item() <= 1e-5 * max(1.0, chain.abs().max().item())
     if S in (64, 128):
         assert torch.equal(fused, chain)
+
+
+@pytest.mark.parametrize("src,S", [(128, 128), (64, 64), (640, 128)])
+def test_fused_depth_render_dense_front_facing_grid(src, S):
+    """A height field of 64 x 64 quads (8192 triangles, all front-facing) over the whole image: more than 2048 of a
+    round's 4096 faces survive the culls in ONE tile (src == S: every source pixel is sampled), then a second round.
+    The round-3 kernel packed the survivor count into the upper 12 bits of a signed work-item scan."""
+    from spherehand_amd import ops
+    n = 64
+    rs = np.random.RandomState(5)
+    gx, gy = np.meshgrid(np.linspace(1.0, src - 2.0, n + 1), np.linspace(1.0, src - 2.0, n + 1))
+    gx = gx + rs.uniform(-0.2, 0.2, gx.shape)
+    gy = gy + rs.uniform(-0.2, 0.2, gy.shape)
+    v = np.zeros((2, (n + 1) * (n + 1), 4), np.float32)
+    v[..., 0] = gx.reshape(-1); v[..., 1] = gy.reshape(-1); v[..., 3] = 1
+    v[0, :, 2] = (30 + 20 * np.sin(gx / 9.0) * np.cos(gy / 7.0)).reshape(-1)
+    v[1, :, 2] = rs.uniform(5, 90, (n + 1) * (n + 1))
+    idx = lambda r, c: r * (n + 1) + c
+    faces = []
+    for r in range(n):
+        for c in range(n):
+            a, b, d, e = idx(r, c), idx(r, c + 1), idx(r + 1, c), idx(r + 1, c + 1)
+            faces += [(a, d, b), (b, d, e)]
+    faces = np.asarray(faces, np.int32)
+    vd, fd = dev(v), dev(faces)
+    raw = ops.tri_raster_indexed_fwd(src, src, vd, fd)
+    if (raw < 1000).float().mean().item() < 0.5:          # the other winding is the front-facing one
+        faces = faces[:, [0, 2, 1]].copy()
+        fd = dev(faces)
+        raw = ops.tri_raster_indexed_fwd(src, src, vd, fd)
+    assert (raw < 1000).float().mean().item() > 0.9
+    fused = ops.mesh_depth_fwd(vd, fd, S, src, 100.0)
+    chain = torch.nn.functional.interpolate(torch.clamp(raw, max=100.0).unsqueeze(1), size=(S, S), mode="bilinear",
+                                            align_corners=False).squeeze(1)
+    assert torch.equal(fused, chain)

@@ -104,6 +104,45 @@ def test_multitask_loss_wiring_cpu_terms():
     assert "mv_projection" not in terms and "mv_consistency" not in terms
 
 
+def _tp_inputs(g, conv):
+    result = {k: [conv(g["mt_res_" + k])] for k in
+              ("real_uv_hms", "synt_uv_hms", "synt_xyz", "batch_synt_fea", "batch_real_fea")}
+    synt_target = {k: conv(g["mt_synt_" + k]) for k in ("uv_hms", "d_hms", "xyz_pts")}
+    return result, synt_target
+
+
+def test_multitask_loss_temporal_and_prior_wiring_two_batches():
+    """--temporal and --prior ON, two consecutive batches through one criterion (g7 keys mtp_*: the imported
+    reference's MultiTaskLoss(True x 7), network/create_network_and_criterion.py:238-246; TemporalSmoothnessLoss keeps
+    the previous batch's last sample, network/util_modules.py:367-381; the VAE's draw is the recorded one).  CPU: the
+    terms that need no HIP kernel, and the gradient of temporal + prior w.r.t. the joints."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.criterion import MultiTaskLoss
+    from spherehand_amd.pose_vae import default_pose_vae
+    g = golden("g7_network.npz")
+    crit = MultiTaskLoss(True, False, False, True, default_pose_vae(), True, True, hand_model.load_mesh(), image_size=64)
+    result, synt_target = _tp_inputs(g, t)
+    eps = t(g["mtp_eps"])
+    orig = torch.randn_like
+    torch.randn_like = lambda a, *aa, **k: eps.clone() if tuple(a.shape) == tuple(eps.shape) else orig(a, *aa, **k)
+    try:
+        for call in (0, 1):
+            xg = t(g["mtp_call%d_real_xyz" % call]).requires_grad_(True)
+            terms, _ = crit(dict(result, real_xyz=[xg]), synt_target=synt_target,
+                            real_target={"real_dms": None, "camera_poses": None, "inv_camera_poses": None, "is_mv": True})
+            (terms["temporal_smooth"] + terms["pose_prior"]).backward()
+            for k in ("synt_uv", "synt_d", "uv_hm_mean", "pose_prior", "temporal_smooth", "collision", "bone_length",
+                      "domain_loss"):
+                ref = float(g["mtp_call%d_%s" % (call, k)])
+                assert abs(float(terms[k]) - ref) <= 1e-5 * max(1.0, abs(ref)), (call, k, float(terms[k]), ref)
+            gref = g["mtp_call%d_grad_temporal_plus_prior" % call]
+            assert np.abs(xg.grad.numpy() - gref).max() <= 1e-5 * np.abs(gref).max() + 1e-7, call
+    finally:
+        torch.randn_like = orig
+    # the state the second call used: the first batch's last sample
+    assert np.array_equal(crit.temporal_smooth_loss.previous_skel.numpy(), g["mtp_call1_real_xyz"][-1])
+
+
 def test_network_wrapper_shapes_and_scale_division():
     from spherehand_amd.criterion import HeatmapEstimationNetwork
     net = HeatmapEstimationNetwork(16, 0.01, 41, 1).eval()
