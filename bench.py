@@ -156,12 +156,13 @@ def rocprof_avg_us():
 
 
 def timed_steps(step, steps, warmup, dist, device):
-    """The driver's timing contract: `warmup` untimed steps, then exactly `steps` steps
-    bracketed by a barrier + device synchronize on both sides; returns the MAX over
-    ranks of the elapsed seconds (every rank gets the same number).  A rank's clock stops
-    when ITS device has finished its steps (synchronize), the closing barrier follows and the
-    maximum over the ranks is the job's time: the barrier's own latency (a collective of
-    tens of microseconds against a 300-us region of 20 steps) is not work of the job."""
+    """`warmup` untimed steps, then exactly `steps` steps; returns the MAX over ranks of the elapsed
+    seconds (every rank gets the same number).  The region opens with barrier + device synchronize
+    (the driver's contract).  It CLOSES with this rank's device synchronize, the clock stops, and only then
+    come the closing barrier and the max-over-ranks all-reduce: a deliberate reading of "barrier +
+    synchronize on both sides" -- the job's time is the slowest rank's time to finish its K steps, and
+    the closing barrier's own latency (a collective of tens of microseconds against a 300-us region of
+    20 steps) is not work of the job.  With one rank the two readings coincide."""
     def sync():
         if device.type == "cuda":
             torch.cuda.synchronize(device)
@@ -245,7 +246,8 @@ def large_batch(lib, _lib, dev, stream):
                                                 "fwd"), stream, reps, 5, 3, warm_ms=40.0)
         b = mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_bwd(p[0], p[3], p[2], n, J, S, S, p[4], s), "bwd"),
                            stream, reps, 5, 3, warm_ms=40.0)
-        bf, bb = int(n * (4 * S * S + written * S * S + 16 * J)), n * (4 * S * S + S * S + 32 * J)
+        # one owner-byte convention for both directions: the owner bytes of the touched rows (what the pair moves)
+        bf, bb = int(n * (4 * S * S + written * S * S + 16 * J)), int(n * (4 * S * S + written * S * S + 32 * J))
         out[str(n)] = {"fwd_us": round(f, 2), "bwd_us": round(b, 2), "fwd_us_per_256": round(f * 256 / n, 3),
                        "bwd_us_per_256": round(b * 256 / n, 3), "fwd_frac": roof(bf, f)["frac"],
                        "bwd_frac": roof(bb, b)["frac"], "crops_per_s_fwd_bwd": round(n / ((f + b) * 1e-6), 1)}
@@ -587,6 +589,19 @@ def main():
         # forward's 21.1 MB, no arithmetic, same stream) takes at this batch size -- the practical
         # ceiling of any kernel that has to write a 256-crop batch per launch
         fill_us = kernel_us(lambda _s: depth.fill_(100.0))
+        # the launch floor of the forward's shape (one 1024-thread workgroup with the whole CU's LDS per crop) over
+        # the forward's bytes: records in, depth + the touched rows' owner bytes out, nothing else (capi.hip)
+        rows_t = int(round(owner_written * S))
+        floor_lds = 160 * 1024
+        r0f = (S - rows_t) // 2
+
+        def floor(s):
+            _lib.check(lib.shr_selftest_launch_floor(sp, BATCH, J, S, S, r0f, r0f + rows_t, dp, ap, floor_lds, s), "floor")
+        floor_us = kernel_us(floor)
+        # the same K steps with the PUBLIC forward (complete owner map), timed like the headline
+        def step_full():
+            fwd_full(sh); bwd(sh)
+        elapsed_full = timed_steps(step_full, args.steps, args.warmup, dist, dev)
         big = sec = None
         if rank == 0 and world == 1 and dist is None and not args.no_secondary:
             # one hipGraph replay of the headline step (forward + backward as one graph launch)
@@ -610,16 +625,39 @@ def main():
         #   spheres, writes grad_spheres
         #   (forward with SHR_RASTER_OWNER_TOUCHED_ROWS: the owner bytes of the touched rows only -- the measured
         #   fraction; the backward is priced at the whole images although it reads the touched rows only)
+        # Three byte conventions, each applied to BOTH directions and named in the line:
+        #   touched   depth / grad image + the owner bytes of the touched rows (what this pair has to move) + records
+        #   full      ... + the complete owner map (the public argmin contract; SURVEY 8d "u8 argmin saved")
+        #   survey8d  SURVEY 8d's primary figure: no owner map at all (66 192 + 66 848 B per crop)
         bytes_fwd = int(BATCH * (4 * S * S + owner_written * S * S + 16 * J))
+        bytes_bwd = int(BATCH * (4 * S * S + owner_written * S * S + 16 * J + 16 * J))
         bytes_fwd_full = BATCH * (4 * S * S + S * S + 16 * J)
-        bytes_bwd = BATCH * (4 * S * S + S * S + 16 * J + 16 * J)
+        bytes_bwd_full = BATCH * (4 * S * S + S * S + 16 * J + 16 * J)
+        bytes_fwd_8d = BATCH * (4 * S * S + 16 * J)
+        bytes_bwd_8d = BATCH * (4 * S * S + 16 * J + 16 * J)
         dom, dom_us, dom_bytes = ("sphere_zbuf_bwd_kernel", bwd_us, bytes_bwd) if bwd_us >= fwd_us else \
             ("sphere_zbuf_fwd_kernel", fwd_us, bytes_fwd)
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
         traffic, traffic_src = pmc_traffic(dom)
+        rp = rocprof_avg_us()
+        frac_rocprof = None
+        if rp is not None and "launched_from_c" in rp:      # the committed rocprofv3 summary of the C-loop launches
+            key = "bwd" if dom.endswith("bwd_kernel") else "fwd"
+            frac_rocprof = {"frac": roof(dom_bytes, rp["launched_from_c"][key])["frac"],
+                            "frac_fwd": roof(bytes_fwd, rp["launched_from_c"]["fwd"])["frac"],
+                            "frac_bwd": roof(bytes_bwd, rp["launched_from_c"]["bwd"])["frac"],
+                            "avg_us": {"fwd": rp["launched_from_c"]["fwd"], "bwd": rp["launched_from_c"]["bwd"]},
+                            "source": rp["launched_from_c"]["source"],
+                            "is": "same algorithmic bytes / AverageNs of the committed rocprofv3 --kernel-trace --stats "
+                                  "run of the C-loop launches (tools/collect_profiles_r04.sh); a different process "
+                                  "than this line's live HIP-event means"}
         out = {
             "metric": "depth crops/s (raster fwd+bwd, 128x128, batch 256)",
             "value": round(world * BATCH * args.steps / elapsed, 1),
+            "value_full_owner_map": round(world * BATCH * args.steps / elapsed_full, 1),
+            "value_is": "forward with SHR_RASTER_OWNER_TOUCHED_ROWS + backward: the pair ops.SphereDepthRaster issues "
+                        "(the owner map never leaves it); value_full_owner_map = the same steps with the public "
+                        "forward that completes the uint8 owner map (round 2's definition of the step)",
             "unit": "crops/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -647,11 +685,34 @@ def main():
                                          "serialises the dispatches and, from Python, the host then costs more per "
                                          "launch than the kernel takes; launched_from_c = the same launches from a C "
                                          "loop under the tracer: profiles/README.md)",
-                         "rocprof_avg_us": rocprof_avg_us(),
+                         "rocprof_avg_us": rp,
+                         "frac_rocprof": frac_rocprof,
                          "owner_map": "touched rows only (SHR_RASTER_OWNER_TOUCHED_ROWS): %.1f %% of the owner bytes"
                                       % (100 * owner_written),
                          "full_owner_map": dict(fwd_us=round(fwd_full_us, 3), **roof(bytes_fwd_full, fwd_full_us)),
                          "frac_fwd": roof(bytes_fwd, fwd_us)["frac"], "frac_bwd": roof(bytes_bwd, bwd_us)["frac"],
+                         "byte_conventions": {
+                             "touched_rows": {"fwd_bytes": bytes_fwd, "bwd_bytes": bytes_bwd,
+                                              "frac_fwd": roof(bytes_fwd, fwd_us)["frac"],
+                                              "frac_bwd": roof(bytes_bwd, bwd_us)["frac"],
+                                              "is": "depth / grad image + owner bytes of the touched rows + records; "
+                                                    "`frac`, `frac_fwd`, `frac_bwd` use it"},
+                             "full_owner_map": {"fwd_bytes": bytes_fwd_full, "bwd_bytes": bytes_bwd_full,
+                                                "frac_fwd": roof(bytes_fwd_full, fwd_full_us)["frac"],
+                                                "frac_bwd": roof(bytes_bwd_full, bwd_us)["frac"],
+                                                "is": "SURVEY 8d 'u8 argmin saved' (165 808 B per crop fwd + bwd); the "
+                                                      "forward timed is the public one that writes the whole map"},
+                             "survey8d_no_owner_map": {"fwd_bytes": bytes_fwd_8d, "bwd_bytes": bytes_bwd_8d,
+                                                       "frac_fwd": roof(bytes_fwd_8d, fwd_us)["frac"],
+                                                       "frac_bwd": roof(bytes_bwd_8d, bwd_us)["frac"],
+                                                       "is": "SURVEY 8d's primary 133 040 B per crop (argmin recomputed): "
+                                                             "the owner bytes these kernels do move are not counted"}},
+                         "launch_floor": {"us": round(floor_us, 3), "fwd_over_floor": round(fwd_us / floor_us, 3),
+                                          "bytes": bytes_fwd,
+                                          "shape": "%d workgroups x 1024 threads, %d B of LDS each (one per CU), 16-byte "
+                                                   "sc1 stores of depth + the owner bytes of %d rows, the records read: "
+                                                   "no arithmetic (shr_selftest_launch_floor)" % (BATCH, floor_lds, rows_t),
+                                          **{k: v for k, v in roof(bytes_fwd, floor_us).items() if k in ("achieved", "frac")}},
                          "plain_fill_of_the_depth_output_us": round(fill_us, 3)},
         }
         if big is not None:

@@ -78,6 +78,12 @@ int shr_set_tuning(int key, int value);
  * differs from the correctly rounded one. */
 int shr_selftest_sqrt(unsigned lo_bits, unsigned hi_bits,
                       unsigned long long *mismatches, void *stream);
+/* Measurement hook (bench.py `roofline.launch_floor`, not part of the path): N workgroups of 1024 threads with
+ * lds_bytes of dynamic LDS -- the sphere forward's launch shape at one crop per CU -- that only move the forward's
+ * bytes: read spheres[N,J,4], write depth[N,H,W] (background) and the owner bytes of rows [row0, row1) of every crop
+ * (argmin may be NULL), full-line 16-byte stores.  W % 16 == 0, buffers 16-byte aligned. */
+int shr_selftest_launch_floor(const float *spheres, int N, int J, int H, int W, int row0, int row1,
+                              float *depth, uint8_t *argmin, int lds_bytes, void *stream);
 
 /* Sphere-set depth rasterizer ------------------------------------------------
  * Replaces BallRender.forward + the min over the sphere axis:

@@ -3,7 +3,7 @@
 
 #include "sphere_zbuf.h"
 
-extern "C" int shr_abi_version(void) { return 13; }
+extern "C" int shr_abi_version(void) { return 14; }
 
 extern "C" const char *shr_error_string(int code) {
   switch (code) {
@@ -46,5 +46,49 @@ extern "C" int shr_selftest_sqrt(unsigned lo_bits, unsigned hi_bits, unsigned lo
   if (!mismatches || hi_bits < lo_bits) return SHR_EINVAL;
   hipLaunchKernelGGL(sqrt_selftest_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, lo_bits, hi_bits,
                      mismatches);
+  return (int)hipGetLastError();
+}
+
+// Launch-floor probe (bench.py `roofline.launch_floor`): the sphere forward's launch shape at one crop per CU -- N
+// workgroups of 1024 threads, `lds_bytes` of dynamic LDS (the forward takes the whole CU's: one workgroup per CU) --
+// doing NOTHING but the forward's memory traffic: the crop's 16 J record bytes in, the H x W fp32 depth image and the
+// owner bytes of rows [row0, row1) out, all as full-line 16-byte stores with the forward's cache policy.  What this
+// takes is the floor of ANY kernel of that shape over those bytes: dispatch of one workgroup per CU, one request
+// round trip, the drain of the write queues, the end-of-kernel release.
+__global__ void __launch_bounds__(1024)
+launch_floor_kernel(const float4 *__restrict__ spheres, int J, int H, int W, int row0, int row1,
+                    float *__restrict__ depth, uint8_t *__restrict__ argmin) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4 *s_rec = reinterpret_cast<float4 *>(smem);
+  const int n = blockIdx.x, tid = threadIdx.x;
+  if (tid < J) {   // (kept alive: the request is issued and awaited like the forward's)
+    const float4 t = spheres[(size_t)n * J + tid];
+    s_rec[tid] = t;
+    asm volatile("" : : "v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
+  }
+  float4 *out4 = reinterpret_cast<float4 *>(depth + (size_t)n * H * W);
+  const int nchunk = (H * W) >> 2;
+  const float4 bg = make_float4(shr::kBackground, shr::kBackground, shr::kBackground, shr::kBackground);
+  for (int c = tid; c < nchunk; c += 1024) shr::stream_store(out4 + c, bg);
+  if (argmin) {
+    uint4 *a16 = reinterpret_cast<uint4 *>(argmin + (size_t)n * H * W + (size_t)row0 * W);
+    const int npiece = ((row1 - row0) * W) >> 4;
+    const uint4 none = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    for (int c = tid; c < npiece; c += 1024) shr::stream_store(a16 + c, none);
+  }
+}
+
+extern "C" int shr_selftest_launch_floor(const float *spheres, int N, int J, int H, int W, int row0, int row1,
+                                         float *depth, uint8_t *argmin, int lds_bytes, void *stream) {
+  if (N == 0) return SHR_OK;
+  if (!spheres || !depth || N < 0 || J <= 0 || J > SHR_MAX_SPHERES || H <= 0 || W <= 0 || (W & 15) || row0 < 0 ||
+      row1 < row0 || row1 > H || lds_bytes < 1024 || lds_bytes > 160 * 1024)
+    return SHR_EINVAL;
+  if ((((uintptr_t)spheres | (uintptr_t)depth | (uintptr_t)argmin) & 15u) != 0) return SHR_EINVAL;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(launch_floor_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(launch_floor_kernel, dim3((unsigned)N), dim3(1024), (size_t)lds_bytes, (hipStream_t)stream,
+                     reinterpret_cast<const float4 *>(spheres), J, H, W, row0, row1, depth, argmin);
   return (int)hipGetLastError();
 }

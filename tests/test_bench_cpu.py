@@ -27,8 +27,24 @@ def test_bench_constants_and_traffic_lookup():
     fwd = 4 * 128 * 128 + 128 * 128 + 16 * 41
     bwd = 4 * 128 * 128 + 128 * 128 + 16 * 41 + 16 * 41
     assert fwd + bwd == 165808
-    # the forward must write every byte; the backward may read fewer (it skips untouched rows)
-    traffic, src = bench.pmc_traffic("sphere_zbuf_fwd_kernel")
-    assert traffic is None or (traffic > 0.9 * 256 * fwd and src.startswith("profiles/"))
-    traffic, src = bench.pmc_traffic("sphere_zbuf_bwd_kernel")
-    assert traffic is None or (0.3 * 256 * bwd < traffic < 1.5 * 256 * bwd and src.startswith("profiles/"))
+    # The committed PMC traffic against the bytes the committed line CLAIMS (touched-rows convention: depth / grad image
+    # + the owner bytes of the touched rows + records): the forward has to write all of them and little more; the
+    # backward stages the touched rows of the gradient only, so it may move less -- never much more.
+    import glob
+    import re
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))
+    traffic_f, src = bench.pmc_traffic("sphere_zbuf_fwd_kernel")
+    traffic_b, _ = bench.pmc_traffic("sphere_zbuf_bwd_kernel")
+    if traffic_f is None or not lines:
+        return
+    assert src.startswith("profiles/")
+    line = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
+    own = float(re.search(r"([\d.]+) %", line["roofline"]["owner_map"]).group(1)) / 100.0
+    claimed_f = 256 * (4 * 128 * 128 + own * 128 * 128 + 16 * 41)
+    claimed_b = 256 * (4 * 128 * 128 + own * 128 * 128 + 32 * 41)
+    conv = line["roofline"].get("byte_conventions")
+    if conv is not None:                                   # (lines since round 4 carry the byte counts themselves)
+        assert abs(conv["touched_rows"]["fwd_bytes"] - claimed_f) <= 1e-3 * claimed_f
+        assert abs(conv["touched_rows"]["bwd_bytes"] - claimed_b) <= 1e-3 * claimed_b
+    assert 0.97 * claimed_f <= traffic_f <= 1.15 * claimed_f, (traffic_f, claimed_f)
+    assert 0.5 * claimed_b <= traffic_b <= 1.15 * claimed_b, (traffic_b, claimed_b)

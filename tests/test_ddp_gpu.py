@@ -54,8 +54,8 @@ def test_one_rank_rccl_ddp_step_equals_the_plain_step(tmp_path):
     gmax = max(v.abs().max().item() for v in plain["grads"].values())
     for k in plain["grads"]:
         assert (plain["grads"][k] - rccl["grads"][k]).abs().max().item() <= 1e-6 * gmax + 1e-9, k
-    for k in plain["params"]:
-        assert (plain["params"][k] - rccl["params"][k]).abs().max().item() <= 2e-6, k
+    for k in plain["params"]:    # after one Adam step (lr 1e-3): a last-bit gradient difference moves a weight by up to ~1e-5
+        assert (plain["params"][k] - rccl["params"][k]).abs().max().item() <= 2e-5, k
 
 
 def test_one_rank_rccl_bucket_allreduce():
