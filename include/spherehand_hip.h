@@ -72,6 +72,7 @@ int shr_device_info(char *name_host, int name_len, int *num_cu_host);
 #define SHR_TUNE_FWD_RUN_TABLE 14   /* forward, whole-crop workgroups on power-of-two images: runs on a sphere start from a
                                     * per-(sphere, lane) LDS table built by the idle waves: -1 = when it fits (default),
                                     * 0 = never, 1 = same as -1 */
+#define SHR_TUNE_MSE_D2M_K 15        /* fused render-and-compare + data->model: points per lane of the search, 0 = default, 2, 4 */
 int shr_set_tuning(int key, int value);
 /* Self-test: adds to *mismatches (device, caller-zeroed u64) the number of fp32
  * bit patterns in [lo_bits, hi_bits) where the rasterizer's internal square root
@@ -171,6 +172,24 @@ int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W,
                           float *depth, float *sse_partial,
                           float *grad_spheres_partial, void *stream);
 
+/* The same launch with the DATA->MODEL term of the same pairing folded in (mesh/multiview_utility.py:103-105 ->
+ * DataToModelLoss, mesh/render.py:123-142): every workgroup searches the foreground pixels (<= 99) of the observed
+ * region it has loaded for the comparison against the crop's spheres -- the observed images are read ONCE for both
+ * terms of MutualProjectionLoss.  The sums leave as 64-bit fixed-point INTEGERS per (crop, region), so that adding
+ * the R regions is exact and the result does not depend on the cut:
+ *   d2m_loss_fx[n*R + r]            sum over the region of clamp(e, 0, 50) in units of 2^-20 mm
+ *                                   (INT64_MIN: a NaN term -- the crop's loss is NaN as in the reference),
+ *   d2m_grad_fx[(n*R + r)*J*3 + .]  d(sum) / d centre_j, components in units of 2^-26,
+ * term for term what shr_data_to_model adds up (one implementation, csrc/d2m_search.h): the totals are bit-identical
+ * to that kernel's.  d2m_diag_v = V > 0 restricts the term to the same-view pairs n with (n / V) % V == n % V
+ * (is_mv = False, mesh/multiview_utility.py:115-127); the other crops' d2m outputs are left unwritten.
+ * _supported: a region of the fused kernel has at most 16384 pixels (64x64 ... 256x256 images do). */
+int shr_sphere_raster_mse_d2m_supported(int H, int W);
+int shr_sphere_raster_mse_d2m(const float *spheres, int N, int J, int H, int W,
+                              const float *target, const int32_t *target_index,
+                              float *depth, float *sse_partial, float *grad_spheres_partial,
+                              int d2m_diag_v, long long *d2m_loss_fx, long long *d2m_grad_fx, void *stream);
+
 /* CollisionLoss and BoneLengthLoss (mesh/render.py:145-206) on M samples of J sphere centres (sample m at
  * joints + m*sample_stride floats, [J][3]) with their gradients, one launch.  Collision pairs: spheres
  * 0..num_palm-1 (palm) against every finger sphere, and finger spheres of different fingers (finger f =
@@ -269,6 +288,13 @@ int shr_mv_loss_combine(const float *cam, const float *inv_cam, const float *sse
                         const float *grad_spheres_part, int Rm, const float *d2m_part,
                         const float *grad_d2m_part, int Rd, int B, int V, int J, int H, int W, int is_mv,
                         float d2m_weight, float *loss, float *grad_joints, void *stream);
+/* The same assembly from the outputs of shr_sphere_raster_mse_d2m: the data->model partials are the fixed-point
+ * integers d2m_loss_fx [N][Rm], d2m_grad_fx [N][Rm][J][3] indexed by PAIR n (with is_mv = 0 only the same-view pairs
+ * are read), summed exactly over the regions before the one conversion to floating point. */
+int shr_mv_loss_combine_fx(const float *cam, const float *inv_cam, const float *sse_part,
+                           const float *grad_spheres_part, int Rm, const long long *d2m_loss_fx,
+                           const long long *d2m_grad_fx, int B, int V, int J, int H, int W, int is_mv,
+                           float d2m_weight, float *loss, float *grad_joints, void *stream);
 /* grad_joints[B,V,J,3] = sum_j R(b,i,j)^T grad_spheres[b,i,j,k].xyz (the view
  * transforms are constants: detached at mesh/multiview_utility.py:68). */
 int shr_mutual_project_bwd(const float *cam, const float *inv_cam, const float *grad_spheres,

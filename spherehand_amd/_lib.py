@@ -15,7 +15,7 @@ import torch  # noqa: F401  (device memory, streams: the plumbing this library s
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libspherehand_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -52,6 +52,9 @@ SIGNATURES = {
     "shr_group_norm_relu_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp], _i),
     "shr_group_norm_relu_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "shr_sphere_raster_mse": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "shr_sphere_raster_mse_d2m_supported": ([_i, _i], _i),
+    "shr_sphere_raster_mse_d2m": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp], _i),
+    "shr_mv_loss_combine_fx": ([_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
     "shr_mutual_project_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "shr_mutual_project_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "shr_tri_raster_fwd": ([_vp, _i, _i, _i, _i, _vp, _vp], _i),

@@ -41,6 +41,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "d2m_search.h"
 
 namespace shr {
 
@@ -52,13 +53,10 @@ constexpr int kD2mCap = 512;                // ring entries per wave (< 256 left
 // ds_read_b64 per point, where the linear layout put a lane's four entries 32 bytes from the next lane's (every
 // eighth lane on the same banks).  The append writes entries consecutive in pixel order: the four of a dense lane
 // go to the four rows at one column, the rows' pitch shifts them by 16 banks each.
-constexpr int kD2mTables = 4;
 constexpr int kD2mTableStride = SHR_MAX_SPHERES * 4 + 2;   // u64 per copy (+ 16 bytes)
 constexpr int kD2mRingCols = kD2mCap / 4;
 constexpr int kD2mRingPitch = kD2mRingCols + 8;   // uint2 per row (+ 64 bytes: rows start 16 banks apart)
 __device__ __forceinline__ int d2m_slot(int e) { return (e & 3) * kD2mRingPitch + ((e >> 2) & (kD2mRingCols - 1)); }
-constexpr float kLossScale = 1048576.f;     // 2^20: loss in units of 2^-20 mm (e <= 50 -> < 2^26 per point)
-constexpr float kGradScale = 67108864.f;    // 2^26 per unit-vector component
 
 // A wave's position in its sequence of units: band `band` = units band * band_units .. (clipped).  Bands are handed
 // out DYNAMICALLY inside the workgroup (an LDS counter): the sums are order-independent integers, so which wave
@@ -124,156 +122,14 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
   uint2 *ring = s_q[wave];
   long long loss_fx = 0;
 
-  // a sphere's record by an explicit LDS read whose wait is placed by hand (see stage 1 below)
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const unsigned table_base = (unsigned)(size_t)s_c;
-  auto lds_request = [&](int j) {
-    f4 r;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(table_base + 16u * (unsigned)j));
-    return r;
-  };
-  auto lds_arrived = [&](f4 &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)); };
-
-  // ---- the search over `count` (<= 64 K) ring entries starting at `head`; lane l takes the K
-  // consecutive entries K l .. K l + K - 1 (neighbouring pixels: mostly one owner) -------------------
+  // ---- the search over `count` (<= 64 K) ring entries starting at `head` (d2m_search.h, shared with the fused
+  // render-and-compare kernel) ----------------------------------------------------------------------
+  D2mCtx ctx;
+  ctx.s_c = s_c; ctx.cj = cj; ctx.all = all; ctx.table_odd = table_odd; ctx.J = J; ctx.lane = lane;
+  ctx.ax = ax; ctx.ay = ay; ctx.s_acc = s_acc; ctx.acc_stride = kD2mTableStride; ctx.s_nan = &s_nan;
   auto search = [&](auto kc, int head, int count) {
     constexpr int K = decltype(kc)::value;
-    float px[K], py[K], pz[K], best[K];
-    int bj[K];
-    bool valid[K];
-    bool zbad = false;
-#pragma unroll
-    for (int i = 0; i < K; i++) {
-      const int idx = K * lane + i;
-      valid[i] = idx < count;
-      const uint2 e = ring[d2m_slot(head + (valid[i] ? idx : 0))];
-      px[i] = axis_coord(ax, (int)(e.x & 0xffffu));
-      py[i] = axis_coord(ay, (int)(e.x >> 16));
-      pz[i] = __uint_as_float(e.y);
-      zbad |= !(fabsf(pz[i]) < __builtin_inff());
-    }
-    auto eval = [&](const float4 c, int j, bool tie_rule) {
-#pragma unroll
-      for (int i = 0; i < K; i++) {
-        const float dx = px[i] - c.x, dy = py[i] - c.y, dz = pz[i] - c.z;
-        const float t = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        const float a = fabsf(__builtin_amdgcn_sqrtf(t) - c.w);   // <= 1 ulp root: the loss is continuous
-        const bool lt = tie_rule ? (a < best[i] || (a == best[i] && j < bj[i])) : (a < best[i]);
-        bj[i] = lt ? j : bj[i];
-        best[i] = lt ? a : best[i];
-      }
-    };
-    if (!table_odd && __ballot(zbad) == 0ull) {
-      // All inputs finite: no NaN can arise (an overflowing distance is +inf).  Strip bounds with
-      // lanes = spheres: rows of the first / last entry (pixel order inside a band).
-      const int v_lo = __builtin_amdgcn_readfirstlane((int)(ring[d2m_slot(head)].x >> 16));
-      const int v_hi = __builtin_amdgcn_readfirstlane((int)(ring[d2m_slot(head + count - 1)].x >> 16));
-      const float y_lo = axis_coord(ay, v_lo), y_hi = axis_coord(ay, v_hi);
-      // <= | ||p - c_j|| - r_j | for every point of the strip, up to the rounding the margins below cover
-      const float lb = fmaxf(fmaxf(y_lo - cj.y, cj.y - y_hi), 0.f) - cj.w;
-      unsigned long long m1 = __ballot(!(lb > 1e-3f)) & all;     // the sphere's y extent meets the strip (or nearly)
-      if (m1 == 0ull) m1 = all;
-#pragma unroll
-      for (int i = 0; i < K; i++) { best[i] = __builtin_inff(); bj[i] = 0; }
-      // stage 1, ascending j, strict '<': ties keep the first index (torch.min's convention).
-      // The NEXT sphere's record is requested before the current one is evaluated (explicit ds_read_b128 +
-      // s_waitcnt: left to itself hipcc reads the record at the top of the iteration and waits for it at once,
-      // one exposed LDS round trip per sphere).
-      {
-        unsigned long long m = m1;
-        int j = __builtin_ctzll(m);
-        f4 c = lds_request(j);
-        lds_arrived(c);
-        while (true) {
-          m &= m - 1;
-          const int jn = m ? __builtin_ctzll(m) : j;
-          f4 cn = lds_request(jn);
-          eval(make_float4(c.x, c.y, c.z, c.w), j, false);
-          lds_arrived(cn);
-          if (!m) break;
-          j = jn; c = cn;
-        }
-      }
-      // stage 2: what could still win or tie.  A point whose minimum stays above 50 is worth exactly 50
-      // with no gradient whatever the owner, so 50 caps the reach.
-      unsigned long long m2 = all & ~m1;
-      if (m2) {
-        float wmax = -__builtin_inff();
-#pragma unroll
-        for (int i = 0; i < K; i++) wmax = fmaxf(wmax, valid[i] ? best[i] : -__builtin_inff());
-        const float reach = fminf(wave_minmax_all<false>(wmax), 50.f) * 1.00001f + 1e-3f;
-        m2 &= __ballot(!(lb * 0.99999f > reach));
-        if (m2) {
-          int j = __builtin_ctzll(m2);
-          f4 c = lds_request(j);
-          lds_arrived(c);
-          while (true) {
-            m2 &= m2 - 1;
-            const int jn = m2 ? __builtin_ctzll(m2) : j;
-            f4 cn = lds_request(jn);
-            eval(make_float4(c.x, c.y, c.z, c.w), j, true);
-            lds_arrived(cn);
-            if (!m2) break;
-            j = jn; c = cn;
-          }
-        }
-      }
-    }
-    else {
-      // a NaN / infinity somewhere: every sphere in index order with torch.min's NaN rule
-      for (int j = 0; j < J; j++) {
-        const float4 c = s_c[j];
-#pragma unroll
-        for (int i = 0; i < K; i++) {
-          const float dx = px[i] - c.x, dy = py[i] - c.y, dz = pz[i] - c.z;
-          const float a = fabsf(__builtin_amdgcn_sqrtf((dx * dx + dy * dy) + dz * dz) - c.w);
-          if (j == 0 || ((best[i] == best[i]) && (a < best[i] || a != a))) { best[i] = a; bj[i] = j; }
-        }
-      }
-    }
-    bool nan = false;
-#pragma unroll
-    for (int i = 0; i < K; i++) {
-      if (valid[i]) {
-        if (best[i] != best[i]) nan = true;           // torch.clamp keeps NaN: the crop's loss is NaN
-        else loss_fx += (long long)__float2int_rn(fminf(fmaxf(best[i], 0.f), 50.f) * kLossScale);
-      }
-    }
-    if (nan) s_nan = 1;
-    if (WANT_GRAD) {
-      int g[K][3];
-      bool live[K];
-#pragma unroll
-      for (int i = 0; i < K; i++) {
-        const float4 c = s_c[bj[i]];
-        const float dx = px[i] - c.x, dy = py[i] - c.y, dz = pz[i] - c.z;
-        const float t2 = (dx * dx + dy * dy) + dz * dz;
-        // the sign decides the gradient's direction: correctly rounded root, as a host sqrtf
-        const float dist = (t2 >= 0.01f && t2 <= 1e12f) ? sqrt_rn(t2) : __builtin_sqrtf(t2);
-        const float t = dist - c.w;
-        live[i] = valid[i] && best[i] <= 50.f && dist != 0.f && t != 0.f && dist < __builtin_inff();
-        const float k = (t > 0.f ? -kGradScale : kGradScale) * __builtin_amdgcn_rcpf(dist);
-        g[i][0] = live[i] ? __float2int_rn(k * dx) : 0;
-        g[i][1] = live[i] ? __float2int_rn(k * dy) : 0;
-        g[i][2] = live[i] ? __float2int_rn(k * dz) : 0;
-      }
-      // a lane's K points are neighbouring pixels: those sharing point 0's owner go with it
-#pragma unroll
-      for (int i = 1; i < K; i++) {
-        const bool same = live[i] && live[0] && bj[i] == bj[0];
-        g[0][0] += same ? g[i][0] : 0; g[0][1] += same ? g[i][1] : 0; g[0][2] += same ? g[i][2] : 0;
-        live[i] = live[i] && !same;
-      }
-#pragma unroll
-      for (int i = 0; i < K; i++) {
-        if (live[i]) {
-          unsigned long long *row = s_acc + (lane & (kD2mTables - 1)) * kD2mTableStride + bj[i] * 4;
-          atomicAdd(row + 0, (unsigned long long)(long long)g[i][0]);
-          atomicAdd(row + 1, (unsigned long long)(long long)g[i][1]);
-          atomicAdd(row + 2, (unsigned long long)(long long)g[i][2]);
-        }
-      }
-    }
+    d2m_search<K, WANT_GRAD>(ctx, [&](int idx) { return ring[d2m_slot(head + idx)]; }, count, loss_fx);
   };
 
   // ---- this wave's units: three loads in flight, compact, search ------------------------------

@@ -89,7 +89,7 @@ def sphere_raster_bwd(spheres, grad_depth, argmin=None):
 
 TUNE_FWD_LDS_BYTES, TUNE_FWD_OWNER_LDS_BYTES, TUNE_BWD_LDS_BYTES, TUNE_FORCE_GENERAL, TUNE_FWD_WAVES = 1, 2, 3, 4, 5
 TUNE_FWD_SHARES, TUNE_BWD_SHARES, TUNE_D2M_WAVES, TUNE_D2M_BAND_UNITS, TUNE_PERSISTENT, TUNE_FWD_ZBUF_BYTES = 6, 7, 8, 9, 10, 11
-TUNE_BWD_WAVES, TUNE_MSE_BOX, TUNE_FWD_RUN_TABLE = 12, 13, 14
+TUNE_BWD_WAVES, TUNE_MSE_BOX, TUNE_FWD_RUN_TABLE, TUNE_MSE_D2M_K = 12, 13, 14, 15
 
 
 def set_tuning(key, value):
@@ -163,6 +163,56 @@ def sphere_raster_mse(spheres, target, target_index=None, want_depth=True):
         else:
             sse, grad = sse.view(N), grad.view(N, J, 4)
     return depth, sse, grad
+
+
+D2M_LOSS_SCALE, D2M_GRAD_SCALE = 2.0 ** -20, 2.0 ** -26   # units of the fused kernel's fixed-point sums
+D2M_NAN = -2 ** 63
+
+
+def sphere_raster_mse_d2m_supported(spheres, target, H, W):
+    """True when shr_sphere_raster_mse_d2m takes these buffers (fused kernel + a region of at most 16384 pixels)."""
+    return sphere_raster_mse_supported(spheres, target, H, W) and \
+        bool(_lib.lib().shr_sphere_raster_mse_d2m_supported(int(H), int(W)))
+
+
+def sphere_raster_mse_d2m(spheres, target, target_index=None, want_depth=True, diag_v=0, raw=False):
+    """The fused render-and-compare launch with the data->model term of the same (crop, observed image) pairing:
+    -> (depth [N,H,W] or None, sse [N], grad_spheres [N,J,4], d2m_loss_sum [N], d2m_grad_centres [N,J,3]).
+    The d2m sums are the kernel's 64-bit fixed-point totals over the regions, converted once (the floats
+    data_to_model() returns for a whole crop); raw=True returns the integer partials [N,R], [N,R,J,3] instead.
+    diag_v = V > 0: only crops n with (n // V) % V == n % V carry a d2m term (the others' entries are undefined)."""
+    _check_input(spheres, "spheres")
+    _check_input(target, "target")
+    if spheres.dim() != 3 or spheres.shape[2] != 4 or target.dim() != 3:
+        raise RuntimeError("spheres must be [N,J,4] and target [M,H,W]")
+    N, J, _ = spheres.shape
+    H, W = target.shape[1:]
+    if target_index is None and target.shape[0] != N:
+        raise RuntimeError("target must hold one image per crop unless target_index is given")
+    if target_index is not None:
+        _check_index(target_index, N, target.shape[0], "target_index")
+    lib = _lib.lib()
+    R = lib.shr_sphere_raster_mse_regions(int(H), int(W))
+    if R <= 0 or not lib.shr_sphere_raster_mse_d2m_supported(int(H), int(W)):
+        raise RuntimeError("image too large for the fused render-and-compare + data->model kernel")
+    dev = spheres.device
+    with _on(dev):
+        depth = torch.empty((N, H, W), dtype=torch.float32, device=dev) if want_depth else None
+        sse = torch.empty((N, R), dtype=torch.float32, device=dev)
+        grad = torch.empty((N, R, J, 4), dtype=torch.float32, device=dev)
+        dl = torch.empty((N, R), dtype=torch.int64, device=dev)
+        dg = torch.empty((N, R, J, 3), dtype=torch.int64, device=dev)
+        _lib.check(lib.shr_sphere_raster_mse_d2m(_ptr(spheres), N, J, H, W, _ptr(target), _ptr(target_index), _ptr(depth),
+                                                 _ptr(sse), _ptr(grad), int(diag_v), _ptr(dl), _ptr(dg), _stream()),
+                   "shr_sphere_raster_mse_d2m")
+        sse, grad = (sse.sum(1), grad.sum(1)) if R > 1 else (sse.view(N), grad.view(N, J, 4))
+        if raw:
+            return depth, sse, grad, dl, dg
+        nan = (dl == D2M_NAN).any(1)
+        loss = (dl.sum(1).double() * D2M_LOSS_SCALE).float()
+        loss = torch.where(nan, torch.full_like(loss, float("nan")), loss)
+        gcen = (dg.sum(1).double() * D2M_GRAD_SCALE).float()
+    return depth, sse, grad, loss, gcen
 
 
 class SphereRasterSSE(torch.autograd.Function):
@@ -245,12 +295,16 @@ class DataToModel(torch.autograd.Function):
         return None, grad * (grad_out / ctx.count), None, None
 
 
+FUSE_D2M = True    # MutualProjectionLossFused: data->model inside the render-and-compare launch (False: its own kernel)
+
+
 class MutualProjectionLossFused(torch.autograd.Function):
     """(cam, inv_cam [B,V,4,4], joints [B,V,J,3], observed [B*V,H,W], radii [J], index [B*V*V] int32, is_mv) ->
-    (loss, projected depth [B*V*V,H,W]): MutualProjectionLoss (mesh/multiview_utility.py:90-130) as FIVE launches
-    -- view projection, fused render-and-compare, data->model, and the assembly kernel that weights, adds and
-    pulls both sphere gradients back to the joints (the whole backward is done in the forward: the losses are
-    plain sums) -- plus one scaling in backward.  The unfused wiring needed ~35 small torch launches around the
+    (loss, projected depth [B*V*V,H,W]): MutualProjectionLoss (mesh/multiview_utility.py:90-130) as FOUR launches
+    -- view projection, fused render-and-compare WITH the data->model search of the same pairing, and the assembly
+    kernel that weights, adds and pulls both sphere gradients back to the joints (the whole backward is done in the
+    forward: the losses are plain sums) -- plus one scaling in backward.  (FUSE_D2M = False, or an image whose
+    regions exceed the fused search: data->model as its own launch, five in all.)  The unfused wiring needed ~35 small torch launches around the
     same three kernels."""
 
     @staticmethod
@@ -280,25 +334,37 @@ class MutualProjectionLossFused(torch.autograd.Function):
             depth = torch.empty((N, H, W), dtype=torch.float32, device=dev)
             sse = torch.empty((N, Rm), dtype=torch.float32, device=dev)
             gsp = torch.empty((N, Rm, J, 4), dtype=torch.float32, device=dev)
-            _lib.check(lib.shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), _ptr(depth),
-                                                 _ptr(sse), _ptr(gsp), _stream()), "shr_sphere_raster_mse")
-            if is_mv:
-                E, cen, cidx = N, spheres, index
-            else:                # the V same-view pairs only: their records and observed-image numbers, gathered
-                E = B * V
-                cen = spheres.index_select(0, diag_index)
-                cidx = index.index_select(0, diag_index)
-            Rd = lib.shr_data_to_model_parts(E, int(H), int(W))
-            d2m = torch.empty((E, Rd), dtype=torch.float32, device=dev)
-            gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
-            _lib.check(lib.shr_data_to_model_partial(_ptr(observed), _ptr(cidx), _ptr(cen), 4, _ptr(radii), E, J, H, W, Rd,
-                                                     _ptr(d2m), _ptr(gd2m), _stream()), "shr_data_to_model_partial")
             loss = torch.empty(1, dtype=torch.float32, device=dev)
             want = ctx.needs_input_grad[2]
             gj = torch.empty((B, V, J, 3), dtype=torch.float32, device=dev) if want else None
-            _lib.check(lib.shr_mv_loss_combine(_ptr(cam), _ptr(inv_cam), _ptr(sse), _ptr(gsp), Rm, _ptr(d2m), _ptr(gd2m), Rd,
-                                               B, V, J, H, W, int(bool(is_mv)), float(d2m_weight), _ptr(loss), _ptr(gj),
-                                               _stream()), "shr_mv_loss_combine")
+            if FUSE_D2M and lib.shr_sphere_raster_mse_d2m_supported(int(H), int(W)) and observed.data_ptr() % 16 == 0:
+                # FOUR launches: the data->model term rides in the render-and-compare kernel (one read of the observed
+                # images for both terms); with is_mv = False only the same-view pairs are searched (diag_v = V)
+                dl = torch.empty((N, Rm), dtype=torch.int64, device=dev)
+                dg = torch.empty((N, Rm, J, 3), dtype=torch.int64, device=dev)
+                _lib.check(lib.shr_sphere_raster_mse_d2m(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), _ptr(depth),
+                                                         _ptr(sse), _ptr(gsp), 0 if is_mv else V, _ptr(dl), _ptr(dg),
+                                                         _stream()), "shr_sphere_raster_mse_d2m")
+                _lib.check(lib.shr_mv_loss_combine_fx(_ptr(cam), _ptr(inv_cam), _ptr(sse), _ptr(gsp), Rm, _ptr(dl), _ptr(dg),
+                                                      B, V, J, H, W, int(bool(is_mv)), float(d2m_weight), _ptr(loss),
+                                                      _ptr(gj), _stream()), "shr_mv_loss_combine_fx")
+            else:
+                _lib.check(lib.shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), _ptr(depth),
+                                                     _ptr(sse), _ptr(gsp), _stream()), "shr_sphere_raster_mse")
+                if is_mv:
+                    E, cen, cidx = N, spheres, index
+                else:                # the V same-view pairs only: their records and observed-image numbers, gathered
+                    E = B * V
+                    cen = spheres.index_select(0, diag_index)
+                    cidx = index.index_select(0, diag_index)
+                Rd = lib.shr_data_to_model_parts(E, int(H), int(W))
+                d2m = torch.empty((E, Rd), dtype=torch.float32, device=dev)
+                gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
+                _lib.check(lib.shr_data_to_model_partial(_ptr(observed), _ptr(cidx), _ptr(cen), 4, _ptr(radii), E, J, H, W, Rd,
+                                                         _ptr(d2m), _ptr(gd2m), _stream()), "shr_data_to_model_partial")
+                _lib.check(lib.shr_mv_loss_combine(_ptr(cam), _ptr(inv_cam), _ptr(sse), _ptr(gsp), Rm, _ptr(d2m), _ptr(gd2m), Rd,
+                                                   B, V, J, H, W, int(bool(is_mv)), float(d2m_weight), _ptr(loss), _ptr(gj),
+                                                   _stream()), "shr_mv_loss_combine")
         if want:
             ctx.save_for_backward(gj)
         ctx.mark_non_differentiable(depth)
