@@ -320,7 +320,14 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
         loss, _ = crit(cam, inv, joints, real, True)
         loss.backward()
     n5 = B5 * 9
+    # the data->model term compacts every observed image into a point list first; MutualProjectionLoss keeps the lists
+    # while it is handed the same observations again (a second hourglass stack, a fitting loop).  Training feeds fresh
+    # observations every step: the headline number is measured with the cache OFF, the cached one beside it.
+    crit.cache_points = False
     t_mv = torch_us(mv_step, 10)
+    crit.cache_points = True
+    t_mv_cached = torch_us(mv_step, 10)
+    crit.cache_points = False
     with torch.no_grad():
         _, pts = crit.mutual_projection(cam, inv, joints.detach())
     obs = real.view(B5 * 3, S5, S5).contiguous()
@@ -334,6 +341,16 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     a = [t.data_ptr() for t in (obs, index, cen, rad, ls, gr)]
     t_d2m = mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_partial(a[0], a[1], a[2], 3, a[3], n5, J, S5, S5, R,
                                                                                a[4], a[5], s), "d2m"), stream, 20, 3, 3)
+    # two-step data->model: compaction per observed IMAGE (384), search per crop (1152)
+    M5 = B5 * 3
+    ws = ops.d2m_compact(obs)
+    Pp = ops.d2m_points_parts(n5)
+    ls2 = torch.empty(n5 * Pp, device=dev); gr2 = torch.empty(n5 * Pp, J, 3, device=dev)
+    t_cmp = mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_compact(a[0], M5, S5, S5, ws.data_ptr(), s), "compact"),
+                           stream, 20, 3, 3)
+    t_pts = mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_from_points(ws.data_ptr(), M5, a[1], a[2], 3, a[3], n5, J, S5, S5, Pp,
+                                                                                   ls2.data_ptr(), gr2.data_ptr(), s), "points"), stream, 20, 3, 3)
+    fg_px = int((obs <= 99).sum().item())                       # foreground pixels of the 384 observed images
     Rm = lib.shr_sphere_raster_mse_regions(S5, S5)
     dep = torch.empty(n5, S5, S5, device=dev); sse = torch.empty(n5 * Rm, device=dev)
     gsp = torch.empty(n5 * Rm, J, 4, device=dev)
@@ -342,12 +359,21 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
                                                                            m[5], s), "mse"), stream, 20, 3, 3)
     sec["config5_per_gpu_1152_crops_256x256"] = {
         "mutual_projection_loss_fwd_bwd_us": round(t_mv, 1),
+        "mutual_projection_loss_fwd_bwd_same_observations_us": round(t_mv_cached, 1),
+        "mutual_projection_loss_is": "forward + backward of MutualProjectionLoss on fresh observations every call (point-list "
+                                     "cache off: what a training step pays); _same_observations_us = the same with the cache "
+                                     "on and the observed images unchanged between calls (second hourglass stack, fitting loop)",
         "crops_per_s": round(n5 / (t_mv * 1e-6), 1),
-        # data->model: every pair reads its observed image once (4 S^2) + the 41 records
+        # two-step data->model (the path the loss takes): images read once (4 S^2 each) and their foreground written as
+        # 16-byte points; the search reads every crop's image list (16 B per point) + the 41 records
+        "d2m_compact_kernel": dict(us=round(t_cmp, 1), images=M5, **roof(M5 * 4 * S5 * S5 + 16 * fg_px, t_cmp)),
+        "d2m_points_kernel": dict(us=round(t_pts, 1), parts=Pp, **roof(3 * 16 * fg_px + n5 * 16 * J, t_pts)),
+        # the streaming kernel (round 2; still behind shr_data_to_model_partial): every pair reads its image (4 S^2)
         "data_to_model_kernel": dict(us=round(t_d2m, 1), workgroups_per_crop=R, **roof(n5 * (4 * S5 * S5 + 16 * J), t_d2m)),
         # fused render-and-compare: reads the observed image, writes the projection (returned by the loss)
         "sphere_zbuf_mse_kernel": dict(us=round(t_mse, 1), **roof(n5 * (8 * S5 * S5 + 32 * J), t_mse)),
     }
+    del ws, ls2, gr2
     del ds, crit, real, obs, dep, gsp, gr
 
     # the same two kernels at 128x128 (1152 crops)

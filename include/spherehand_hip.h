@@ -72,7 +72,9 @@ int shr_device_info(char *name_host, int name_len, int *num_cu_host);
 #define SHR_TUNE_FWD_RUN_TABLE 14   /* forward, whole-crop workgroups on power-of-two images: runs on a sphere start from a
                                     * per-(sphere, lane) LDS table built by the idle waves: -1 = when it fits (default),
                                     * 0 = never, 1 = same as -1 */
-#define SHR_TUNE_MSE_D2M_K 15        /* fused render-and-compare + data->model: points per lane of the search, 0 = default, 2, 4 */
+#define SHR_TUNE_D2M_TILED 15        /* data->model kernel: 1 = units are 32 x 8-pixel tiles and a search is bounded by its
+                                    * points' own x-y box (default wherever W % 4 == 0 and the images are 16-byte aligned),
+                                    * 0 = 256 consecutive pixels per unit and strip bounds (round 2's kernel) */
 int shr_set_tuning(int key, int value);
 /* Self-test: adds to *mismatches (device, caller-zeroed u64) the number of fp32
  * bit patterns in [lo_bits, hi_bits) where the rasterizer's internal square root
@@ -154,6 +156,26 @@ int shr_data_to_model_partial(const float *depth, const int32_t *depth_index,
                               int N, int J, int H, int W, int parts, float *loss_parts,
                               float *grad_parts, void *stream);
 
+/* The same loss in TWO STEPS (round 4), for callers that compare one observed image with several sphere sets (the V*V
+ * view pairs of mesh/multiview_utility.py:98-105 share V images) -- or that just want the faster path:
+ *   shr_data_to_model_compact      every image of depth[M,H,W] once: its foreground pixels (<= 99) as (xg, yg, depth, v << 16 | u)
+ *                                  records sorted by 16 x 16-pixel tile, into `workspace`
+ *                                  (shr_data_to_model_points_bytes(M, H, W) bytes, 16-byte aligned; 0 = image not
+ *                                  taken: W % 4 != 0 or more than 2^28 pixels -- use the calls above);
+ *   shr_data_to_model_from_points  crop n (sphere set n) against the points of image depth_index[n] (or n; then
+ *                                  M == N): loss_parts [N*parts], grad_parts [N*parts][J][3] (may be NULL) exactly
+ *                                  as shr_data_to_model_partial returns them, 1 <= parts <= 64.
+ * The per-point search is the same code (csrc/d2m_search.h) with a tighter -- still conservative -- bound; the sums
+ * are fixed-point integers: for parts = 1 the results are bit-identical to shr_data_to_model's and bit-reproducible.
+ * (With parts > 1 a part owns every parts-th group of 256 points of the image's list, whose order follows the arrival
+ * of the compaction's workgroups: the PARTIAL sums then vary from run to run, their total only to a float rounding.) */
+long long shr_data_to_model_points_bytes(int M, int H, int W);
+int shr_data_to_model_compact(const float *depth, int M, int H, int W, void *workspace, void *stream);
+int shr_data_to_model_from_points(const void *workspace, int M, const int32_t *depth_index,
+                                  const float *centres, int centre_stride, const float *radii,
+                                  int N, int J, int H, int W, int parts, float *loss_parts,
+                                  float *grad_parts, void *stream);
+
 /* Fused render-and-compare: the model->data term of mesh/multiview_utility.py:98-101 and
  * :107-113 (MSELoss(BallRender(...).min(), observed)) with its whole backward, one
  * launch: e = raster(spheres[n]) - target[target_index ? target_index[n] : n],
@@ -171,24 +193,6 @@ int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W,
                           const float *target, const int32_t *target_index,
                           float *depth, float *sse_partial,
                           float *grad_spheres_partial, void *stream);
-
-/* The same launch with the DATA->MODEL term of the same pairing folded in (mesh/multiview_utility.py:103-105 ->
- * DataToModelLoss, mesh/render.py:123-142): every workgroup searches the foreground pixels (<= 99) of the observed
- * region it has loaded for the comparison against the crop's spheres -- the observed images are read ONCE for both
- * terms of MutualProjectionLoss.  The sums leave as 64-bit fixed-point INTEGERS per (crop, region), so that adding
- * the R regions is exact and the result does not depend on the cut:
- *   d2m_loss_fx[n*R + r]            sum over the region of clamp(e, 0, 50) in units of 2^-20 mm
- *                                   (INT64_MIN: a NaN term -- the crop's loss is NaN as in the reference),
- *   d2m_grad_fx[(n*R + r)*J*3 + .]  d(sum) / d centre_j, components in units of 2^-26,
- * term for term what shr_data_to_model adds up (one implementation, csrc/d2m_search.h): the totals are bit-identical
- * to that kernel's.  d2m_diag_v = V > 0 restricts the term to the same-view pairs n with (n / V) % V == n % V
- * (is_mv = False, mesh/multiview_utility.py:115-127); the other crops' d2m outputs are left unwritten.
- * _supported: a region of the fused kernel has at most 16384 pixels (64x64 ... 256x256 images do). */
-int shr_sphere_raster_mse_d2m_supported(int H, int W);
-int shr_sphere_raster_mse_d2m(const float *spheres, int N, int J, int H, int W,
-                              const float *target, const int32_t *target_index,
-                              float *depth, float *sse_partial, float *grad_spheres_partial,
-                              int d2m_diag_v, long long *d2m_loss_fx, long long *d2m_grad_fx, void *stream);
 
 /* CollisionLoss and BoneLengthLoss (mesh/render.py:145-206) on M samples of J sphere centres (sample m at
  * joints + m*sample_stride floats, [J][3]) with their gradients, one launch.  Collision pairs: spheres
@@ -288,13 +292,6 @@ int shr_mv_loss_combine(const float *cam, const float *inv_cam, const float *sse
                         const float *grad_spheres_part, int Rm, const float *d2m_part,
                         const float *grad_d2m_part, int Rd, int B, int V, int J, int H, int W, int is_mv,
                         float d2m_weight, float *loss, float *grad_joints, void *stream);
-/* The same assembly from the outputs of shr_sphere_raster_mse_d2m: the data->model partials are the fixed-point
- * integers d2m_loss_fx [N][Rm], d2m_grad_fx [N][Rm][J][3] indexed by PAIR n (with is_mv = 0 only the same-view pairs
- * are read), summed exactly over the regions before the one conversion to floating point. */
-int shr_mv_loss_combine_fx(const float *cam, const float *inv_cam, const float *sse_part,
-                           const float *grad_spheres_part, int Rm, const long long *d2m_loss_fx,
-                           const long long *d2m_grad_fx, int B, int V, int J, int H, int W, int is_mv,
-                           float d2m_weight, float *loss, float *grad_joints, void *stream);
 /* grad_joints[B,V,J,3] = sum_j R(b,i,j)^T grad_spheres[b,i,j,k].xyz (the view
  * transforms are constants: detached at mesh/multiview_utility.py:68). */
 int shr_mutual_project_bwd(const float *cam, const float *inv_cam, const float *grad_spheres,

@@ -36,6 +36,9 @@ SIGNATURES = {
     "shr_data_to_model_indexed": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "shr_data_to_model_parts": ([_i, _i, _i], _i),
     "shr_data_to_model_partial": ([_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
+    "shr_data_to_model_points_bytes": ([_i, _i, _i], ctypes.c_longlong),
+    "shr_data_to_model_compact": ([_vp, _i, _i, _i, _vp, _vp], _i),
+    "shr_data_to_model_from_points": ([_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "shr_mv_loss_combine": ([_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
     "shr_sphere_raster_mse_regions": ([_i, _i], _i),
     "shr_pair_losses": ([_vp, ctypes.c_longlong, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
@@ -52,9 +55,6 @@ SIGNATURES = {
     "shr_group_norm_relu_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp], _i),
     "shr_group_norm_relu_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "shr_sphere_raster_mse": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
-    "shr_sphere_raster_mse_d2m_supported": ([_i, _i], _i),
-    "shr_sphere_raster_mse_d2m": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp], _i),
-    "shr_mv_loss_combine_fx": ([_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
     "shr_mutual_project_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "shr_mutual_project_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "shr_tri_raster_fwd": ([_vp, _i, _i, _i, _i, _vp, _vp], _i),

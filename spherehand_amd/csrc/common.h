@@ -182,6 +182,7 @@ __device__ __forceinline__ float sqrt_rn(float x) {
 
 int d2m_set_waves(int waves);        // data_to_model.hip: launch-shape hooks behind SHR_TUNE_D2M_WAVES /
 int d2m_set_band_units(int units);  // SHR_TUNE_D2M_BAND_UNITS
+int d2m_set_tiled(int on);          // SHR_TUNE_D2M_TILED
 
 __device__ __forceinline__ bool is_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 

@@ -44,16 +44,23 @@ struct D2mCtx {
 
 // entry(i), 0 <= i < count <= 64 K: the group's i-th point as (v << 16 | u, bits(z)).
 // BOX2D = false: the entries are in pixel order and the bound is the strip of rows between the first and the last one.
-// BOX2D = true (the fused kernel's tile-sorted queue): any order; the bound is the points' own bounding box in x and y
-// (one transposed four-component wave minimum over the coordinates the lanes already hold),
-//     | ||p - c|| - r | >= dist_xy(c, box) - r,
-// which a group of one or two 16 x 16-pixel tiles makes far tighter than a strip across the whole hand (7-8 spheres
-// searched per point instead of ~19 at 256 x 256).  Both bounds are conservative: the minimum and its first index are
+// BOX2D = true (tile-sorted points): any order; the bound is the points' own bounding BOX in x, y and z (two transposed
+// wave minima over the coordinates the lanes already hold),
+//     | ||p - c|| - r | >= dist(c, box) - r,
+// which a group of one or two 16 x 16-pixel tiles makes far tighter than a strip across the whole hand: at 256 x 256,
+// 1 mm of pose noise, 256-point groups (tools/analyze_d2m_groups.py) 6.9 + 0.8 spheres are evaluated per point (stage 1
+// + stage 2) against 11.8 + 1.4 with pixel-order strips; the depth extent of a tile alone removes a quarter (9.3 + 1.0
+// with the x-y box only).  Both bounds are conservative: the minimum and its first index are
 // exact either way, so the fixed-point terms -- and the sums -- do not depend on the grouping.
-template <int K, bool WANT_GRAD, bool BOX2D = false, typename Entry>
-__device__ __forceinline__ void d2m_search(const D2mCtx &cx, Entry &&entry, int count, long long &loss_fx) {
+// (core: the group's points already in registers as COORDINATES -- px, py = the grid coordinates of mesh/render.py:31-32
+// (axis_coord), pz = the depth value; lane l holds points K l + i; first_v / last_v = rows of the group's first and
+// last entry, used by the strip bound only)
+template <int K, bool WANT_GRAD, bool BOX2D>
+__device__ __forceinline__ void d2m_search_core(const D2mCtx &cx, const float (&px)[K], const float (&py)[K],
+                                                const float (&pz)[K], int count, int first_v, int last_v,
+                                                long long &loss_fx) {
   const int lane = cx.lane;
-  const Axis &ax = cx.ax, &ay = cx.ay;
+  const Axis &ay = cx.ay;
   const float4 *s_c = cx.s_c;
   const float4 cj = cx.cj;
   // a sphere's record by an explicit LDS read whose wait is placed by hand (see stage 1 below)
@@ -66,18 +73,13 @@ __device__ __forceinline__ void d2m_search(const D2mCtx &cx, Entry &&entry, int 
   };
   auto lds_arrived = [&](f4 &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)); };
 
-  float px[K], py[K], pz[K], best[K];
+  float best[K];
   int bj[K];
   bool valid[K];
   bool zbad = false;
 #pragma unroll
   for (int i = 0; i < K; i++) {
-    const int idx = K * lane + i;
-    valid[i] = idx < count;
-    const uint2 e = entry(valid[i] ? idx : 0);
-    px[i] = axis_coord(ax, (int)(e.x & 0xffffu));
-    py[i] = axis_coord(ay, (int)(e.x >> 16));
-    pz[i] = __uint_as_float(e.y);
+    valid[i] = K * lane + i < count;
     zbad |= !(fabsf(pz[i]) < __builtin_inff());
   }
   auto eval = [&](const float4 c, int j, bool tie_rule) {
@@ -96,22 +98,23 @@ __device__ __forceinline__ void d2m_search(const D2mCtx &cx, Entry &&entry, int 
     float lb;
     if (BOX2D) {
       const float inf = __builtin_inff();
-      float x0 = inf, x1 = inf, y0 = inf, y1 = inf;    // (min x, min -x, min y, min -y over the lane's valid points)
+      float x0 = inf, x1 = inf, y0 = inf, y1 = inf, z0 = inf, z1 = inf;   // (min x, min -x, ... over the lane's valid points)
 #pragma unroll
       for (int i = 0; i < K; i++) {
         x0 = fminf(x0, valid[i] ? px[i] : inf); x1 = fminf(x1, valid[i] ? -px[i] : inf);
         y0 = fminf(y0, valid[i] ? py[i] : inf); y1 = fminf(y1, valid[i] ? -py[i] : inf);
+        z0 = fminf(z0, valid[i] ? pz[i] : inf); z1 = fminf(z1, valid[i] ? -pz[i] : inf);
       }
-      const float m = wave_min4_transposed(x0, x1, y0, y1, lane);
+      const float m = wave_min4_transposed(x0, x1, y0, y1, lane), mz = wave_min4_transposed(z0, z1, z0, z1, lane);
       const float x_lo = readlane_f(m, 12), x_hi = -readlane_f(m, 13), y_lo = readlane_f(m, 14), y_hi = -readlane_f(m, 15);
+      const float z_lo = readlane_f(mz, 12), z_hi = -readlane_f(mz, 13);
       const float ddx = fmaxf(fmaxf(x_lo - cj.x, cj.x - x_hi), 0.f), ddy = fmaxf(fmaxf(y_lo - cj.y, cj.y - y_hi), 0.f);
-      // (v_sqrt_f32 is within an ulp, the sum of squares within two: the margins below are 1e-5 relative + 1e-3 mm)
-      lb = __builtin_amdgcn_sqrtf(ddx * ddx + ddy * ddy) - cj.w;
+      const float ddz = fmaxf(fmaxf(z_lo - cj.z, cj.z - z_hi), 0.f);
+      // (v_sqrt_f32 is within an ulp, the sum of squares within three: the margins below are 1e-5 relative + 1e-3 mm)
+      lb = __builtin_amdgcn_sqrtf((ddx * ddx + ddy * ddy) + ddz * ddz) - cj.w;
     } else {
       // rows of the first / last entry (pixel order inside a group)
-      const int v_lo = __builtin_amdgcn_readfirstlane((int)(entry(0).x >> 16));
-      const int v_hi = __builtin_amdgcn_readfirstlane((int)(entry(count - 1).x >> 16));
-      const float y_lo = axis_coord(ay, v_lo), y_hi = axis_coord(ay, v_hi);
+      const float y_lo = axis_coord(ay, first_v), y_hi = axis_coord(ay, last_v);
       lb = fmaxf(fmaxf(y_lo - cj.y, cj.y - y_hi), 0.f) - cj.w;
     }
     // lb <= | ||p - c_j|| - r_j | for every point of the group, up to the rounding the margins below cover
@@ -224,6 +227,36 @@ __device__ __forceinline__ void d2m_search(const D2mCtx &cx, Entry &&entry, int 
       }
     }
   }
+}
+
+// entry(i), 0 <= i < count <= 64 K: the group's i-th point as (v << 16 | u, bits(z)) (a lane without a point reads
+// entry 0: finite coordinates, never counted).
+template <int K, bool WANT_GRAD, bool BOX2D = false, typename Entry>
+__device__ __forceinline__ void d2m_search(const D2mCtx &cx, Entry &&entry, int count, long long &loss_fx) {
+  float px[K], py[K], pz[K];
+#pragma unroll
+  for (int i = 0; i < K; i++) {
+    const int idx = K * cx.lane + i;
+    const uint2 e = entry(idx < count ? idx : 0);
+    px[i] = axis_coord(cx.ax, (int)(e.x & 0xffffu));
+    py[i] = axis_coord(cx.ay, (int)(e.x >> 16));
+    pz[i] = __uint_as_float(e.y);
+  }
+  int first_v = 0, last_v = 0;
+  if (!BOX2D) {
+    first_v = __builtin_amdgcn_readfirstlane((int)(entry(0).x >> 16));
+    last_v = __builtin_amdgcn_readfirstlane((int)(entry(count - 1).x >> 16));
+  }
+  d2m_search_core<K, WANT_GRAD, BOX2D>(cx, px, py, pz, count, first_v, last_v, loss_fx);
+}
+
+// The same for points that come with their coordinates (the two-step path's lists): e[i] = (xg, yg, depth, -), box bound.
+template <int K, bool WANT_GRAD>
+__device__ __forceinline__ void d2m_search_points(const D2mCtx &cx, const float4 (&e)[K], int count, long long &loss_fx) {
+  float px[K], py[K], pz[K];
+#pragma unroll
+  for (int i = 0; i < K; i++) { px[i] = e[i].x; py[i] = e[i].y; pz[i] = e[i].z; }
+  d2m_search_core<K, WANT_GRAD, true>(cx, px, py, pz, count, 0, 0, loss_fx);
 }
 
 }  // namespace shr

@@ -77,43 +77,27 @@ __global__ void mutual_project_bwd_kernel(const float *__restrict__ cam, const f
 // gradients of the two kernels (R partials each) weighted, added and pulled back through the view transforms
 // (constants: detached at :68; the radii are buffers).  The loss is accumulated in fp64 in a fixed order.
 // d2m_part / gd2m_part hold one entry per pair (is_mv) or per DIAGONAL pair b*V+i (else).
-// FX (round 4): the data->model partials are the fused kernel's fixed-point integers, one entry per PAIR n and region
-// (d2m_part = long long [N][Rd] in 2^-20 mm, LLONG_MIN = NaN; gd2m_part = long long [N][Rd][J][3] in 2^-26): the
-// regions are added as integers -- exact, whatever the cut -- and converted once, to the float the stand-alone kernel
-// returns for the whole crop.
-template <bool FX>
 __global__ void __launch_bounds__(256)
 mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ inv_cam,
                        const float *__restrict__ sse_part, const float4 *__restrict__ gsp_part, int Rm,
-                       const void *__restrict__ d2m_part_, const void *__restrict__ gd2m_part_, int Rd, int B, int V,
+                       const float *__restrict__ d2m_part, const float *__restrict__ gd2m_part, int Rd, int B, int V,
                        int J, int is_mv, float w_m, float w_d, float *__restrict__ loss_out,
                        float *__restrict__ grad_joints) {
-  const float *d2m_part = static_cast<const float *>(d2m_part_), *gd2m_part = static_cast<const float *>(gd2m_part_);
-  const long long *d2m_fx = static_cast<const long long *>(d2m_part_), *gd2m_fx = static_cast<const long long *>(gd2m_part_);
   const long long total = (long long)B * V * J;
   if (blockIdx.x == gridDim.x - 1) {
-    // the scalar: one workgroup, every thread a strided fp64 partial, then a fixed tree
+    // the scalar: one workgroup; every thread a strided fp64 partial over the FLAT partial-result arrays (one element
+    // per iteration: independent loads, where a loop over pairs with inner loops over the parts chained 4.5 x 8
+    // dependent round trips per thread -- 11 us for config 5's 1152 pairs), then a fixed tree: deterministic
     __shared__ double s_m[256], s_d[256];
     const long long N = (long long)B * V * V;
     double am = 0.0, ad = 0.0;
-    for (long long n = threadIdx.x; n < N; n += 256) {
+    for (long long e = threadIdx.x; e < N * Rm; e += 256) {
+      const long long n = e / Rm;
       const int j = (int)(n % V), i = (int)((n / V) % V);
-      if (!is_mv && i != j) continue;
-      for (int r = 0; r < Rm; r++) am += (double)sse_part[n * Rm + r];
-      if (FX) {
-        long long t = 0;
-        bool nan = false;
-        for (int r = 0; r < Rd; r++) {
-          const long long v = d2m_fx[n * Rd + r];
-          nan |= v == (long long)0x8000000000000000ull;
-          t += v;
-        }
-        ad += nan ? (double)__builtin_nanf("") : (double)(float)((double)t * (1.0 / 1048576.0));
-      } else {
-        const long long e = is_mv ? n : (n / ((long long)V * V)) * V + i;
-        for (int r = 0; r < Rd; r++) ad += (double)d2m_part[e * Rd + r];
-      }
+      if (is_mv || i == j) am += (double)sse_part[e];
     }
+    const long long E = is_mv ? N : (long long)B * V;     // d2m entries: every pair, or the same-view pairs only
+    for (long long e = threadIdx.x; e < E * Rd; e += 256) ad += (double)d2m_part[e];
     s_m[threadIdx.x] = am; s_d[threadIdx.x] = ad;
     __syncthreads();
     for (int h = 128; h > 0; h >>= 1) {
@@ -138,21 +122,10 @@ mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ 
       gx += a.x; gy += a.y; gz += a.z;
     }
     float dx = 0.f, dy = 0.f, dz = 0.f;
-    if (FX) {
-      long long tx = 0, ty = 0, tz = 0;
-      for (int r = 0; r < Rd; r++) {
-        const long long *a = gd2m_fx + ((n * Rd + r) * J + k) * 3;
-        tx += a[0]; ty += a[1]; tz += a[2];
-      }
-      dx = (float)((double)tx * (1.0 / 67108864.0));
-      dy = (float)((double)ty * (1.0 / 67108864.0));
-      dz = (float)((double)tz * (1.0 / 67108864.0));
-    } else {
-      const long long e = is_mv ? n : (long long)b * V + i;
-      for (int r = 0; r < Rd; r++) {
-        const float *a = gd2m_part + ((e * Rd + r) * J + k) * 3;
-        dx += a[0]; dy += a[1]; dz += a[2];
-      }
+    const long long e = is_mv ? n : (long long)b * V + i;
+    for (int r = 0; r < Rd; r++) {
+      const float *a = gd2m_part + ((e * Rd + r) * J + k) * 3;
+      dx += a[0]; dy += a[1]; dz += a[2];
     }
     const float sx = w_m * gx + w_d * dx, sy = w_m * gy + w_d * dy, sz = w_m * gz + w_d * dz;
     float R[3][3], t[3];
@@ -166,18 +139,16 @@ mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ 
 
 }  // namespace shr
 
-namespace {
-template <bool FX>
-int launch_combine(const float *cam, const float *inv_cam, const float *sse_part, const float *grad_spheres_part, int Rm,
-                   const void *d2m_part, const void *grad_d2m_part, int Rd, int B, int V, int J, int H, int W, int is_mv,
-                   float d2m_weight, float *loss, float *grad_joints, void *stream) {
+extern "C" int shr_mv_loss_combine(const float *cam, const float *inv_cam, const float *sse_part,
+                                   const float *grad_spheres_part, int Rm, const float *d2m_part,
+                                   const float *grad_d2m_part, int Rd, int B, int V, int J, int H, int W, int is_mv,
+                                   float d2m_weight, float *loss, float *grad_joints, void *stream) {
   using namespace shr;
   if (B == 0) return SHR_OK;
   if (!cam || !inv_cam || !sse_part || !grad_spheres_part || !d2m_part || !grad_d2m_part || !loss || B < 0 || V <= 0 ||
       J <= 0 || H <= 0 || W <= 0 || Rm <= 0 || Rd <= 0)
     return SHR_EINVAL;
   if (((uintptr_t)grad_spheres_part & 15u) != 0) return SHR_EINVAL;
-  if (FX && ((((uintptr_t)d2m_part | (uintptr_t)grad_d2m_part) & 7u) != 0)) return SHR_EINVAL;
   if ((long long)B * V * V * J > (1LL << 31) - 256) return SHR_ETOOLARGE;
   // MSELoss means and the reference's x9 / x3 (mesh/multiview_utility.py:100-101, :126-127); DataToModelLoss means
   // over the same pixel counts (mesh/render.py:142) times its x9 / x3 and the caller's 500 (:129)
@@ -185,27 +156,10 @@ int launch_combine(const float *cam, const float *inv_cam, const float *sse_part
   const double wm = is_mv ? 9.0 / ((double)B * V * V * px) : 3.0 / ((double)B * px);
   const double wd = (double)d2m_weight * wm;
   const long long total = (long long)B * V * J;
-  hipLaunchKernelGGL(mv_loss_combine_kernel<FX>, dim3((unsigned)((total + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(mv_loss_combine_kernel, dim3((unsigned)((total + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream,
                      cam, inv_cam, sse_part, reinterpret_cast<const float4 *>(grad_spheres_part), Rm, d2m_part,
                      grad_d2m_part, Rd, B, V, J, is_mv, (float)wm, (float)wd, loss, grad_joints);
   return (int)hipGetLastError();
-}
-}  // namespace
-
-extern "C" int shr_mv_loss_combine(const float *cam, const float *inv_cam, const float *sse_part,
-                                   const float *grad_spheres_part, int Rm, const float *d2m_part,
-                                   const float *grad_d2m_part, int Rd, int B, int V, int J, int H, int W, int is_mv,
-                                   float d2m_weight, float *loss, float *grad_joints, void *stream) {
-  return launch_combine<false>(cam, inv_cam, sse_part, grad_spheres_part, Rm, d2m_part, grad_d2m_part, Rd, B, V, J, H, W,
-                               is_mv, d2m_weight, loss, grad_joints, stream);
-}
-
-extern "C" int shr_mv_loss_combine_fx(const float *cam, const float *inv_cam, const float *sse_part,
-                                      const float *grad_spheres_part, int Rm, const long long *d2m_loss_fx,
-                                      const long long *d2m_grad_fx, int B, int V, int J, int H, int W, int is_mv,
-                                      float d2m_weight, float *loss, float *grad_joints, void *stream) {
-  return launch_combine<true>(cam, inv_cam, sse_part, grad_spheres_part, Rm, d2m_loss_fx, d2m_grad_fx, Rm, B, V, J, H, W,
-                              is_mv, d2m_weight, loss, grad_joints, stream);
 }
 
 extern "C" int shr_mutual_project_fwd(const float *cam, const float *inv_cam, const float *joints,

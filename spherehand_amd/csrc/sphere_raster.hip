@@ -22,7 +22,6 @@ struct Tuning {
   int fwd_zbuf_bytes = 0;               // forward z-buffer bytes per workgroup; 0 = by launch size (launch_zbuf_fwd_t)
   int persistent = 1;                   // 0: one workgroup per crop; 1: persistent workgroups when N exceeds the device; > 1: that many
   int run_table = -1;                   // whole-crop workgroups start their runs from an LDS table: -1 = when it fits, 0 = never
-  int mse_d2m_k = 0;                    // fused data->model search, points per lane: 0 = default, 2 or 4
 } g_tune;
 
 constexpr int kMaxLds = 160 * 1024;
@@ -224,7 +223,7 @@ extern "C" int shr_set_tuning(int key, int value) {
     case SHR_TUNE_FWD_ZBUF_BYTES: if (value < 0) return SHR_EINVAL; g_tune.fwd_zbuf_bytes = value; return SHR_OK;
     case SHR_TUNE_PERSISTENT: if (value < 0) return SHR_EINVAL; g_tune.persistent = value; return SHR_OK;
     case SHR_TUNE_FWD_RUN_TABLE: if (value < -1 || value > 1) return SHR_EINVAL; g_tune.run_table = value; return SHR_OK;
-    case SHR_TUNE_MSE_D2M_K: if (value != 0 && value != 1 && value != 2 && value != 4) return SHR_EINVAL; g_tune.mse_d2m_k = value; return SHR_OK;
+    case SHR_TUNE_D2M_TILED: return d2m_set_tiled(value);
     case SHR_TUNE_D2M_WAVES: return d2m_set_waves(value);
     case SHR_TUNE_D2M_BAND_UNITS: return d2m_set_band_units(value);
     case SHR_TUNE_FWD_SHARES:
@@ -346,28 +345,9 @@ extern "C" int shr_sphere_raster_mse_regions(int H, int W) {
   return rows > 0 ? (H + rows - 1) / rows : 0;
 }
 
-namespace {
-constexpr int kD2mMinZbufBytes = 2048 + 4 * 72 * 8;   // sphere_zbuf.h: kD2mHead + one group of 256 entries
-
-// Tiles of the fused data->model search's queue (sphere_zbuf.h): a wave holds four consecutive 256-pixel units = 1024 / W
-// rows of the region (a band); SB bands x one column block of 2^cbs pixels make a tile of about 16 x 16 pixels, and the
-// tiles of a region -- ceil(16 / SB) x NC of them -- are at most 64 (one per lane of the prefix) with at most 16 column
-// blocks (a wave's counter row).  Returns cbs | SB << 8 | NC << 16.
-int d2m_geometry(int W) {
-  int sb = W / 64;
-  if (sb < 1) sb = 1;
-  if (sb > 16) sb = 16;
-  const int nsb = (16 + sb - 1) / sb;
-  int cbs = 4;
-  while (((W + (1 << cbs) - 1) >> cbs) > 16 || nsb * ((W + (1 << cbs) - 1) >> cbs) > 64) cbs++;
-  const int nc = (W + (1 << cbs) - 1) >> cbs;
-  return cbs | (sb << 8) | (nc << 16);
-}
-
-// The fused kernel, with or without the data->model term (d2m_k = 0: without; 2 / 4: points per lane of its search).
-int launch_mse(const float *spheres, int N, int J, int H, int W, const float *target, const int32_t *target_index,
-               float *depth, float *sse_partial, float *grad_spheres_partial, int d2m_k, int d2m_diag_v,
-               long long *d2m_loss, long long *d2m_grad, void *stream) {
+extern "C" int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W, const float *target,
+                                     const int32_t *target_index, float *depth, float *sse_partial,
+                                     float *grad_spheres_partial, void *stream) {
   using namespace shr;
   if (N == 0) return SHR_OK;
   if (!spheres || !target || !sse_partial || !grad_spheres_partial || N < 0 || J <= 0 || H <= 0 || W <= 0)
@@ -377,10 +357,6 @@ int launch_mse(const float *spheres, int N, int J, int H, int W, const float *ta
     return SHR_EINVAL;   // 16-byte rows only: compose shr_sphere_raster_fwd / _bwd otherwise
   const int rows = mse_rows(H, W);
   if (rows <= 0 || (H + rows - 1) / rows > 65535) return SHR_ETOOLARGE;
-  if (d2m_k && (!d2m_loss || !d2m_grad || d2m_diag_v < 0 || (((uintptr_t)d2m_loss | (uintptr_t)d2m_grad) & 7u) != 0))
-    return SHR_EINVAL;
-  if (d2m_k && ((long long)rows * W > 16384 || H > 65535)) return SHR_ETOOLARGE;   // a region's 64 units sit in registers
-  if (d2m_k && (long long)rows * (W + kRowPad) * 8 < kD2mMinZbufBytes) return SHR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const size_t part = (size_t)kZWaves * J * 16;   // [wave][J] partial sums
   const size_t lds = kHdrBytes + part + (size_t)rows * (W + kRowPad) * 8;
@@ -388,86 +364,39 @@ int launch_mse(const float *spheres, int N, int J, int H, int W, const float *ta
   // first read follows an index load -- so it stays at one workgroup per crop and region: PERSIST = false)
   const int regions = (H + rows - 1) / rows;
   dim3 grid((unsigned)N, (unsigned)regions);
-  static AttrDone attr[3][4];
+  static AttrDone attr_a, attr_b, attr_c;
   // Two workgroups per CU when the launch has them (forward with owner map, 1152 crops @256x256: 157 -> 95 us with the
   // box z-buffer at half of the LDS, tools/exp_fwd256.py): the box variant, 64 VGPRs, zcells cells of z-buffer.
   const size_t half = kMaxLds / 2;
   const bool box_ok = is_pow2(W) && is_pow2(H) && W >= 32 && lds > half && (long long)N * regions >= 2LL * num_cus() &&
                       half >= kHdrBytes + part + 8 * (size_t)max_box_pitch(W) * 8;
   const int box = g_tune.mse_box < 0 ? (box_ok ? 1 : 0) : (g_tune.mse_box && is_pow2(W) && is_pow2(H) && W >= 32);
-  const float4 *sp = reinterpret_cast<const float4 *>(spheres);
-  float4 *gsp = reinterpret_cast<float4 *>(grad_spheres_partial);
-  const int w4s = log2_if_pow2(W / 4);
-  const AxisK axk = make_axis_k(W, H);
-  const int geom = d2m_geometry(W);
-  const int ki = d2m_k == 0 ? 0 : (d2m_k == 1 ? 3 : (d2m_k == 2 ? 1 : 2));
-#define MSE_LAUNCH(KERNEL, LDS, ...)                                                             \
-  do {                                                                                           \
-    auto k = KERNEL;                                                                             \
-    const hipError_t e = allow_big_lds(k, &attr[vi][ki]);                                        \
-    if (e != hipSuccess) return (int)e;                                                          \
-    hipLaunchKernelGGL(k, grid, dim3(1024), LDS, s, __VA_ARGS__);                                \
-  } while (0)
   if (box) {
-    const int vi = 0;
     size_t blds = g_tune.mse_box > 1 ? (size_t)g_tune.mse_box : half;
-    size_t least = kHdrBytes + part + 8 * (size_t)max_box_pitch(W) * 8;
-    if (d2m_k && least < kHdrBytes + part + kD2mMinZbufBytes) least = kHdrBytes + part + kD2mMinZbufBytes;   // tile counters + one group of the queue
+    const size_t least = kHdrBytes + part + 8 * (size_t)max_box_pitch(W) * 8;
     if (blds < least) blds = least;
     if (blds > (size_t)kMaxLds) blds = kMaxLds;
     const int zcells = (int)((blds - kHdrBytes - part) / 8);
-#define BOX_ARGS sp, N, J, H, W, target, target_index, rows, w4s, zcells, g_tune.fwd_shares, g_tune.bwd_shares, depth, \
-                 sse_partial, gsp, axk, d2m_loss, d2m_grad, d2m_diag_v, geom
-    if (d2m_k == 4) MSE_LAUNCH((sphere_zbuf_mse_box_kernel<true, 4>), blds, BOX_ARGS);
-    else if (d2m_k == 2) MSE_LAUNCH((sphere_zbuf_mse_box_kernel<true, 2>), blds, BOX_ARGS);
-    else if (d2m_k == 1) MSE_LAUNCH((sphere_zbuf_mse_box_kernel<true, 1>), blds, BOX_ARGS);
-    else MSE_LAUNCH((sphere_zbuf_mse_box_kernel<true, 0>), blds, BOX_ARGS);
-#undef BOX_ARGS
+    auto k = sphere_zbuf_mse_box_kernel<true>;
+    const hipError_t e = allow_big_lds(k, &attr_c);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, grid, dim3(1024), blds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
+                       target_index, rows, log2_if_pow2(W / 4), zcells, g_tune.fwd_shares, g_tune.bwd_shares, depth,
+                       sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H));
+  } else if (is_pow2(W) && is_pow2(H)) {
+    auto k = sphere_zbuf_mse_kernel<true, false>;
+    const hipError_t e = allow_big_lds(k, &attr_a);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
+                       target_index, rows, log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, depth, sse_partial,
+                       reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H));
   } else {
-#define FULL_ARGS sp, N, J, H, W, target, target_index, rows, w4s, g_tune.fwd_shares, g_tune.bwd_shares, depth, \
-                  sse_partial, gsp, axk, d2m_loss, d2m_grad, d2m_diag_v, geom
-    if (is_pow2(W) && is_pow2(H)) {
-      const int vi = 1;
-      if (d2m_k == 4) MSE_LAUNCH((sphere_zbuf_mse_kernel<true, false, 4>), lds, FULL_ARGS);
-      else if (d2m_k == 2) MSE_LAUNCH((sphere_zbuf_mse_kernel<true, false, 2>), lds, FULL_ARGS);
-      else if (d2m_k == 1) MSE_LAUNCH((sphere_zbuf_mse_kernel<true, false, 1>), lds, FULL_ARGS);
-      else MSE_LAUNCH((sphere_zbuf_mse_kernel<true, false, 0>), lds, FULL_ARGS);
-    } else {
-      const int vi = 2;
-      if (d2m_k == 4) MSE_LAUNCH((sphere_zbuf_mse_kernel<false, false, 4>), lds, FULL_ARGS);
-      else if (d2m_k == 2) MSE_LAUNCH((sphere_zbuf_mse_kernel<false, false, 2>), lds, FULL_ARGS);
-      else if (d2m_k == 1) MSE_LAUNCH((sphere_zbuf_mse_kernel<false, false, 1>), lds, FULL_ARGS);
-      else MSE_LAUNCH((sphere_zbuf_mse_kernel<false, false, 0>), lds, FULL_ARGS);
-    }
-#undef FULL_ARGS
+    auto k = sphere_zbuf_mse_kernel<false, false>;
+    const hipError_t e = allow_big_lds(k, &attr_b);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
+                       target_index, rows, log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, depth, sse_partial,
+                       reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H));
   }
-#undef MSE_LAUNCH
   return (int)hipGetLastError();
-}
-}  // namespace
-
-extern "C" int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W, const float *target,
-                                     const int32_t *target_index, float *depth, float *sse_partial,
-                                     float *grad_spheres_partial, void *stream) {
-  return launch_mse(spheres, N, J, H, W, target, target_index, depth, sse_partial, grad_spheres_partial, 0, 0, nullptr,
-                    nullptr, stream);
-}
-
-extern "C" int shr_sphere_raster_mse_d2m_supported(int H, int W) {
-  const int rows = mse_rows(H, W);
-  // (a region's z-buffer LDS holds the tile counters and at least one group of the point queue first)
-  return rows > 0 && (W % 4) == 0 && (long long)rows * W <= 16384 && H <= 65535 &&
-         (long long)rows * (W + shr::kRowPad) * 8 >= kD2mMinZbufBytes;
-}
-
-extern "C" int shr_sphere_raster_mse_d2m(const float *spheres, int N, int J, int H, int W, const float *target,
-                                         const int32_t *target_index, float *depth, float *sse_partial,
-                                         float *grad_spheres_partial, int d2m_diag_v, long long *d2m_loss_fx,
-                                         long long *d2m_grad_fx, void *stream) {
-  if (!shr_sphere_raster_mse_d2m_supported(H, W)) return SHR_ETOOLARGE;
-  // points per lane of the search: 4 amortises a sphere's record over 256 points; 2 halves a group (finer balance over
-  // the sixteen waves, tighter strips) at twice the record reads -- measured: see DESIGN 4.2b
-  const int k = g_tune.mse_d2m_k ? g_tune.mse_d2m_k : 4;
-  return launch_mse(spheres, N, J, H, W, target, target_index, depth, sse_partial, grad_spheres_partial, k, d2m_diag_v,
-                    d2m_loss_fx, d2m_grad_fx, stream);
 }

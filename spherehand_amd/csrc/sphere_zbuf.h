@@ -44,7 +44,6 @@
 #pragma once
 #include <type_traits>
 #include "sphere_tile.h"
-#include "d2m_search.h"
 
 namespace shr {
 
@@ -1385,39 +1384,12 @@ constexpr int kSphereCostMse = 28;
 // (BOX: the z-buffer covers the touched box only, `zcells` cells, as in the forward -- half of a CU's LDS and, with
 // 64 VGPRs, two workgroups per CU; the rows a box has beyond it go through the tile code of the general path, which
 // adds to the same partial sums.  Needs a power-of-two image at least 32 wide: tile rows are then whole units.)
-//
-// D2M = K > 0 (round 4): the data->model term of the same (crop, observed image) pairing
-// (mesh/multiview_utility.py:103-105, mesh/render.py:123-142) is evaluated by this workgroup as well, IN FRONT of the
-// scan conversion, from the observed pixels it has loaded anyway (registers `tpre`): no second launch, and the
-// z-buffer's LDS -- not in use yet -- holds the points:
-//   count    every wave counts the foreground pixels (depth <= 99) of its four CONSECUTIVE units (one band of the
-//            region) per column block of 2^cbs pixels, in a private row of LDS counters;
-//   place    after the first barrier a prefix over the TILES -- (group of SB bands) x (column block), ~16 x 16 pixels,
-//            visited boustrophedon -- gives every (wave, column block) its range of the queue; each foreground pixel
-//            is written there as (v << 16 | u, z): the queue is sorted by tile;
-//   search   the waves draw groups of 64 K consecutive entries from an LDS counter (integer sums: order-independent)
-//            and run d2m_search.h on them with the group's own x-y bounding box as the bound -- one or two tiles, where
-//            the stand-alone kernel's pixel-order groups are strips across the whole hand: ~8 instead of ~19 spheres
-//            evaluated per point.  Same per-point code, same fixed-point terms as data_to_model_kernel.
-// The sums go out as 64-bit INTEGERS per (crop, region) -- d2m_loss[slot] in 2^-20 mm (LLONG_MIN: NaN),
-// d2m_grad[slot][J][3] in 2^-26 -- so that the caller's sum over the regions is exact and does not depend on how a
-// crop was cut; then the partial-sum rows are re-zeroed, the z-buffer initialised, the observed pixels REQUESTED AGAIN
-// (the search needs their sixteen registers; the lines were read microseconds ago by this CU), one more barrier, and
-// the kernel continues as before.  A queue smaller than the region's foreground takes several place / search rounds.
-// d2m_diag_v = V > 0: only crops n with (n / V) % V == n % V (the same-view pairs of is_mv = False,
-// mesh/multiview_utility.py:115-127) are searched; the others' d2m outputs stay unwritten.
-// d2m_geom = cbs | SB << 8 | NC << 16 (launcher: d2m_geometry()).  Needs every unit of a region in `tpre`: at most 64
-// units = 16384 pixels per region.
-template <bool POW2, bool PERSIST, bool BOX, int D2M = 0>
+template <bool POW2, bool PERSIST, bool BOX>
 __device__ __forceinline__ void
 sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_, const float *__restrict__ target,
                      const int *__restrict__ target_index, float *__restrict__ depth,
                      float *__restrict__ sse_out, float4 *__restrict__ grad_out, int rows_per_region_,
-                     int w4_shift_, int shares_fwd, int shares_bwd, int zcells_, AxisK axk,
-                     long long *__restrict__ d2m_loss = nullptr, long long *__restrict__ d2m_grad = nullptr,
-                     int d2m_diag_v = 0, int d2m_geom = 0) {
-  static_assert(D2M == 0 || D2M == 1 || D2M == 2 || D2M == 4, "points per lane of the fused data->model search");
-  static_assert(D2M == 0 || !PERSIST, "the d2m scalars live where a persistent workgroup parks the next crop's records");
+                     int w4_shift_, int shares_fwd, int shares_bwd, int zcells_, AxisK axk) {
   using Key = unsigned long long;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
@@ -1462,15 +1434,14 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   float *out = depth ? depth + (size_t)n * H * W + (size_t)r0 * W : nullptr;
   if (BOX) asm volatile("" : "+v"(ax.mul), "+v"(ay.mul), "+v"(ax.half), "+v"(ay.half));   // (SGPR budget, see the forward)
   if (tid < kZWaves * J) s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // (16 waves x J <= 64 spheres)
-  auto init_zbuf = [&]() {  // background everywhere (BOX: every cell a box of this region can use)
+  {  // background everywhere (BOX: every cell a box of this region can use)
     const Key bg = (Key)background_cell();
     const int ninit = BOX ? min(zcells, rh * max_box_pitch(W)) : rh * LW;
     const int nvec = ninit >> 1;
     const ulonglong2 v = make_ulonglong2(bg, bg);
     for (int i = tid; i < nvec; i += 1024) reinterpret_cast<ulonglong2 *>(zbuf)[i] = v;
     if (tid == 0 && (ninit & 1)) zbuf[ninit - 1] = bg;
-  };
-  if (!D2M) init_zbuf();   // (D2M: the z-buffer's LDS is the point queue first; initialised after the search)
+  }
 
   const int w4 = W >> 2;
   const int nchunk = rh * w4;
@@ -1481,18 +1452,9 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   // wave whatever the spheres are): requested now, it arrives under the list building and the scan
   // conversion instead of costing the convert pass one HBM round trip per unit.
   constexpr int kTgtAhead = 4;   // a 128x128 crop / a 64-row region of a 256-wide one: 64 units, four per wave
-  // (D2M: a wave's units are CONSECUTIVE -- the search's strip bounds want neighbouring rows together)
-  auto unit_of = [&](int k) { return D2M ? (wave_s << 2) + k : wave_s + (k << 4); };
   float4 tpre[kTgtAhead];
 #pragma unroll
-  for (int k = 0; k < kTgtAhead; k++) tpre[k] = tgt4[min((unit_of(k) << 6) + lane, nchunk - 1)];
-  // D2M scalars (where a persistent workgroup would park the next crop's records): [0] next group, [1] NaN, [2] odd
-  // table, [4..5] loss (u64); the per-wave tile counters sit at the head of the z-buffer's LDS, the queue behind them
-  int *s_d2m = reinterpret_cast<int *>(smem + kOffNext);
-  int *s_wcnt = reinterpret_cast<int *>(zbuf);                 // [16 waves][16 column blocks] counts
-  int *s_wcur = s_wcnt + kZWaves * 16;                         // ... and placement cursors
-  constexpr int kD2mHead = 2 * kZWaves * 16 * (int)sizeof(int);
-  const bool d2m_on = D2M != 0 && (d2m_diag_v == 0 || (n / d2m_diag_v) % d2m_diag_v == n % d2m_diag_v);   // workgroup-uniform
+  for (int k = 0; k < kTgtAhead; k++) tpre[k] = tgt4[min(((wave_s + (k << 4)) << 6) + lane, nchunk - 1)];
   int ua = 0, ub = nunits;
   if (bg_wave) {   // rows no sphere touches: depth = background, stored while wave 0 builds the list
     int cv0, cv1, cu0 = 0, cu1 = W - 1;
@@ -1540,175 +1502,11 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
       s_flag[1] = total;
       s_flag[12] = behind != 0ull;   // only a sphere centred behind the background can hit at exactly 100.0 (tie_owner)
     }
-    if (D2M) {
-      const float inf = __builtin_inff();
-      const bool odd = valid && (!(fabsf(sph.x) < inf) || !(fabsf(sph.y) < inf) || !(fabsf(sph.z) < inf) || !(fabsf(sph.w) < inf));
-      const bool any = __ballot(odd) != 0ull;
-      if (lane == 0) { s_d2m[0] = 0; s_d2m[1] = 0; s_d2m[2] = any; s_d2m[4] = 0; s_d2m[5] = 0; }
-    }
-  }
-  // ---- D2M: count this wave's foreground pixels per column block (mesh/render.py:138: background = d > 99) ------
-  const int cbs = d2m_geom & 0xff, SB = (d2m_geom >> 8) & 0xff, NC = (d2m_geom >> 16) & 0xff;
-  // (k is a RUN-TIME, wave-uniform index and the loops over the units are not unrolled: four units' worth of
-  // temporaries side by side did not fit the 64 registers of the two-per-CU variant)
-  auto d2m_unit = [&](int k, const float4 t0, const float4 t1, const float4 t2, const float4 t3, bool fg[4], float tz[4], int &v, int &x) {   // (pixels past the region's end do not exist)
-    static_assert(kTgtAhead == 4, "the select chain below names four units");
-    // (selects on OPAQUE wave-uniform conditions: written as `tpre[k]` -- or as a chain on k itself -- the compiler
-    // moves the array to scratch memory and indexes it there)
-    int k1 = rfl((int)(k == 1)), k2 = rfl((int)(k == 2)), k3 = rfl((int)(k == 3));
-    asm volatile("" : "+s"(k1), "+s"(k2), "+s"(k3));
-    float4 t = t0;
-    t.x = k1 ? t1.x : t.x; t.y = k1 ? t1.y : t.y; t.z = k1 ? t1.z : t.z; t.w = k1 ? t1.w : t.w;
-    t.x = k2 ? t2.x : t.x; t.y = k2 ? t2.y : t.y; t.z = k2 ? t2.z : t.z; t.w = k2 ? t2.w : t.w;
-    t.x = k3 ? t3.x : t.x; t.y = k3 ? t3.y : t.y; t.z = k3 ? t3.z : t.z; t.w = k3 ? t3.w : t.w;
-    const int u = unit_of(k), c = (u << 6) + lane;
-    const bool in = u < nunits && c < nchunk;
-    if (POW2 || w4_shift >= 0) { v = c >> w4_shift; x = (c & (w4 - 1)) << 2; }
-    else { v = c / w4; x = (c - v * w4) << 2; }
-    tz[0] = t.x; tz[1] = t.y; tz[2] = t.z; tz[3] = t.w;
-#pragma unroll
-    for (int i = 0; i < 4; i++) fg[i] = in && !(tz[i] > 99.0f);
-  };
-  if (D2M && d2m_on) {
-    if (lane < 16) s_wcnt[wave_s * 16 + lane] = 0;   // (this wave's row: its own LDS operations are ordered)
-#pragma unroll 1
-    for (int k = 0; k < kTgtAhead; k++) {
-      bool fg[4];
-      float tz[4];
-      int v, x;
-      d2m_unit(k, tpre[0], tpre[1], tpre[2], tpre[3], fg, tz, v, x);
-      const int cnt = (int)fg[0] + (int)fg[1] + (int)fg[2] + (int)fg[3];
-      if (cnt) atomicAdd(&s_wcnt[wave_s * 16 + (x >> cbs)], cnt);
-    }
   }
   __syncthreads();
   if (!(wave_s == 0 || bg_wave)) sph = s_sph[lane];
   float4 sph_next = make_float4(0.f, 0.f, 0.f, 0.f);
   if (pf_wave && has_next && valid) sph_next = spheres[(size_t)(n + crop_step) * J + lane];
-  if (D2M) {
-    if (d2m_on) {
-      constexpr int K = D2M ? D2M : 4, GS = 64 * K, KSH = K == 4 ? 2 : (K == 2 ? 1 : 0), RP = 64 + 8, GSTRIDE = K * RP;
-      // ---- tile prefix: lane = position of a tile in boustrophedon order (at most 64 tiles: d2m_geometry) ----------
-      const int nsb = (kZWaves + SB - 1) / SB, ntiles = nsb * NC;
-      const float rnc = __builtin_amdgcn_rcpf((float)NC);
-      int tile_total = 0;
-      {
-        const int sbp = (int)(((float)lane + 0.5f) * rnc), t = lane - sbp * NC;   // ((lane + 1/2) / NC is >= 1/32 from an integer)
-        const int tcp = (sbp & 1) ? NC - 1 - t : t;
-        if (lane < ntiles)
-          for (int w = sbp * SB; w < min(kZWaves, sbp * SB + SB); w++) tile_total += s_wcnt[w * 16 + tcp];
-      }
-      int incl = tile_total;
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);  // row_shr:1 ... (build_work_list's scan)
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
-      {
-        const int r0s = rl(incl, 15), r1s = rl(incl, 31), r2s = rl(incl, 47);
-        const int row = lane >> 4;
-        incl += (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
-      }
-      const int T = rl(incl, 63), excl = incl - tile_total;
-      const int my_sb = (int)(((float)wave_s + 0.5f) * __builtin_amdgcn_rcpf((float)SB));
-      uint2 *q = reinterpret_cast<uint2 *>(reinterpret_cast<unsigned char *>(zbuf) + kD2mHead);
-      const int zbytes = (BOX ? zcells : rh * LW) * (int)sizeof(Key) - kD2mHead;
-      const int cap = (zbytes / (GSTRIDE * 8)) * GS;          // entries per round (>= any one tile: the launcher's budget)
-      unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_part);   // zeroed above with the partial sums
-      D2mCtx ctx;
-      ctx.s_c = s_sph; ctx.cj = valid ? sph : make_float4(0.f, 0.f, 0.f, 0.f);
-      ctx.all = J >= 64 ? ~0ull : ((1ull << J) - 1ull);
-      ctx.table_odd = s_d2m[2] != 0; ctx.J = J; ctx.lane = lane; ctx.ax = ax; ctx.ay = ay;
-      ctx.s_acc = s_acc; ctx.acc_stride = 4 * J + 2; ctx.s_nan = s_d2m + 1;
-      long long loss_fx = 0;
-      // A ROUND = the longest run of whole tiles [ta, tb) (boustrophedon positions) that fits the queue -- all of them
-      // unless the LDS budget was squeezed.  Placing a round: every foreground pixel of those tiles goes to
-      //   (tile offset - the round's start) + (the tile's pixels in earlier waves) + (its rank in this wave),
-      // the rank drawn from the wave's own cursor row (any order inside a (wave, tile) range is a permutation of it).
-      auto round_end = [&](int ta, int start) {
-        return ta + __builtin_popcountll(__ballot(lane >= ta && lane < ntiles && incl - start <= cap));
-      };
-      auto place = [&](int ta, int tb, int start) {
-        if (lane < 16) s_wcur[wave_s * 16 + lane] = 0;
-#pragma unroll 1
-        for (int k = 0; k < kTgtAhead; k++) {
-          bool fg[4];
-          float tz[4];
-          int v, x;
-          d2m_unit(k, tpre[0], tpre[1], tpre[2], tpre[3], fg, tz, v, x);
-          const int cnt = (int)fg[0] + (int)fg[1] + (int)fg[2] + (int)fg[3], tc = x >> cbs;
-          const int pos = my_sb * NC + ((my_sb & 1) ? NC - 1 - tc : tc);
-          int p = __builtin_amdgcn_ds_bpermute(pos << 2, excl) - start;
-          for (int w = my_sb * SB; w < wave_s; w++) p += s_wcnt[w * 16 + tc];
-          if (cnt && pos >= ta && pos < tb) {
-            p += atomicAdd(&s_wcur[wave_s * 16 + tc], cnt);
-            const unsigned vu = ((unsigned)(v + r0) << 16) | (unsigned)x;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-              if (fg[c]) {
-                const int g = p >> (6 + KSH), e = p & (GS - 1);
-                q[g * GSTRIDE + (e & (K - 1)) * RP + (e >> KSH)] = make_uint2(vu + (unsigned)c, __float_as_uint(tz[c]));
-                p++;
-              }
-            }
-          }
-        }
-      };
-      int ta = 0, start = 0, tb = round_end(0, 0);
-      while (T > 0) {
-        place(ta, tb, start);
-        __syncthreads();
-        const int cnt_round = (tb >= ntiles ? T : rl(excl, min(tb, 63))) - start, G = (cnt_round + GS - 1) >> (6 + KSH);
-        for (;;) {
-          int g = 0;
-          if (lane == 0) g = atomicAdd(&s_d2m[0], 1);
-          g = rfl(g);
-          if (g >= G) break;
-          const uint2 *qg = q + g * GSTRIDE;
-#ifndef EXP_NO_SEARCH
-          d2m_search<K, true, true>(ctx, [&](int idx) { return qg[(idx & (K - 1)) * RP + (idx >> KSH)]; },
-                                    min(GS, cnt_round - (g << (6 + KSH))), loss_fx);
-#else
-          loss_fx += qg[lane].x;
-#endif
-        }
-        if (tb >= ntiles) break;
-        // another round (a squeezed queue only): the queue is rewritten, the group counter restarts, and the observed
-        // pixels come back from memory -- their registers were the search's
-        __syncthreads();
-        if (tid == 0) s_d2m[0] = 0;
-        ta = tb;
-        start += cnt_round;
-        tb = round_end(ta, start);
-        const float4 *tgt4r = tgt4;
-        asm volatile("" : "+s"(tgt4r));
-#pragma unroll
-        for (int k = 0; k < kTgtAhead; k++) tpre[k] = tgt4r[min((unit_of(k) << 6) + lane, nchunk - 1)];
-      }
-      if (loss_fx) atomicAdd(reinterpret_cast<unsigned long long *>(s_d2m + 4), (unsigned long long)loss_fx);
-      __syncthreads();
-      const size_t dslot = (size_t)n * gridDim.y + blockIdx.y;
-      if (tid == 0)
-        d2m_loss[dslot] = s_d2m[1] ? (long long)0x8000000000000000ull
-                                   : (long long)*reinterpret_cast<unsigned long long *>(s_d2m + 4);
-      if (tid < J * 3) {
-        const int j = tid / 3, c = tid - j * 3;
-        long long t = 0;
-#pragma unroll
-        for (int k = 0; k < kD2mTables; k++) t += (long long)s_acc[k * (4 * J + 2) + j * 4 + c];
-        d2m_grad[dslot * J * 3 + tid] = t;
-      }
-      __syncthreads();             // the tables are read: their LDS becomes the partial sums again
-      if (tid < kZWaves * J) s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef EXP_RELOAD
-      const float4 *tgt4b = tgt4;
-      asm volatile("" : "+s"(tgt4b));
-#pragma unroll
-      for (int k = 0; k < kTgtAhead; k++) tpre[k] = tgt4b[min((unit_of(k) << 6) + lane, nchunk - 1)];
-#endif
-    }
-    init_zbuf();
-    __syncthreads();
-  }
   const bool general = s_flag[0] != 0;
   const bool may_tie = rfl(s_flag[12]) != 0;
   ua = rfl(s_flag[2]);
@@ -1797,12 +1595,11 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
     };
 #pragma unroll
     for (int k = 0; k < kTgtAhead; k++)
-      if (unit_of(k) < nunits) convert_unit(unit_of(k), tpre[k]);
-    if (!D2M)      // (D2M: at most 64 units per region, all of them in tpre)
-      for (int u = wave_s + (kTgtAhead << 4); u < nunits; u += kZWaves) {
-        const int c = (u << 6) + lane;
-        convert_unit(u, tgt4[min(c, nchunk - 1)]);
-      }
+      if (wave_s + (k << 4) < nunits) convert_unit(wave_s + (k << 4), tpre[k]);
+    for (int u = wave_s + (kTgtAhead << 4); u < nunits; u += kZWaves) {
+      const int c = (u << 6) + lane;
+      convert_unit(u, tgt4[min(c, nchunk - 1)]);
+    }
     __syncthreads();
 
     // ---- walk (backward): static slices, per-run DPP sums into the wave's LDS row ------------
@@ -1929,32 +1726,28 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
 // (argument order of the two wrappers: what a wave needs before it requests its records -- and the observed image's
 // index -- comes first, among the 14 argument dwords that are preloaded into SGPRs; the outputs and the axis constants
 // follow and are fetched by an s_load whose wait sits behind those requests)
-template <bool POW2, bool PERSIST, int D2M = 0>
+template <bool POW2, bool PERSIST>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J, int H, int W, const float *__restrict__ target,
                        const int *__restrict__ target_index, int rows_per_region, int w4_shift, int shares_fwd,
                        int shares_bwd, float *__restrict__ depth, float *__restrict__ sse_out,
-                       float4 *__restrict__ grad_out, AxisK axk, long long *__restrict__ d2m_loss,
-                       long long *__restrict__ d2m_grad, int d2m_diag_v, int d2m_geom) {
-  sphere_zbuf_mse_body<POW2, PERSIST, false, D2M>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
-                                                  rows_per_region, w4_shift, shares_fwd, shares_bwd, 0, axk, d2m_loss,
-                                                  d2m_grad, d2m_diag_v, d2m_geom);
+                       float4 *__restrict__ grad_out, AxisK axk) {
+  sphere_zbuf_mse_body<POW2, PERSIST, false>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
+                                             rows_per_region, w4_shift, shares_fwd, shares_bwd, 0, axk);
 }
 
 // two of these per CU: eight waves per SIMD, i.e. at most 64 VGPRs -- and few enough SGPRs: left alone the kernel takes
 // 93 (descriptor count) and the second workgroup does not become resident (242 us against 172 with the cap's 78 and 15
 // scalar spills, 1152 crops @256x256)
-template <bool POW2, int D2M = 0>
+template <bool POW2>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sphere_zbuf_mse_box_kernel(const float4 *__restrict__ spheres, int N, int J, int H, int W, const float *__restrict__ target,
                            const int *__restrict__ target_index, int rows_per_region, int w4_shift, int zcells,
                            int shares_fwd, int shares_bwd, float *__restrict__ depth, float *__restrict__ sse_out,
-                           float4 *__restrict__ grad_out, AxisK axk, long long *__restrict__ d2m_loss,
-                           long long *__restrict__ d2m_grad, int d2m_diag_v, int d2m_geom) {
+                           float4 *__restrict__ grad_out, AxisK axk) {
   static_assert(POW2, "box variant: power-of-two images");
-  sphere_zbuf_mse_body<POW2, false, true, D2M>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
-                                               rows_per_region, w4_shift, shares_fwd, shares_bwd, zcells, axk, d2m_loss,
-                                               d2m_grad, d2m_diag_v, d2m_geom);
+  sphere_zbuf_mse_body<POW2, false, true>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
+                                          rows_per_region, w4_shift, shares_fwd, shares_bwd, zcells, axk);
 }
 
 }  // namespace shr

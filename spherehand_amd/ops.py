@@ -89,7 +89,7 @@ def sphere_raster_bwd(spheres, grad_depth, argmin=None):
 
 TUNE_FWD_LDS_BYTES, TUNE_FWD_OWNER_LDS_BYTES, TUNE_BWD_LDS_BYTES, TUNE_FORCE_GENERAL, TUNE_FWD_WAVES = 1, 2, 3, 4, 5
 TUNE_FWD_SHARES, TUNE_BWD_SHARES, TUNE_D2M_WAVES, TUNE_D2M_BAND_UNITS, TUNE_PERSISTENT, TUNE_FWD_ZBUF_BYTES = 6, 7, 8, 9, 10, 11
-TUNE_BWD_WAVES, TUNE_MSE_BOX, TUNE_FWD_RUN_TABLE, TUNE_MSE_D2M_K = 12, 13, 14, 15
+TUNE_BWD_WAVES, TUNE_MSE_BOX, TUNE_FWD_RUN_TABLE, TUNE_D2M_TILED = 12, 13, 14, 15
 
 
 def set_tuning(key, value):
@@ -165,56 +165,6 @@ def sphere_raster_mse(spheres, target, target_index=None, want_depth=True):
     return depth, sse, grad
 
 
-D2M_LOSS_SCALE, D2M_GRAD_SCALE = 2.0 ** -20, 2.0 ** -26   # units of the fused kernel's fixed-point sums
-D2M_NAN = -2 ** 63
-
-
-def sphere_raster_mse_d2m_supported(spheres, target, H, W):
-    """True when shr_sphere_raster_mse_d2m takes these buffers (fused kernel + a region of at most 16384 pixels)."""
-    return sphere_raster_mse_supported(spheres, target, H, W) and \
-        bool(_lib.lib().shr_sphere_raster_mse_d2m_supported(int(H), int(W)))
-
-
-def sphere_raster_mse_d2m(spheres, target, target_index=None, want_depth=True, diag_v=0, raw=False):
-    """The fused render-and-compare launch with the data->model term of the same (crop, observed image) pairing:
-    -> (depth [N,H,W] or None, sse [N], grad_spheres [N,J,4], d2m_loss_sum [N], d2m_grad_centres [N,J,3]).
-    The d2m sums are the kernel's 64-bit fixed-point totals over the regions, converted once (the floats
-    data_to_model() returns for a whole crop); raw=True returns the integer partials [N,R], [N,R,J,3] instead.
-    diag_v = V > 0: only crops n with (n // V) % V == n % V carry a d2m term (the others' entries are undefined)."""
-    _check_input(spheres, "spheres")
-    _check_input(target, "target")
-    if spheres.dim() != 3 or spheres.shape[2] != 4 or target.dim() != 3:
-        raise RuntimeError("spheres must be [N,J,4] and target [M,H,W]")
-    N, J, _ = spheres.shape
-    H, W = target.shape[1:]
-    if target_index is None and target.shape[0] != N:
-        raise RuntimeError("target must hold one image per crop unless target_index is given")
-    if target_index is not None:
-        _check_index(target_index, N, target.shape[0], "target_index")
-    lib = _lib.lib()
-    R = lib.shr_sphere_raster_mse_regions(int(H), int(W))
-    if R <= 0 or not lib.shr_sphere_raster_mse_d2m_supported(int(H), int(W)):
-        raise RuntimeError("image too large for the fused render-and-compare + data->model kernel")
-    dev = spheres.device
-    with _on(dev):
-        depth = torch.empty((N, H, W), dtype=torch.float32, device=dev) if want_depth else None
-        sse = torch.empty((N, R), dtype=torch.float32, device=dev)
-        grad = torch.empty((N, R, J, 4), dtype=torch.float32, device=dev)
-        dl = torch.empty((N, R), dtype=torch.int64, device=dev)
-        dg = torch.empty((N, R, J, 3), dtype=torch.int64, device=dev)
-        _lib.check(lib.shr_sphere_raster_mse_d2m(_ptr(spheres), N, J, H, W, _ptr(target), _ptr(target_index), _ptr(depth),
-                                                 _ptr(sse), _ptr(grad), int(diag_v), _ptr(dl), _ptr(dg), _stream()),
-                   "shr_sphere_raster_mse_d2m")
-        sse, grad = (sse.sum(1), grad.sum(1)) if R > 1 else (sse.view(N), grad.view(N, J, 4))
-        if raw:
-            return depth, sse, grad, dl, dg
-        nan = (dl == D2M_NAN).any(1)
-        loss = (dl.sum(1).double() * D2M_LOSS_SCALE).float()
-        loss = torch.where(nan, torch.full_like(loss, float("nan")), loss)
-        gcen = (dg.sum(1).double() * D2M_GRAD_SCALE).float()
-    return depth, sse, grad, loss, gcen
-
-
 class SphereRasterSSE(torch.autograd.Function):
     """(spheres [N,J,4], target [M,H,W], target_index [N] int32 or None) -> (sse [N], depth
     [N,H,W]): per-crop sum of squared differences between the rendered spheres and an
@@ -238,6 +188,9 @@ class SphereRasterSSE(torch.autograd.Function):
         return grad * grad_sse.view(-1, 1, 1), None, None
 
 
+D2M_TWO_STEP = True   # data->model: compact the images once + search the point lists (False: the streaming kernel)
+
+
 def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
     """depth [N,H,W], centres [N,J,3], radii [J] -> loss_sum [N] (and the unit
     gradient d loss_sum[n]/d centres [N,J,3]).  With depth_index [N] int32, depth is
@@ -255,6 +208,10 @@ def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
         raise RuntimeError("radii must have J entries")
     if depth_index is not None:
         _check_index(depth_index, N, depth.shape[0], "depth_index")
+    if D2M_TWO_STEP and N > 0 and d2m_points_supported(depth):
+        # compact every image once, search the point lists (bit-identical sums, see csrc/data_to_model.hip)
+        ws = d2m_compact(depth)
+        return data_to_model_from_points(ws, depth.shape[0], H, W, centres, radii, depth_index, want_grad)
     lib = _lib.lib()
     R = lib.shr_data_to_model_parts(N, int(H), int(W))     # large crops: R partial results per crop, added here
     with _on(depth.device):
@@ -269,6 +226,57 @@ def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
             loss_sum = loss_sum.view(N)
             grad = grad.view(N, J, 3) if want_grad else None
     return (loss_sum, grad) if want_grad else loss_sum
+
+
+def d2m_points_supported(depth):
+    """True when the two-step data->model path takes this image stack [M,H,W] (16-byte rows, at most 4 M pixels)."""
+    return depth.dim() == 3 and depth.shape[0] > 0 and depth.data_ptr() % 16 == 0 and \
+        _lib.lib().shr_data_to_model_points_bytes(int(depth.shape[0]), int(depth.shape[1]), int(depth.shape[2])) > 0
+
+
+def d2m_compact(depth):
+    """depth [M,H,W] -> workspace (uint8 tensor): every image's foreground pixels as tile-sorted point records, for
+    data_to_model_from_points (shr_data_to_model_compact)."""
+    _check_input(depth, "depth")
+    M, H, W = depth.shape
+    lib = _lib.lib()
+    nbytes = lib.shr_data_to_model_points_bytes(int(M), int(H), int(W))
+    if nbytes <= 0 or depth.data_ptr() % 16:
+        raise RuntimeError("image not taken by the two-step data->model path (rows of 4 pixels, 16-byte aligned)")
+    with _on(depth.device):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=depth.device)
+        _lib.check(lib.shr_data_to_model_compact(_ptr(depth), M, H, W, _ptr(ws), _stream()), "shr_data_to_model_compact")
+    return ws
+
+
+def d2m_points_parts(N):
+    """Partial results per crop of the point-list search: ONE.  The regions of an image enter its list in the order
+    their workgroups arrive, so the groups a part would own change from run to run; a crop's total is an integer sum
+    over all its points and does not (bit-reproducible), several float partials added afterwards would only be equal
+    to a rounding.  The launcher gives a crop's workgroup more waves when there are few crops."""
+    return 1
+
+
+def data_to_model_from_points(ws, M, H, W, centres, radii, depth_index=None, want_grad=False, centre_stride=None, parts=None):
+    """The search step: centres [N,J,3] (or the rasterizer's [N,J,4] records with centre_stride=4) against the point
+    lists of images depth_index[n] (or n) -> loss_sum [N] (and grad_centres [N,J,3])."""
+    N, J = centres.shape[0], centres.shape[1]
+    stride = int(centres.shape[2]) if centre_stride is None else centre_stride
+    P = d2m_points_parts(N) if parts is None else parts
+    lib = _lib.lib()
+    with _on(centres.device):
+        loss = torch.empty((N, P), dtype=torch.float32, device=centres.device)
+        grad = torch.empty((N, P, J, 3), dtype=torch.float32, device=centres.device) if want_grad else None
+        _lib.check(lib.shr_data_to_model_from_points(_ptr(ws), int(M), _ptr(depth_index), _ptr(centres), stride, _ptr(radii), N, J,
+                                                     int(H), int(W), P, _ptr(loss), _ptr(grad), _stream()),
+                   "shr_data_to_model_from_points")
+        if P > 1:
+            loss = loss.sum(1)
+            grad = grad.sum(1) if want_grad else None
+        else:
+            loss = loss.view(N)
+            grad = grad.view(N, J, 3) if want_grad else None
+    return (loss, grad) if want_grad else loss
 
 
 class DataToModel(torch.autograd.Function):
@@ -295,20 +303,16 @@ class DataToModel(torch.autograd.Function):
         return None, grad * (grad_out / ctx.count), None, None
 
 
-FUSE_D2M = True    # MutualProjectionLossFused: data->model inside the render-and-compare launch (False: its own kernel)
-
-
 class MutualProjectionLossFused(torch.autograd.Function):
     """(cam, inv_cam [B,V,4,4], joints [B,V,J,3], observed [B*V,H,W], radii [J], index [B*V*V] int32, is_mv) ->
-    (loss, projected depth [B*V*V,H,W]): MutualProjectionLoss (mesh/multiview_utility.py:90-130) as FOUR launches
-    -- view projection, fused render-and-compare WITH the data->model search of the same pairing, and the assembly
-    kernel that weights, adds and pulls both sphere gradients back to the joints (the whole backward is done in the
-    forward: the losses are plain sums) -- plus one scaling in backward.  (FUSE_D2M = False, or an image whose
-    regions exceed the fused search: data->model as its own launch, five in all.)  The unfused wiring needed ~35 small torch launches around the
+    (loss, projected depth [B*V*V,H,W]): MutualProjectionLoss (mesh/multiview_utility.py:90-130) as FIVE launches
+    -- view projection, fused render-and-compare, data->model, and the assembly kernel that weights, adds and
+    pulls both sphere gradients back to the joints (the whole backward is done in the forward: the losses are
+    plain sums) -- plus one scaling in backward.  The unfused wiring needed ~35 small torch launches around the
     same three kernels."""
 
     @staticmethod
-    def forward(ctx, cam, inv_cam, joints, observed, radii, index, diag_index, is_mv, d2m_weight):
+    def forward(ctx, cam, inv_cam, joints, observed, radii, index, diag_index, is_mv, d2m_weight, points_ws=None):
         cam, inv_cam, joints = (t.detach().contiguous().float() for t in (cam, inv_cam, joints))
         observed, radii = observed.contiguous().float(), radii.contiguous().float()
         for t, name in ((cam, "camera_poses"), (inv_cam, "inv_camera_poses"), (joints, "joints"), (observed, "depth_maps"),
@@ -334,37 +338,37 @@ class MutualProjectionLossFused(torch.autograd.Function):
             depth = torch.empty((N, H, W), dtype=torch.float32, device=dev)
             sse = torch.empty((N, Rm), dtype=torch.float32, device=dev)
             gsp = torch.empty((N, Rm, J, 4), dtype=torch.float32, device=dev)
-            loss = torch.empty(1, dtype=torch.float32, device=dev)
-            want = ctx.needs_input_grad[2]
-            gj = torch.empty((B, V, J, 3), dtype=torch.float32, device=dev) if want else None
-            if FUSE_D2M and lib.shr_sphere_raster_mse_d2m_supported(int(H), int(W)) and observed.data_ptr() % 16 == 0:
-                # FOUR launches: the data->model term rides in the render-and-compare kernel (one read of the observed
-                # images for both terms); with is_mv = False only the same-view pairs are searched (diag_v = V)
-                dl = torch.empty((N, Rm), dtype=torch.int64, device=dev)
-                dg = torch.empty((N, Rm, J, 3), dtype=torch.int64, device=dev)
-                _lib.check(lib.shr_sphere_raster_mse_d2m(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), _ptr(depth),
-                                                         _ptr(sse), _ptr(gsp), 0 if is_mv else V, _ptr(dl), _ptr(dg),
-                                                         _stream()), "shr_sphere_raster_mse_d2m")
-                _lib.check(lib.shr_mv_loss_combine_fx(_ptr(cam), _ptr(inv_cam), _ptr(sse), _ptr(gsp), Rm, _ptr(dl), _ptr(dg),
-                                                      B, V, J, H, W, int(bool(is_mv)), float(d2m_weight), _ptr(loss),
-                                                      _ptr(gj), _stream()), "shr_mv_loss_combine_fx")
+            _lib.check(lib.shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), _ptr(depth),
+                                                 _ptr(sse), _ptr(gsp), _stream()), "shr_sphere_raster_mse")
+            if is_mv:
+                E, cen, cidx = N, spheres, index
+            else:                # the V same-view pairs only: their records and observed-image numbers, gathered
+                E = B * V
+                cen = spheres.index_select(0, diag_index)
+                cidx = index.index_select(0, diag_index)
+            if D2M_TWO_STEP and d2m_points_supported(observed):
+                # every observed image is compared with V sphere sets (mesh/multiview_utility.py:99): compacted once
+                # (points_ws: the caller's point lists of these very images, MutualProjectionLoss keeps them while it
+                # is handed the same observations again -- a second hourglass stack, a fitting loop)
+                ws = points_ws if points_ws is not None else d2m_compact(observed)
+                Rd = d2m_points_parts(E)
+                d2m = torch.empty((E, Rd), dtype=torch.float32, device=dev)
+                gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
+                _lib.check(lib.shr_data_to_model_from_points(_ptr(ws), int(observed.shape[0]), _ptr(cidx), _ptr(cen), 4, _ptr(radii),
+                                                             E, J, H, W, Rd, _ptr(d2m), _ptr(gd2m), _stream()),
+                           "shr_data_to_model_from_points")
             else:
-                _lib.check(lib.shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), _ptr(depth),
-                                                     _ptr(sse), _ptr(gsp), _stream()), "shr_sphere_raster_mse")
-                if is_mv:
-                    E, cen, cidx = N, spheres, index
-                else:                # the V same-view pairs only: their records and observed-image numbers, gathered
-                    E = B * V
-                    cen = spheres.index_select(0, diag_index)
-                    cidx = index.index_select(0, diag_index)
                 Rd = lib.shr_data_to_model_parts(E, int(H), int(W))
                 d2m = torch.empty((E, Rd), dtype=torch.float32, device=dev)
                 gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
                 _lib.check(lib.shr_data_to_model_partial(_ptr(observed), _ptr(cidx), _ptr(cen), 4, _ptr(radii), E, J, H, W, Rd,
                                                          _ptr(d2m), _ptr(gd2m), _stream()), "shr_data_to_model_partial")
-                _lib.check(lib.shr_mv_loss_combine(_ptr(cam), _ptr(inv_cam), _ptr(sse), _ptr(gsp), Rm, _ptr(d2m), _ptr(gd2m), Rd,
-                                                   B, V, J, H, W, int(bool(is_mv)), float(d2m_weight), _ptr(loss), _ptr(gj),
-                                                   _stream()), "shr_mv_loss_combine")
+            loss = torch.empty(1, dtype=torch.float32, device=dev)
+            want = ctx.needs_input_grad[2]
+            gj = torch.empty((B, V, J, 3), dtype=torch.float32, device=dev) if want else None
+            _lib.check(lib.shr_mv_loss_combine(_ptr(cam), _ptr(inv_cam), _ptr(sse), _ptr(gsp), Rm, _ptr(d2m), _ptr(gd2m), Rd,
+                                               B, V, J, H, W, int(bool(is_mv)), float(d2m_weight), _ptr(loss), _ptr(gj),
+                                               _stream()), "shr_mv_loss_combine")
         if want:
             ctx.save_for_backward(gj)
         ctx.mark_non_differentiable(depth)
@@ -374,9 +378,9 @@ class MutualProjectionLossFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_depth):
         if g_loss is None:
-            return (None,) * 9
+            return (None,) * 10
         (gj,) = ctx.saved_tensors
-        return None, None, gj * g_loss, None, None, None, None, None, None
+        return None, None, gj * g_loss, None, None, None, None, None, None, None
 
 
 class MutualProject(torch.autograd.Function):

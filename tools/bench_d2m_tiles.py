@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Config 5's per-GPU share (1152 crops @256x256, and @128x128): render-and-compare, data->model, and the two fused in
-one launch at each search width; the whole MutualProjectionLoss forward + backward with the fusion on and off."""
+"""Config 5's per-GPU share (1152 crops @256x256, and @128x128): render-and-compare, the pixel-order data->model kernel
+and the tile-sorted one at each search width; the whole MutualProjectionLoss forward + backward with either."""
 import os
 import sys
 
@@ -43,28 +43,45 @@ with torch.cuda.stream(stream):
         Rm = lib.shr_sphere_raster_mse_regions(S5, S5)
         dep = torch.empty(n5, S5, S5, device=dev); sse = torch.empty(n5 * Rm, device=dev)
         gsp = torch.empty(n5 * Rm, J, 4, device=dev)
-        dl = torch.empty(n5 * Rm, dtype=torch.int64, device=dev); dg = torch.empty(n5 * Rm, J, 3, dtype=torch.int64, device=dev)
-        m = [t.data_ptr() for t in (sph, obs, index, dep, sse, gsp, dl, dg)]
+        m = [t.data_ptr() for t in (sph, obs, index, dep, sse, gsp)]
         t_mse = bench.mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_mse(m[0], n5, J, S5, S5, m[1], m[2], m[3], m[4],
                                                                                     m[5], s), "mse"), stream, 20, 3, 3)
         print("S=%d  crops=%d  fg=%.3f  mse %.1f us   d2m %.1f us (R=%d)   sum %.1f" %
               (S5, n5, float((obs <= 99).float().mean()), t_mse, t_d2m, R, t_mse + t_d2m), flush=True)
-        for K in (4, 2, 1):
-            ops.set_tuning(ops.TUNE_MSE_D2M_K, K)
-            for diag in (0, 3):
-                t = bench.mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_mse_d2m(m[0], n5, J, S5, S5, m[1], m[2], m[3], m[4],
-                                                                                            m[5], diag, m[6], m[7], s), "fused"), stream, 20, 3, 3)
-                print("   fused K=%d diag_v=%d: %.1f us" % (K, diag, t), flush=True)
-        ops.set_tuning(ops.TUNE_MSE_D2M_K, 0)
+        ws = ops.d2m_compact(obs)
+        M = obs.shape[0]
+        t_c = bench.mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_compact(obs.data_ptr(), M, S5, S5, ws.data_ptr(), s), "compact"),
+                                   stream, 20, 3, 3)
+        print("   two-step: compact %d images %.1f us (%.1f MB workspace)" % (M, t_c, ws.numel() / 1e6), flush=True)
+        for waves in (0, 8):
+            ops.set_tuning(ops.TUNE_D2M_WAVES, waves)
+            for parts in (1, 2, 4, 8):
+                ls2 = torch.empty(n5 * parts, device=dev); gr2 = torch.empty(n5 * parts, J, 3, device=dev)
+                t = bench.mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_from_points(ws.data_ptr(), M, a[1], a[2], 4, a[3], n5, J, S5, S5, parts,
+                                                                                                ls2.data_ptr(), gr2.data_ptr(), s), "pts"), stream, 20, 3, 3)
+                print("   two-step: search waves=%d parts=%d: %.1f us" % (waves, parts, t), flush=True)
+        ops.set_tuning(ops.TUNE_D2M_WAVES, 0)
+        for parts in (1, 2):
+            ls2 = torch.empty(n5 * parts, device=dev)
+            t = bench.mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_from_points(ws.data_ptr(), M, a[1], a[2], 4, a[3], n5, J, S5, S5, parts,
+                                                                                            ls2.data_ptr(), None, s), "pts"), stream, 20, 3, 3)
+            print("   two-step: search WITHOUT gradient parts=%d: %.1f us" % (parts, t), flush=True)
+        for tiled in (1, 0):
+            ops.set_tuning(ops.TUNE_D2M_TILED, tiled)
+            t = bench.mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_partial(a[0], a[1], a[2], 4, a[3], n5, J, S5, S5, R,
+                                                                                        a[4], a[5], s), "d2m"), stream, 20, 3, 3)
+            print("   streaming kernel tiled=%d parts=%d: %.1f us" % (tiled, R, t), flush=True)
+        ops.set_tuning(ops.TUNE_D2M_TILED, 1)
         for is_mv in (True, False):
-            for fuse in (True, False):
-                ops.FUSE_D2M = fuse
+            for two in (True, False):
+                ops.D2M_TWO_STEP = two
 
                 def mv_step():
                     joints.grad = None
                     loss, _ = crit(cam, inv, joints, real, is_mv)
                     loss.backward()
                 t = bench.mean_launch_us(lambda _s: mv_step(), stream, 10, 3, 3)
-                print("   MutualProjectionLoss fwd+bwd is_mv=%s fuse_d2m=%s: %.1f us" % (is_mv, fuse, t), flush=True)
-        ops.FUSE_D2M = True
-        del ds, crit, real, obs, dep, gsp, gr, dl, dg
+                print("   MutualProjectionLoss fwd+bwd is_mv=%s two_step_d2m=%s: %.1f us" % (is_mv, two, t), flush=True)
+        ops.D2M_TWO_STEP = True
+        del ws
+        del ds, crit, real, obs, dep, gsp, gr

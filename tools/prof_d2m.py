@@ -16,5 +16,9 @@ obs = real.view(B * 3, S, S).contiguous()
 idx = (torch.arange(B, device="cuda", dtype=torch.int32).view(B, 1, 1) * 3 + torch.arange(3, device="cuda", dtype=torch.int32).view(1, 1, 3)).expand(B, 3, 3).reshape(-1).contiguous()
 cen = pts.squeeze(-1).reshape(N, 41, 3).contiguous()
 rad = crit.data_to_model_criterion.radiuses.view(-1).contiguous()
+if 'TILED' in os.environ:
+    ops.set_tuning(ops.TUNE_D2M_TILED, int(os.environ['TILED']))
+if 'BAND' in os.environ:
+    ops.set_tuning(ops.TUNE_D2M_BAND_UNITS, int(os.environ['BAND']))
 for _ in range(int(os.environ.get('REPS', '5'))): ops.data_to_model(obs, cen, rad, want_grad=True, depth_index=idx)
 torch.cuda.synchronize()
