@@ -443,7 +443,7 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     with torch.cuda.graph(g, stream=stream):
         chain()
     t_chain = mean_launch_us(lambda _s: g.replay(), stream, 100, 3, 10)
-    t_eager = torch_us(chain, 50)
+    t_eager = mean_launch_us(lambda _s: chain(), stream, 50, 3, 30)   # (30 warm-up iterations: allocator and clocks settled)
     sec["pose_to_depth_to_pose_us"] = {"graph_replay_us": round(t_chain, 2), "eager_autograd_us": round(t_eager, 1),
                                        "crops_per_s_graph": round(BATCH / (t_chain * 1e-6), 1),
                                        "chain": "pose[256,26] -> fk_fwd -> key-point skinning -> sphere raster fwd (+ owner map) "

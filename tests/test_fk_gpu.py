@@ -144,3 +144,4 @@ def test_keypoint_spheres_kernel_vs_torch_skinning(fk):
         from spherehand_amd import ops
         ops.KeypointSpheres.apply(T1.detach()[:, :5], hbr.lbs.kp_bone, hbr.lbs.skin_wv, hbr.radiuses.view(-1),
                                   hbr.lbs.kp_bone_start, hbr.lbs.kp_bone_points, True)
+
