@@ -79,7 +79,7 @@ class MutualProjectionLoss(nn.Module):
             if W % 4 == 0 and observed.data_ptr() % 16 == 0 and \
                     ops._lib.lib().shr_sphere_raster_mse_regions(int(H), int(W)) > 0:
                 index, diag = self._indices(B, V, joints.device)
-                ws = self._point_lists(observed) if ops.D2M_TWO_STEP and ops.d2m_points_supported(observed) else None
+                ws = self._point_lists(observed) if ops.d2m_two_step_pays(observed) else None
                 loss, projected = ops.MutualProjectionLossFused.apply(camera_poses, inv_camera_poses, joints, observed, radii,
                                                                       index, diag, bool(is_mv), 500.0, ws)
                 return loss, projected.view(B, V, V, H, W)

@@ -215,7 +215,7 @@ def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
         raise RuntimeError("radii must have J entries")
     if depth_index is not None:
         _check_index(depth_index, N, depth.shape[0], "depth_index")
-    if D2M_TWO_STEP and N > 0 and d2m_points_supported(depth):
+    if N > 0 and d2m_two_step_pays(depth):
         # compact every image once, search the point lists (bit-identical sums, see csrc/data_to_model.hip)
         ws = d2m_compact(depth)
         return data_to_model_from_points(ws, depth.shape[0], H, W, centres, radii, depth_index, want_grad)
@@ -235,10 +235,19 @@ def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
     return (loss_sum, grad) if want_grad else loss_sum
 
 
+D2M_TWO_STEP_MIN_PIXELS = 1 << 23   # (384 images @128x128 = 6.3 M pixels: the two paths tie there -- 52 vs 55 us at 1152 crops)
+
+
 def d2m_points_supported(depth):
-    """True when the two-step data->model path takes this image stack [M,H,W] (16-byte rows, at most 4 M pixels)."""
+    """True when the two-step data->model path takes this image stack [M,H,W] (16-byte rows, at most 2^28 pixels)."""
     return depth.dim() == 3 and depth.shape[0] > 0 and depth.data_ptr() % 16 == 0 and \
         _lib.lib().shr_data_to_model_points_bytes(int(depth.shape[0]), int(depth.shape[1]), int(depth.shape[2])) > 0
+
+
+def d2m_two_step_pays(depth):
+    """The two-step path costs a launch more than the streaming kernel and wins where the streaming kernel is bound by
+    its VALU work (large images compared with several sphere sets); small stacks stay with one launch."""
+    return D2M_TWO_STEP and depth.numel() >= D2M_TWO_STEP_MIN_PIXELS and d2m_points_supported(depth)
 
 
 def d2m_compact(depth):
@@ -353,7 +362,7 @@ class MutualProjectionLossFused(torch.autograd.Function):
                 E = B * V
                 cen = spheres.index_select(0, diag_index)
                 cidx = index.index_select(0, diag_index)
-            if D2M_TWO_STEP and d2m_points_supported(observed):
+            if points_ws is not None or d2m_two_step_pays(observed):
                 # every observed image is compared with V sphere sets (mesh/multiview_utility.py:99): compacted once
                 # (points_ws: the caller's point lists of these very images, MutualProjectionLoss keeps them while it
                 # is handed the same observations again -- a second hourglass stack, a fitting loop)

@@ -54,6 +54,17 @@ def _d2m(obs, index, sph, parts):
     return loss, grad
 
 
+@pytest.fixture(autouse=True)
+def two_step_at_any_size():
+    """The module-level entries take the two-step path only above ops.D2M_TWO_STEP_MIN_PIXELS (where it pays); here it
+    is what is under test, at every size."""
+    from spherehand_amd import ops
+    keep = ops.D2M_TWO_STEP_MIN_PIXELS
+    ops.D2M_TWO_STEP_MIN_PIXELS = 0
+    yield
+    ops.D2M_TWO_STEP_MIN_PIXELS = keep
+
+
 @pytest.fixture
 def tune():
     from spherehand_amd import ops

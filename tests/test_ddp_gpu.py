@@ -20,6 +20,17 @@ def launch(world, out, model_dir, **extra):
     return torch.load(out)
 
 
+def _params_agree(a, b, gmax):
+    """After one Adam step (lr 1e-3) the first update is lr * g / (|g| + 1e-8): where the gradient is well above the
+    rounding noise of the two runs the weights agree closely; a weight whose gradient IS noise (|g| <~ 1e-7) moves by
+    up to lr in a direction the noise decides -- bounded by 2 lr, not comparable further."""
+    for k in a["params"]:
+        d = (a["params"][k] - b["params"][k]).abs()
+        solid = a["grads"][k].abs() > 1e-5 * gmax
+        assert d[solid].max().item() <= 2e-5 if solid.any() else True, k
+        assert d.max().item() <= 2.1e-3, k
+
+
 def test_two_rank_render_fit_step_equals_single_process(tmp_path):
     one = launch(1, str(tmp_path / "w1.pt"), str(tmp_path / "m1"))
     two = launch(2, str(tmp_path / "w2.pt"), str(tmp_path / "m2"))
@@ -35,8 +46,7 @@ def test_two_rank_render_fit_step_equals_single_process(tmp_path):
     print("gmax %.4g worst grad diff %.4g" % (gmax, worst))
     for k in one["grads"]:           # averaged gradients (MIOpen may pick another algorithm at half the batch)
         assert (one["grads"][k] - two["grads"][k]).abs().max().item() <= 1e-5 * gmax + 1e-8, k
-    for k in one["params"]:          # after one Adam step (lr 1e-3: a step is <= 1e-3 per weight)
-        assert (one["params"][k] - two["params"][k]).abs().max().item() <= 2e-5, k
+    _params_agree(one, two, gmax)
 
 
 def test_one_rank_rccl_ddp_step_equals_the_plain_step(tmp_path):
@@ -49,13 +59,13 @@ def test_one_rank_rccl_ddp_step_equals_the_plain_step(tmp_path):
     rccl = launch(1, str(tmp_path / "r.pt"), str(tmp_path / "mr"), SHR_FORCE_DIST="1", SHR_DDP_BACKEND="nccl")
     assert plain["ddp"] != "DistributedDataParallel" and plain["backend"] is None
     assert rccl["ddp"] == "DistributedDataParallel" and rccl["backend"] == "nccl" and rccl["world"] == 1
+    # (two processes: MIOpen's convolution backward is not bit-reproducible from run to run, the bars are the two-rank test's)
     for k in plain["terms"]:
-        assert abs(plain["terms"][k] - rccl["terms"][k]) <= 1e-6 * max(1.0, abs(plain["terms"][k])), k
+        assert abs(plain["terms"][k] - rccl["terms"][k]) <= 1e-5 * max(1.0, abs(plain["terms"][k])), k
     gmax = max(v.abs().max().item() for v in plain["grads"].values())
     for k in plain["grads"]:
-        assert (plain["grads"][k] - rccl["grads"][k]).abs().max().item() <= 1e-6 * gmax + 1e-9, k
-    for k in plain["params"]:    # after one Adam step (lr 1e-3): a last-bit gradient difference moves a weight by up to ~1e-5
-        assert (plain["params"][k] - rccl["params"][k]).abs().max().item() <= 2e-5, k
+        assert (plain["grads"][k] - rccl["grads"][k]).abs().max().item() <= 1e-5 * gmax + 1e-8, k
+    _params_agree(plain, rccl, gmax)
 
 
 def test_one_rank_rccl_bucket_allreduce():
