@@ -89,15 +89,32 @@ mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ 
     // per iteration: independent loads, where a loop over pairs with inner loops over the parts chained 4.5 x 8
     // dependent round trips per thread -- 11 us for config 5's 1152 pairs), then a fixed tree: deterministic
     __shared__ double s_m[256], s_d[256];
-    const long long N = (long long)B * V * V;
+    // (32-bit indices: the launcher keeps B V V J below 2^31 and the partial counts small; four loads in flight per
+    // thread -- one element per iteration with 64-bit divisions for its pair chained ~20 round trips and ~60 long
+    // divisions per thread: 11 us for config 5's 1152 pairs)
+    const int N = B * V * V, NE = N * Rm;
     double am = 0.0, ad = 0.0;
-    for (long long e = threadIdx.x; e < N * Rm; e += 256) {
-      const long long n = e / Rm;
-      const int j = (int)(n % V), i = (int)((n / V) % V);
-      if (is_mv || i == j) am += (double)sse_part[e];
+    for (int e0 = threadIdx.x; e0 < NE; e0 += 1024) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + 256 * u;
+        bool take = e < NE;
+        if (take && !is_mv) {
+          const int n = e / Rm, j = n % V, i = (n / V) % V;
+          take = i == j;
+        }
+        v[u] = take ? sse_part[e] : 0.f;
+      }
+      am += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
     }
-    const long long E = is_mv ? N : (long long)B * V;     // d2m entries: every pair, or the same-view pairs only
-    for (long long e = threadIdx.x; e < E * Rd; e += 256) ad += (double)d2m_part[e];
+    const int DE = (is_mv ? N : B * V) * Rd;     // d2m entries: every pair, or the same-view pairs only
+    for (int e0 = threadIdx.x; e0 < DE; e0 += 1024) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = e0 + 256 * u < DE ? d2m_part[e0 + 256 * u] : 0.f;
+      ad += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+    }
     s_m[threadIdx.x] = am; s_d[threadIdx.x] = ad;
     __syncthreads();
     for (int h = 128; h > 0; h >>= 1) {
@@ -107,11 +124,11 @@ mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ 
     if (threadIdx.x == 0) loss_out[0] = (float)((double)w_m * s_m[0] + (double)w_d * s_d[0]);
     return;
   }
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total || !grad_joints) return;
-  const int k = (int)(idx % J);
-  const int i = (int)((idx / J) % V);
-  const int b = (int)(idx / ((long long)J * V));
+  const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (idx >= (int)total || !grad_joints) return;
+  const int k = idx % J;
+  const int i = (idx / J) % V;
+  const int b = idx / (J * V);
   float g[3] = {0.f, 0.f, 0.f};
   for (int j = 0; j < V; j++) {
     if (!is_mv && j != i) continue;
@@ -133,7 +150,7 @@ mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ 
 #pragma unroll
     for (int c = 0; c < 3; c++) g[c] += (R[0][c] * sx + R[1][c] * sy) + R[2][c] * sz;
   }
-  float *o = grad_joints + idx * 3;
+  float *o = grad_joints + (size_t)idx * 3;
   o[0] = g[0]; o[1] = g[1]; o[2] = g[2];
 }
 

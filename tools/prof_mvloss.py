@@ -9,6 +9,7 @@ mesh = hand_model.load_mesh()
 B, S = int(os.environ.get("B", 128)), int(os.environ.get("S", 256))
 ds = SyntheticMultiviewDataset(mesh, B, S, seed=0)
 crit = MutualProjectionLoss(S, mesh).cuda()
+crit.cache_points = os.environ.get('CACHE', '0') == '1'    # default: fresh observations every call (what training pays)
 real, cam, inv = ds.dms.cuda(), ds.cam.cuda(), ds.inv_cam.cuda()
 joints = (ds.joints.cuda() + torch.randn_like(ds.joints.cuda())).requires_grad_(True)
 def step():
