@@ -365,9 +365,9 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
                                      "on and the observed images unchanged between calls (second hourglass stack, fitting loop)",
         "crops_per_s": round(n5 / (t_mv * 1e-6), 1),
         # two-step data->model (the path the loss takes): images read once (4 S^2 each) and their foreground written as
-        # 16-byte points; the search reads every crop's image list (16 B per point) + the 41 records
-        "d2m_compact_kernel": dict(us=round(t_cmp, 1), images=M5, **roof(M5 * 4 * S5 * S5 + 16 * fg_px, t_cmp)),
-        "d2m_points_kernel": dict(us=round(t_pts, 1), parts=Pp, **roof(3 * 16 * fg_px + n5 * 16 * J, t_pts)),
+        # 8-byte points; the search reads every crop's image list (8 B per point) + the 41 records
+        "d2m_compact_kernel": dict(us=round(t_cmp, 1), images=M5, **roof(M5 * 4 * S5 * S5 + 8 * fg_px, t_cmp)),
+        "d2m_points_kernel": dict(us=round(t_pts, 1), parts=Pp, **roof(3 * 8 * fg_px + n5 * 16 * J, t_pts)),
         # the streaming kernel (round 2; still behind shr_data_to_model_partial): every pair reads its image (4 S^2)
         "data_to_model_kernel": dict(us=round(t_d2m, 1), workgroups_per_crop=R, **roof(n5 * (4 * S5 * S5 + 16 * J), t_d2m)),
         # fused render-and-compare: reads the observed image, writes the projection (returned by the loss)

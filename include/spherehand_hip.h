@@ -158,7 +158,7 @@ int shr_data_to_model_partial(const float *depth, const int32_t *depth_index,
 
 /* The same loss in TWO STEPS (round 4), for callers that compare one observed image with several sphere sets (the V*V
  * view pairs of mesh/multiview_utility.py:98-105 share V images) -- or that just want the faster path:
- *   shr_data_to_model_compact      every image of depth[M,H,W] once: its foreground pixels (<= 99) as (xg, yg, depth, v << 16 | u)
+ *   shr_data_to_model_compact      every image of depth[M,H,W] once: its foreground pixels (<= 99) as 8-byte (v << 16 | u, depth)
  *                                  records sorted by 16 x 16-pixel tile, into `workspace`
  *                                  (shr_data_to_model_points_bytes(M, H, W) bytes, 16-byte aligned; 0 = image not
  *                                  taken: W % 4 != 0 or more than 2^28 pixels -- use the calls above);

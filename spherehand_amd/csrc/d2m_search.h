@@ -266,12 +266,16 @@ __device__ __forceinline__ void d2m_search(const D2mCtx &cx, Entry &&entry, int 
   d2m_search_core<K, WANT_GRAD, BOX2D>(cx, px, py, pz, count, first_v, last_v, loss_fx);
 }
 
-// The same for points that come with their coordinates (the two-step path's lists): e[i] = (xg, yg, depth, -), box bound.
+// The same for a group already in registers (the two-step path's lists): e[i] = (v << 16 | u, bits(depth)), box bound.
 template <int K, bool WANT_GRAD>
-__device__ __forceinline__ void d2m_search_points(const D2mCtx &cx, const float4 (&e)[K], int count, long long &loss_fx) {
+__device__ __forceinline__ void d2m_search_points(const D2mCtx &cx, const uint2 (&e)[K], int count, long long &loss_fx) {
   float px[K], py[K], pz[K];
 #pragma unroll
-  for (int i = 0; i < K; i++) { px[i] = e[i].x; py[i] = e[i].y; pz[i] = e[i].z; }
+  for (int i = 0; i < K; i++) {
+    px[i] = axis_coord(cx.ax, (int)(e[i].x & 0xffffu));
+    py[i] = axis_coord(cx.ay, (int)(e[i].x >> 16));
+    pz[i] = __uint_as_float(e[i].y);
+  }
   d2m_search_core<K, WANT_GRAD, true>(cx, px, py, pz, count, 0, 0, loss_fx);
 }
 

@@ -321,8 +321,7 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
 //           pixels), about 16 x 16 pixels -- a prefix over the tiles in boustrophedon order gives every (wave, column
 //           block) its range, the region draws its place in the image's list from a counter (one atomic per region:
 //           the order of the regions in the list is whatever it comes out as), and each pixel is written there as its
-//           POINT (xg, yg, depth, v << 16 | u) -- the grid coordinates of mesh/render.py:31-32, computed once per
-//           image.  The list of an image is sorted by tile inside each region.
+//           8-byte POINT (v << 16 | u, depth).  The list of an image is sorted by tile inside each region.
 //   step 2  d2m_points_kernel: one workgroup per (crop, part).  Wave w takes the groups of 256 consecutive points
 //           of its part (g = part mod parts) in turn (equal work by construction), requests the next group's
 //           points while it searches the current one (d2m_search.h with the group's own bounding box: one or two
@@ -335,7 +334,7 @@ constexpr int kCompactUnits = 4;
 constexpr int kRegionPixels = kCompactWaves * kCompactUnits * 256;   // 16384
 
 __global__ void __launch_bounds__(kCompactWaves * 64)
-d2m_compact_kernel(const float *__restrict__ depth, int H, int W, int geom, float4 *__restrict__ points,
+d2m_compact_kernel(const float *__restrict__ depth, int H, int W, int geom, uint2 *__restrict__ points,
                    int *__restrict__ counts) {
   __shared__ int s_wcnt[kCompactWaves * 16], s_wcur[kCompactWaves * 16], s_base;
   const int m = blockIdx.x, region = blockIdx.y;
@@ -391,8 +390,7 @@ d2m_compact_kernel(const float *__restrict__ depth, int H, int W, int geom, floa
   if (T == 0) return;
   if (tid == 0) s_base = atomicAdd(&counts[m], T);     // this region's place in the image's list
   __syncthreads();
-  float4 *out = points + (size_t)m * P + s_base;
-  const Axis ax = make_axis(W), ay = make_axis(H);
+  uint2 *out = points + (size_t)m * P + s_base;
   const int my_sb = (int)(((float)wave + 0.5f) * __builtin_amdgcn_rcpf((float)SB));
 #pragma unroll
   for (int k = 0; k < kCompactUnits; k++) {
@@ -406,18 +404,17 @@ d2m_compact_kernel(const float *__restrict__ depth, int H, int W, int geom, floa
     if (cnt) {
       p += atomicAdd(&s_wcur[wave * 16 + tc], cnt);     // rank inside the wave's (tile) range: any order will do
       const unsigned vu = ((unsigned)v << 16) | (unsigned)x;
-      const float yg = axis_coord(ay, v);
       const float tz[4] = {t[k].x, t[k].y, t[k].z, t[k].w};
 #pragma unroll
       for (int c = 0; c < 4; c++)
-        if (fg[c]) { out[p] = make_float4(axis_coord(ax, x + c), yg, tz[c], __uint_as_float(vu + (unsigned)c)); p++; }
+        if (fg[c]) { out[p] = make_uint2(vu + (unsigned)c, __float_as_uint(tz[c])); p++; }
     }
   }
 }
 
 template <bool WANT_GRAD, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
-d2m_points_kernel(const float4 *__restrict__ points, const int *__restrict__ counts, int P,
+d2m_points_kernel(const uint2 *__restrict__ points, const int *__restrict__ counts, int P,
                   const int *__restrict__ depth_index, const float *__restrict__ centres, int centre_stride,
                   const float *__restrict__ radii, int J, int H, int W, int parts, float *__restrict__ loss_sum,
                   float *__restrict__ grad_centres) {
@@ -431,18 +428,25 @@ d2m_points_kernel(const float4 *__restrict__ points, const int *__restrict__ cou
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = depth_index ? depth_index[n] : n;
   const int T = counts[m], G = (T + GS - 1) / GS;
-  const float4 *img = points + (size_t)m * P;
-  // group g = points [256 g, 256 g + 256) of the image's list; lane l holds the four points 256 g + 4 l ... (64
-  // contiguous bytes per lane)
-  auto load_group = [&](int g, float4 e[K]) {
+  const uint2 *img = points + (size_t)m * P;
+  // group g = points [256 g, 256 g + 256) of the image's list; lane l holds the four points 256 g + 4 l ... (32
+  // contiguous, 16-byte aligned bytes per lane: two 16-byte loads; the list's last, partial group point by point)
+  static_assert(K == 4, "two 16-byte loads per lane");
+  auto load_group = [&](int g, uint2 e[K]) {
+    const int i0 = g * GS + K * lane;
+    if (g * GS + GS <= T) {
+      const uint4 a = reinterpret_cast<const uint4 *>(img + i0)[0], b = reinterpret_cast<const uint4 *>(img + i0)[1];
+      e[0] = make_uint2(a.x, a.y); e[1] = make_uint2(a.z, a.w); e[2] = make_uint2(b.x, b.y); e[3] = make_uint2(b.z, b.w);
+    } else {
 #pragma unroll
-    for (int i = 0; i < K; i++) e[i] = img[min(g * GS + K * lane + i, T - 1)];
+      for (int i = 0; i < K; i++) e[i] = img[min(i0 + i, T - 1)];
+    }
   };
   // part p owns the groups g = p (mod parts) -- whatever the workgroup size: a part's sum does not depend on the launch
   // shape -- and its waves take them in turn
   const int stride = WAVES * parts;
   int g = part + parts * wave;
-  float4 e[K], en[K];
+  uint2 e[K], en[K];
   if (g < G) load_group(g, e);                    // (in flight while wave 0 reads the records)
   if (wave == 0) {
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -612,7 +616,7 @@ int d2m_tile_geometry(int W) {
 bool d2m_points_ok(int H, int W) {
   return H > 0 && W > 0 && (W & 3) == 0 && W <= 16384 && H <= 65535 && (long long)H * W <= (1LL << 28);
 }
-size_t d2m_counts_offset(int M, int H, int W) { return (size_t)M * H * W * sizeof(float4); }
+size_t d2m_counts_offset(int M, int H, int W) { return (size_t)M * H * W * sizeof(uint2); }
 }  // namespace
 
 extern "C" long long shr_data_to_model_points_bytes(int M, int H, int W) {
@@ -627,7 +631,7 @@ extern "C" int shr_data_to_model_compact(const float *depth, int M, int H, int W
   if (!d2m_points_ok(H, W)) return SHR_ETOOLARGE;
   if (((((uintptr_t)depth) | ((uintptr_t)workspace)) & 15u) != 0) return SHR_EINVAL;
   const int R = (int)(((long long)H * W + kRegionPixels - 1) / kRegionPixels);
-  float4 *points = static_cast<float4 *>(workspace);
+  uint2 *points = static_cast<uint2 *>(workspace);
   int *counts = reinterpret_cast<int *>(static_cast<unsigned char *>(workspace) + d2m_counts_offset(M, H, W));
   hipStream_t s = (hipStream_t)stream;
   const hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)M, s);   // the lists' fill counters
@@ -646,7 +650,7 @@ extern "C" int shr_data_to_model_from_points(const void *workspace, int M, const
   if (!workspace || !centres || !radii || !loss_parts || N < 0 || M <= 0 || J <= 0 || H <= 0 || W <= 0) return SHR_EINVAL;
   if (parts < 1 || parts > 64 || (centre_stride != 3 && centre_stride != 4) || (!depth_index && M != N)) return SHR_EINVAL;
   if (!d2m_points_ok(H, W) || J > SHR_MAX_SPHERES || (long long)N * parts > 0x7fffffffLL) return SHR_ETOOLARGE;
-  const float4 *points = static_cast<const float4 *>(workspace);
+  const uint2 *points = static_cast<const uint2 *>(workspace);
   const int *counts = reinterpret_cast<const int *>(static_cast<const unsigned char *>(workspace) + d2m_counts_offset(M, H, W));
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)(N * parts));

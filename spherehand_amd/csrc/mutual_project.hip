@@ -124,14 +124,19 @@ mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ 
     if (threadIdx.x == 0) loss_out[0] = (float)((double)w_m * s_m[0] + (double)w_d * s_d[0]);
     return;
   }
-  const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (idx >= (int)total || !grad_joints) return;
-  const int k = idx % J;
-  const int i = (idx / J) % V;
-  const int b = idx / (J * V);
+  // d loss / d joints: VP = 4 (V <= 4) or 8 lanes per (b, i, k), lane j = the pair (b, i, j): the V contributions are
+  // gathered side by side and added across the lanes (xor butterfly: (c0 + c1) + (c2 + c3), for V = 3 the serial
+  // order (c0 + c1) + c2 to the bit) -- a loop over j chained V rounds of dependent loads per thread (10 us at config 5)
+  if (!grad_joints) return;
+  const int vp_shift = V <= 4 ? 2 : 3, VP = 1 << vp_shift;
+  const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  const int idx = t >> vp_shift, j = t & (VP - 1);
+  const bool in = idx < (int)total;
+  const int k = in ? idx % J : 0;
+  const int i = in ? (idx / J) % V : 0;
+  const int b = in ? idx / (J * V) : 0;
   float g[3] = {0.f, 0.f, 0.f};
-  for (int j = 0; j < V; j++) {
-    if (!is_mv && j != i) continue;
+  if (in && j < V && (is_mv || j == i)) {
     const long long n = ((long long)b * V + i) * V + j;
     float gx = 0.f, gy = 0.f, gz = 0.f;
     for (int r = 0; r < Rm; r++) {
@@ -145,13 +150,19 @@ mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ 
       dx += a[0]; dy += a[1]; dz += a[2];
     }
     const float sx = w_m * gx + w_d * dx, sy = w_m * gy + w_d * dy, sz = w_m * gz + w_d * dz;
-    float R[3][3], t[3];
-    pair_rt(cam, inv_cam, b, V, i, j, R, t);
+    float R[3][3], tt[3];
+    pair_rt(cam, inv_cam, b, V, i, j, R, tt);
 #pragma unroll
-    for (int c = 0; c < 3; c++) g[c] += (R[0][c] * sx + R[1][c] * sy) + R[2][c] * sz;
+    for (int c = 0; c < 3; c++) g[c] = (R[0][c] * sx + R[1][c] * sy) + R[2][c] * sz;
   }
-  float *o = grad_joints + (size_t)idx * 3;
-  o[0] = g[0]; o[1] = g[1]; o[2] = g[2];
+  for (int m = 1; m < VP; m <<= 1) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) g[c] += __shfl_xor(g[c], m);
+  }
+  if (in && j == 0) {
+    float *o = grad_joints + (size_t)idx * 3;
+    o[0] = g[0]; o[1] = g[1]; o[2] = g[2];
+  }
 }
 
 }  // namespace shr
@@ -173,7 +184,10 @@ extern "C" int shr_mv_loss_combine(const float *cam, const float *inv_cam, const
   const double wm = is_mv ? 9.0 / ((double)B * V * V * px) : 3.0 / ((double)B * px);
   const double wd = (double)d2m_weight * wm;
   const long long total = (long long)B * V * J;
-  hipLaunchKernelGGL(mv_loss_combine_kernel, dim3((unsigned)((total + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream,
+  if (V > 8) return SHR_ETOOLARGE;   // (the pairs of a view sit side by side in 4 or 8 lanes)
+  const long long lanes = total * (V <= 4 ? 4 : 8);
+  if (lanes > (1LL << 31) - 512) return SHR_ETOOLARGE;
+  hipLaunchKernelGGL(mv_loss_combine_kernel, dim3((unsigned)((lanes + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream,
                      cam, inv_cam, sse_part, reinterpret_cast<const float4 *>(grad_spheres_part), Rm, d2m_part,
                      grad_d2m_part, Rd, B, V, J, is_mv, (float)wm, (float)wd, loss, grad_joints);
   return (int)hipGetLastError();
