@@ -107,7 +107,9 @@ class SyntheticMultiviewDataset(data.Dataset):
         mp = MutualProjection(image_size, mesh).to(dev)
         with torch.no_grad():
             canonical = lbs(fk(params.to(dev)))[:, :, :3]                                   # [N,41,3]
-            joints = torch.einsum('nvij,nkj->nvki', inv_cam[:, :, :3, :3].to(dev), canonical)  # per view
+            joints = torch.einsum('nvij,nkj->nvki', inv_cam[:, :, :3, :3].to(dev), canonical).contiguous()  # per view
+            # (einsum returns a permuted view: as a leaf of the fitting loop it cost a layout copy in every forward and
+            # another in AccumulateGrad -- 9 us of a 300-us loss step)
             dms = []
             for s in range(0, num_samples, 64):
                 d, _ = mp(cam[s:s + 64].to(dev), inv_cam[s:s + 64].to(dev), joints[s:s + 64].contiguous())
