@@ -316,7 +316,8 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
 // In the multiview loss every observed image is compared with the sphere sets of V crops
 // (mesh/multiview_utility.py:99: real_dms expanded V times), and 40 % of the streaming kernel's VALU instructions --
 // the resource it is bound by -- stream and compact pixels (SQ counters, round 4): work that depends on the image only.
-//   step 1  d2m_compact_kernel: one workgroup (16 waves) per (image, region of 16384 consecutive pixels).  Foreground
+//   step 1  d2m_compact_kernel: one workgroup (8 waves) per (image, region of 8192 consecutive pixels; measured with
+//           16 / 8 / 4 waves: compaction 29.0 / 26.8 / 27.0 us, search 74.6 / 74.7 / 83.6 us at config 5).  Foreground
 //           pixels (depth <= 99, mesh/render.py:138) are counted per TILE -- (SB waves) x (column block of 2^cbs
 //           pixels), about 16 x 16 pixels -- a prefix over the tiles in boustrophedon order gives every (wave, column
 //           block) its range, the region draws its place in the image's list from a counter (one atomic per region:
@@ -329,7 +330,7 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
 //           streaming kernel.  Every lane of every group but an image's last holds four points.
 // Same per-point code, conservative bounds, integer sums: results bit-identical to data_to_model_kernel's -- and
 // independent of the order the regions arrived in.
-constexpr int kCompactWaves = 16;
+constexpr int kCompactWaves = 8;
 constexpr int kCompactUnits = 4;
 constexpr int kRegionPixels = kCompactWaves * kCompactUnits * 256;   // 16384
 
