@@ -73,8 +73,9 @@ int shr_device_info(char *name_host, int name_len, int *num_cu_host);
                                     * per-(sphere, lane) LDS table built by the idle waves: -1 = when it fits (default),
                                     * 0 = never, 1 = same as -1 */
 #define SHR_TUNE_D2M_TILED 15        /* data->model kernel: 1 = units are 32 x 8-pixel tiles and a search is bounded by its
-                                    * points' own x-y box (default wherever W % 4 == 0 and the images are 16-byte aligned),
-                                    * 0 = 256 consecutive pixels per unit and strip bounds (round 2's kernel) */
+                                    * points' own box (needs W % 4 == 0 and 16-byte aligned images), 0 = 256 consecutive
+                                    * pixels per unit and strip bounds (round 2's kernel), -1 = tiles from 192 x 192 pixels
+                                    * on (default) */
 int shr_set_tuning(int key, int value);
 /* Self-test: adds to *mismatches (device, caller-zeroed u64) the number of fp32
  * bit patterns in [lo_bits, hi_bits) where the rasterizer's internal square root

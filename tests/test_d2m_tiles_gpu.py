@@ -69,7 +69,7 @@ def two_step_at_any_size():
 def tune():
     from spherehand_amd import ops
     yield ops
-    ops.set_tuning(ops.TUNE_D2M_TILED, 1)
+    ops.set_tuning(ops.TUNE_D2M_TILED, -1)
     ops.set_tuning(ops.TUNE_D2M_WAVES, 0)
     ops.set_tuning(ops.TUNE_D2M_BAND_UNITS, 0)
 

@@ -71,7 +71,7 @@ with torch.cuda.stream(stream):
             t = bench.mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_partial(a[0], a[1], a[2], 4, a[3], n5, J, S5, S5, R,
                                                                                         a[4], a[5], s), "d2m"), stream, 20, 3, 3)
             print("   streaming kernel tiled=%d parts=%d: %.1f us" % (tiled, R, t), flush=True)
-        ops.set_tuning(ops.TUNE_D2M_TILED, 1)
+        ops.set_tuning(ops.TUNE_D2M_TILED, -1)
         for is_mv in (True, False):
             for two in (True, False):
                 ops.D2M_TWO_STEP = two
