@@ -282,6 +282,12 @@ int shr_group_norm_relu_bwd(const float *x, const float *pre_bias, const float *
 int shr_mutual_project_fwd(const float *cam, const float *inv_cam, const float *joints,
                            const float *radii, int B, int V, int J, float *spheres,
                            void *stream);
+/* The two preparations of MutualProjectionLoss (mesh/multiview_utility.py:90-105) in TWO launches instead of three:
+ * shr_mutual_project_fwd (which also clears the point lists' fill counters) followed by the compaction of
+ * shr_data_to_model_compact(depth[M,H,W] -> workspace) without its memset.  Same results as the two calls. */
+int shr_mv_project_compact(const float *cam, const float *inv_cam, const float *joints,
+                           const float *radii, int B, int V, int J, float *spheres,
+                           const float *depth, int M, int H, int W, void *workspace, void *stream);
 /* Assembly of MutualProjectionLoss (mesh/multiview_utility.py:98-129) and of its backward from the partial results
  * of shr_sphere_raster_mse (sse_part [N][Rm], grad_spheres_part [N][Rm][J][4], N = B*V*V pairs) and of
  * shr_data_to_model_partial (d2m_part [E][Rd], grad_d2m_part [E][Rd][J][3]; E = N pairs when is_mv, else the B*V

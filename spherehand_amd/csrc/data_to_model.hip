@@ -332,7 +332,7 @@ data_to_model_kernel(const float *__restrict__ depth, const int *__restrict__ de
 // independent of the order the regions arrived in.
 constexpr int kCompactWaves = 8;
 constexpr int kCompactUnits = 4;
-constexpr int kRegionPixels = kCompactWaves * kCompactUnits * 256;   // 16384
+constexpr int kRegionPixels = kCompactWaves * kCompactUnits * 256;   // 8192
 
 __global__ void __launch_bounds__(kCompactWaves * 64)
 d2m_compact_kernel(const float *__restrict__ depth, int H, int W, int geom, uint2 *__restrict__ points,
@@ -627,21 +627,36 @@ extern "C" long long shr_data_to_model_points_bytes(int M, int H, int W) {
   return (long long)d2m_counts_offset(M, H, W) + 4LL * M;
 }
 
-extern "C" int shr_data_to_model_compact(const float *depth, int M, int H, int W, void *workspace, void *stream) {
-  using namespace shr;
-  if (M == 0) return SHR_OK;
+namespace shr {
+// argument checks of the compaction; *counts = the lists' fill counters inside the workspace
+int d2m_compact_check(const float *depth, int M, int H, int W, void *workspace, int **counts) {
   if (!depth || !workspace || M < 0 || H <= 0 || W <= 0) return SHR_EINVAL;
   if (!d2m_points_ok(H, W)) return SHR_ETOOLARGE;
   if (((((uintptr_t)depth) | ((uintptr_t)workspace)) & 15u) != 0) return SHR_EINVAL;
+  *counts = reinterpret_cast<int *>(static_cast<unsigned char *>(workspace) + d2m_counts_offset(M, H, W));
+  return SHR_OK;
+}
+// the compaction launch alone: the fill counters are zero already (checked arguments)
+int d2m_compact_launch(const float *depth, int M, int H, int W, void *workspace, hipStream_t s) {
   const int R = (int)(((long long)H * W + kRegionPixels - 1) / kRegionPixels);
   uint2 *points = static_cast<uint2 *>(workspace);
   int *counts = reinterpret_cast<int *>(static_cast<unsigned char *>(workspace) + d2m_counts_offset(M, H, W));
-  hipStream_t s = (hipStream_t)stream;
-  const hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)M, s);   // the lists' fill counters
-  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(d2m_compact_kernel, dim3((unsigned)M, (unsigned)R), dim3(kCompactWaves * 64), 0, s, depth, H, W,
                      d2m_tile_geometry(W), points, counts);
   return (int)hipGetLastError();
+}
+}  // namespace shr
+
+extern "C" int shr_data_to_model_compact(const float *depth, int M, int H, int W, void *workspace, void *stream) {
+  using namespace shr;
+  if (M == 0) return SHR_OK;
+  int *counts = nullptr;
+  const int rc = d2m_compact_check(depth, M, H, W, workspace, &counts);
+  if (rc != SHR_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * (size_t)M, s);   // the lists' fill counters
+  if (e != hipSuccess) return (int)e;
+  return d2m_compact_launch(depth, M, H, W, workspace, s);
 }
 
 extern "C" int shr_data_to_model_from_points(const void *workspace, int M, const int32_t *depth_index,

@@ -31,9 +31,13 @@ __device__ __forceinline__ void pair_rt(const float *__restrict__ cam, const flo
 
 __global__ void mutual_project_fwd_kernel(const float *__restrict__ cam, const float *__restrict__ inv_cam,
                                           const float *__restrict__ joints, const float *__restrict__ radii, int B,
-                                          int V, int J, float4 *__restrict__ spheres) {
+                                          int V, int J, float4 *__restrict__ spheres, int *__restrict__ zero,
+                                          int nzero) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)B * V * V * J;
+  // (shr_mv_project_compact: the fill counters of the point lists the NEXT launch builds -- a memset of their own
+  // is a 5-us launch)
+  if (idx < nzero) zero[idx] = 0;
   if (idx >= total) return;
   const int k = (int)(idx % J);
   const int j = (int)((idx / J) % V);
@@ -202,8 +206,33 @@ extern "C" int shr_mutual_project_fwd(const float *cam, const float *inv_cam, co
   const long long total = (long long)B * V * V * J;
   if (total > (1LL << 31) - 256) return SHR_ETOOLARGE;
   hipLaunchKernelGGL(mutual_project_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, cam, inv_cam, joints, radii, B, V, J, reinterpret_cast<float4 *>(spheres));
+                     (hipStream_t)stream, cam, inv_cam, joints, radii, B, V, J, reinterpret_cast<float4 *>(spheres),
+                     (int *)nullptr, 0);
   return (int)hipGetLastError();
+}
+
+extern "C" int shr_mv_project_compact(const float *cam, const float *inv_cam, const float *joints, const float *radii,
+                                      int B, int V, int J, float *spheres, const float *depth, int M, int H, int W,
+                                      void *workspace, void *stream) {
+  using namespace shr;
+  if (B == 0 || M == 0) {   // nothing to fuse: each step on its own (either returns at once on its empty side)
+    const int rc = shr_mutual_project_fwd(cam, inv_cam, joints, radii, B, V, J, spheres, stream);
+    return rc != SHR_OK ? rc : shr_data_to_model_compact(depth, M, H, W, workspace, stream);
+  }
+  if (!cam || !inv_cam || !joints || !radii || !spheres || B < 0 || V <= 0 || J <= 0) return SHR_EINVAL;
+  if (((uintptr_t)spheres & 15u) != 0) return SHR_EINVAL;
+  const long long total = (long long)B * V * V * J;
+  if (total > (1LL << 31) - 256) return SHR_ETOOLARGE;
+  int *counts = nullptr;
+  const int rc = d2m_compact_check(depth, M, H, W, workspace, &counts);
+  if (rc != SHR_OK) return rc;
+  const long long threads = total > M ? total : (long long)M;
+  hipLaunchKernelGGL(mutual_project_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, cam, inv_cam, joints, radii, B, V, J, reinterpret_cast<float4 *>(spheres),
+                     counts, M);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  return d2m_compact_launch(depth, M, H, W, workspace, (hipStream_t)stream);
 }
 
 extern "C" int shr_mutual_project_bwd(const float *cam, const float *inv_cam, const float *grad_spheres, int B, int V,

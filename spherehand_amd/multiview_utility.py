@@ -79,9 +79,11 @@ class MutualProjectionLoss(nn.Module):
             if W % 4 == 0 and observed.data_ptr() % 16 == 0 and \
                     ops._lib.lib().shr_sphere_raster_mse_regions(int(H), int(W)) > 0:
                 index, diag = self._indices(B, V, joints.device)
-                ws = self._point_lists(observed) if ops.d2m_two_step_pays(observed) else None
+                ws, fresh = self._point_lists(observed) if ops.d2m_two_step_pays(observed) else (None, False)
                 loss, projected = ops.MutualProjectionLossFused.apply(camera_poses, inv_camera_poses, joints, observed, radii,
-                                                                      index, diag, bool(is_mv), 500.0, ws)
+                                                                      index, diag, bool(is_mv), 500.0, ws, fresh)
+                if fresh:        # (kept only once the call that fills them has been issued)
+                    self._points = (observed, observed._version, ws) if self.cache_points else None
                 return loss, projected.view(B, V, V, H, W)
         projected_dms, projected_joints = mp(camera_poses, inv_camera_poses, joints)
         J = projected_joints.shape[3]
@@ -109,10 +111,8 @@ class MutualProjectionLoss(nn.Module):
         if self.cache_points and c is not None and c[0].untyped_storage().data_ptr() == observed.untyped_storage().data_ptr() \
                 and c[0].storage_offset() == observed.storage_offset() and c[0].shape == observed.shape \
                 and c[0].device == observed.device and c[1] == observed._version:
-            return c[2]
-        ws = ops.d2m_compact(observed)
-        self._points = (observed, observed._version, ws) if self.cache_points else None
-        return ws
+            return c[2], False
+        return ops.d2m_points_workspace(observed), True   # filled by the fused Function, with the view projection's launch
 
     def _indices(self, B, V, dev):
         key = (B, V, str(dev))

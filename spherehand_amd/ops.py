@@ -250,18 +250,24 @@ def d2m_two_step_pays(depth):
     return D2M_TWO_STEP and depth.numel() >= D2M_TWO_STEP_MIN_PIXELS and d2m_points_supported(depth)
 
 
-def d2m_compact(depth):
-    """depth [M,H,W] -> workspace (uint8 tensor): every image's foreground pixels as tile-sorted point records, for
-    data_to_model_from_points (shr_data_to_model_compact)."""
+def d2m_points_workspace(depth):
+    """An UNFILLED workspace (uint8 tensor) for the point lists of depth [M,H,W] (shr_data_to_model_points_bytes)."""
     _check_input(depth, "depth")
     M, H, W = depth.shape
-    lib = _lib.lib()
-    nbytes = lib.shr_data_to_model_points_bytes(int(M), int(H), int(W))
+    nbytes = _lib.lib().shr_data_to_model_points_bytes(int(M), int(H), int(W))
     if nbytes <= 0 or depth.data_ptr() % 16:
         raise RuntimeError("image not taken by the two-step data->model path (rows of 4 pixels, 16-byte aligned)")
     with _on(depth.device):
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=depth.device)
-        _lib.check(lib.shr_data_to_model_compact(_ptr(depth), M, H, W, _ptr(ws), _stream()), "shr_data_to_model_compact")
+        return torch.empty(nbytes, dtype=torch.uint8, device=depth.device)
+
+
+def d2m_compact(depth):
+    """depth [M,H,W] -> workspace (uint8 tensor): every image's foreground pixels as tile-sorted point records, for
+    data_to_model_from_points (shr_data_to_model_compact)."""
+    ws = d2m_points_workspace(depth)
+    M, H, W = depth.shape
+    with _on(depth.device):
+        _lib.check(_lib.lib().shr_data_to_model_compact(_ptr(depth), M, H, W, _ptr(ws), _stream()), "shr_data_to_model_compact")
     return ws
 
 
@@ -322,13 +328,16 @@ class DataToModel(torch.autograd.Function):
 class MutualProjectionLossFused(torch.autograd.Function):
     """(cam, inv_cam [B,V,4,4], joints [B,V,J,3], observed [B*V,H,W], radii [J], index [B*V*V] int32, is_mv) ->
     (loss, projected depth [B*V*V,H,W]): MutualProjectionLoss (mesh/multiview_utility.py:90-130) as FIVE launches
-    -- view projection, fused render-and-compare, data->model, and the assembly kernel that weights, adds and
-    pulls both sphere gradients back to the joints (the whole backward is done in the forward: the losses are
-    plain sums) -- plus one scaling in backward.  The unfused wiring needed ~35 small torch launches around the
-    same three kernels."""
+    -- view projection, (compaction of the observed images into point lists,) fused render-and-compare, data->model,
+    and the assembly kernel that weights, adds and pulls both sphere gradients back to the joints (the whole backward
+    is done in the forward: the losses are plain sums) -- plus one scaling in backward.  The unfused wiring needed
+    ~35 small torch launches around the same three kernels.
+    points_ws: a point-list workspace of these very observed images (d2m_points_workspace); points_fresh = it is
+    still to be filled (done here, by the call that also projects the views: shr_mv_project_compact)."""
 
     @staticmethod
-    def forward(ctx, cam, inv_cam, joints, observed, radii, index, diag_index, is_mv, d2m_weight, points_ws=None):
+    def forward(ctx, cam, inv_cam, joints, observed, radii, index, diag_index, is_mv, d2m_weight, points_ws=None,
+                points_fresh=False):
         cam, inv_cam, joints = (t.detach().contiguous().float() for t in (cam, inv_cam, joints))
         observed, radii = observed.contiguous().float(), radii.contiguous().float()
         for t, name in ((cam, "camera_poses"), (inv_cam, "inv_camera_poses"), (joints, "joints"), (observed, "depth_maps"),
@@ -347,10 +356,21 @@ class MutualProjectionLossFused(torch.autograd.Function):
             ctx.mark_non_differentiable(depth)
             ctx.set_materialize_grads(False)
             return torch.zeros((), dtype=torch.float32, device=dev), depth
+        # every observed image is compared with V sphere sets (mesh/multiview_utility.py:99): compacted once into a
+        # point list (points_ws: the caller's -- MutualProjectionLoss keeps the lists while it is handed the same
+        # observations again: a second hourglass stack, a fitting loop)
+        two_step = points_ws is not None or d2m_two_step_pays(observed)
+        if two_step and points_ws is None:
+            points_ws, points_fresh = d2m_points_workspace(observed), True
         with _on(dev):
             spheres = torch.empty((N, J, 4), dtype=torch.float32, device=dev)
-            _lib.check(lib.shr_mutual_project_fwd(_ptr(cam), _ptr(inv_cam), _ptr(joints), _ptr(radii), B, V, J, _ptr(spheres),
-                                                  _stream()), "shr_mutual_project_fwd")
+            if two_step and points_fresh:
+                _lib.check(lib.shr_mv_project_compact(_ptr(cam), _ptr(inv_cam), _ptr(joints), _ptr(radii), B, V, J,
+                                                      _ptr(spheres), _ptr(observed), int(observed.shape[0]), H, W,
+                                                      _ptr(points_ws), _stream()), "shr_mv_project_compact")
+            else:
+                _lib.check(lib.shr_mutual_project_fwd(_ptr(cam), _ptr(inv_cam), _ptr(joints), _ptr(radii), B, V, J,
+                                                      _ptr(spheres), _stream()), "shr_mutual_project_fwd")
             depth = torch.empty((N, H, W), dtype=torch.float32, device=dev)
             sse = torch.empty((N, Rm), dtype=torch.float32, device=dev)
             gsp = torch.empty((N, Rm, J, 4), dtype=torch.float32, device=dev)
@@ -362,11 +382,8 @@ class MutualProjectionLossFused(torch.autograd.Function):
                 E = B * V
                 cen = spheres.index_select(0, diag_index)
                 cidx = index.index_select(0, diag_index)
-            if points_ws is not None or d2m_two_step_pays(observed):
-                # every observed image is compared with V sphere sets (mesh/multiview_utility.py:99): compacted once
-                # (points_ws: the caller's point lists of these very images, MutualProjectionLoss keeps them while it
-                # is handed the same observations again -- a second hourglass stack, a fitting loop)
-                ws = points_ws if points_ws is not None else d2m_compact(observed)
+            if two_step:
+                ws = points_ws
                 Rd = d2m_points_parts(E)
                 d2m = torch.empty((E, Rd), dtype=torch.float32, device=dev)
                 gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
@@ -394,9 +411,9 @@ class MutualProjectionLossFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_depth):
         if g_loss is None:
-            return (None,) * 10
+            return (None,) * 11
         (gj,) = ctx.saved_tensors
-        return None, None, gj * g_loss, None, None, None, None, None, None, None
+        return None, None, gj * g_loss, None, None, None, None, None, None, None, None
 
 
 class MutualProject(torch.autograd.Function):

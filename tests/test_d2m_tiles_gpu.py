@@ -307,3 +307,44 @@ def test_point_list_cache_follows_the_observations():
     ws2 = crit._points[2]
     d, _ = crit(cam, inv, joints, dms.clone(), True)              # another tensor with the same values
     assert crit._points[2] is not ws2 and float(d) == float(c)
+
+
+@pytest.mark.parametrize("B,V,S", [(2, 3, 64), (5, 3, 128), (1, 2, 32), (700, 1, 8)])
+def test_project_and_compact_in_two_launches_equals_the_two_calls(B, V, S):
+    """shr_mv_project_compact (the view projection clears the point lists' fill counters, the compaction follows without
+    its memset) == shr_mutual_project_fwd + shr_data_to_model_compact: same sphere records, same sums from the lists --
+    also into a workspace that is full of stale counters, and with more images than projected records (B*V > B*V*V*J
+    never happens with J >= 1, but M > the projection's thread count rounded to workgroups is covered by V = 1, S = 8)."""
+    from spherehand_amd import _lib, ops
+    lib = _lib.lib()
+    rs = np.random.RandomState(B * 100 + S)
+    J = 41 if B < 100 else 1
+    cam = np.tile(np.eye(4, dtype=np.float32), (B, V, 1, 1))
+    cam[..., :3, 3] = rs.uniform(-20, 20, (B, V, 3))
+    cam[..., :3, :3] += rs.uniform(-0.05, 0.05, (B, V, 3, 3)).astype(np.float32)
+    inv = np.linalg.inv(cam).astype(np.float32)
+    joints = rs.uniform(-60, 60, (B, V, J, 3)).astype(np.float32)
+    radii = rs.uniform(6, 20, J).astype(np.float32)
+    obs = dev(_observed(rs, B * V, S, S))
+    camd, invd, jd, rd = dev(cam), dev(inv), dev(joints), dev(radii)
+    want_sph = ops.MutualProject.apply(camd, invd, jd, rd).view(B * V * V, J, 4)
+    ws = ops.d2m_points_workspace(obs)
+    ws.fill_(0x5a)                                                # stale counters and points
+    sph = torch.empty_like(want_sph)
+    _lib.check(lib.shr_mv_project_compact(camd.data_ptr(), invd.data_ptr(), jd.data_ptr(), rd.data_ptr(), B, V, J, sph.data_ptr(),
+                                          obs.data_ptr(), B * V, S, S, ws.data_ptr(), ops._stream()), "shr_mv_project_compact")
+    assert np.array_equal(bits(sph), bits(want_sph))
+    index = dev((np.arange(B)[:, None, None] * V + np.arange(V)[None, None, :] + np.zeros((1, V, 1), np.int64)).reshape(-1).astype(np.int32))
+    N = B * V * V
+    out = []
+    for w in (ws, ops.d2m_compact(obs)):
+        loss = torch.empty((N, 1), device="cuda")
+        grad = torch.empty((N, 1, J, 3), device="cuda")
+        _lib.check(lib.shr_data_to_model_from_points(w.data_ptr(), B * V, index.data_ptr(), want_sph.data_ptr(), 4, rd.data_ptr(), N, J,
+                                                     S, S, 1, loss.data_ptr(), grad.data_ptr(), ops._stream()), "from_points")
+        out.append((bits(loss), bits(grad)))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    nb = ws.numel() - 4 * B * V
+    counts_a = ws[nb:].view(torch.int32).cpu().numpy()
+    counts_b = w[nb:].view(torch.int32).cpu().numpy()
+    assert np.array_equal(counts_a, counts_b) and int(counts_a.sum()) == int((obs <= 99).sum())
