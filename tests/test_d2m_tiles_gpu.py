@@ -333,7 +333,7 @@ def test_project_and_compact_in_two_launches_equals_the_two_calls(B, V, S):
     sph = torch.empty_like(want_sph)
     _lib.check(lib.shr_mv_project_compact(camd.data_ptr(), invd.data_ptr(), jd.data_ptr(), rd.data_ptr(), B, V, J, sph.data_ptr(),
                                           obs.data_ptr(), B * V, S, S, ws.data_ptr(), ops._stream()), "shr_mv_project_compact")
-    assert np.array_equal(bits(sph), bits(want_sph))
+    assert np.array_equal(bits(sph.cpu().numpy()), bits(want_sph.cpu().numpy()))
     index = dev((np.arange(B)[:, None, None] * V + np.arange(V)[None, None, :] + np.zeros((1, V, 1), np.int64)).reshape(-1).astype(np.int32))
     N = B * V * V
     out = []
@@ -342,9 +342,39 @@ def test_project_and_compact_in_two_launches_equals_the_two_calls(B, V, S):
         grad = torch.empty((N, 1, J, 3), device="cuda")
         _lib.check(lib.shr_data_to_model_from_points(w.data_ptr(), B * V, index.data_ptr(), want_sph.data_ptr(), 4, rd.data_ptr(), N, J,
                                                      S, S, 1, loss.data_ptr(), grad.data_ptr(), ops._stream()), "from_points")
-        out.append((bits(loss), bits(grad)))
+        out.append((bits(loss.cpu().numpy()), bits(grad.cpu().numpy())))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     nb = ws.numel() - 4 * B * V
     counts_a = ws[nb:].view(torch.int32).cpu().numpy()
     counts_b = w[nb:].view(torch.int32).cpu().numpy()
     assert np.array_equal(counts_a, counts_b) and int(counts_a.sum()) == int((obs <= 99).sum())
+
+
+@pytest.mark.parametrize("is_mv", [True, False])
+def test_render_and_compare_beside_the_point_search_gives_the_same_bits(is_mv):
+    """ops.MV_OVERLAP: the fused render-and-compare kernel on a side stream while the point search runs on the caller's
+    -- loss, projected depth and d loss / d joints are bit-identical to the one-stream order, call after call (the
+    joins are stream waits; a missing one would show as stale partial results)."""
+    from spherehand_amd import hand_model, ops
+    from spherehand_amd.datasets import SyntheticMultiviewDataset
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    mesh = hand_model.load_mesh()
+    ds = SyntheticMultiviewDataset(mesh, 24, 128, seed=4, device="cuda")
+    crit = MutualProjectionLoss(128, mesh).cuda()
+    crit.cache_points = False
+    cam, inv, dms = ds.cam.cuda(), ds.inv_cam.cuda(), ds.dms.cuda()
+    gen = torch.Generator("cuda").manual_seed(3)
+    keep = ops.MV_OVERLAP
+    try:
+        for it in range(6):
+            base = ds.joints.cuda() + 2.0 * torch.randn(ds.joints.shape, device="cuda", generator=gen)
+            out = []
+            for mode in (False, True):
+                ops.MV_OVERLAP = mode
+                j = base.clone().requires_grad_(True)
+                loss, proj = crit(cam, inv, j, dms, is_mv)
+                loss.backward()
+                out.append((loss.detach().clone(), proj.detach().clone(), j.grad.clone()))
+            assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2]), it
+    finally:
+        ops.MV_OVERLAP = keep
