@@ -323,10 +323,12 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     # the data->model term compacts every observed image into a point list first; MutualProjectionLoss keeps the lists
     # while it is handed the same observations again (a second hourglass stack, a fitting loop).  Training feeds fresh
     # observations every step: the headline number is measured with the cache OFF, the cached one beside it.
+    # (50 steps per timed batch: the events bracket the host's way to the first launch of a batch too -- one step's worth
+    # of Python before the GPU has anything -- which 10-step batches charged at a tenth per step)
     crit.cache_points = False
-    t_mv = torch_us(mv_step, 10)
+    t_mv = torch_us(mv_step, 50, 3, 10)
     crit.cache_points = True
-    t_mv_cached = torch_us(mv_step, 10)
+    t_mv_cached = torch_us(mv_step, 50, 3, 10)
     crit.cache_points = False
     with torch.no_grad():
         _, pts = crit.mutual_projection(cam, inv, joints.detach())
@@ -443,7 +445,10 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     with torch.cuda.graph(g, stream=stream):
         chain()
     t_chain = mean_launch_us(lambda _s: g.replay(), stream, 100, 3, 10)
-    t_eager = mean_launch_us(lambda _s: chain(), stream, 50, 3, 30)   # (30 warm-up iterations: allocator and clocks settled)
+    # (host-bound: timed after 0.6 s of the same loop -- the host cores idle at 1.2 GHz while the graph replays above only
+    # wait for the GPU, and take a few tenths of a second of load to clock up: 208 -> 128 -> 104 us over three
+    # consecutive 500-iteration runs of tools/prof_eager.py on one box)
+    t_eager = mean_launch_us(lambda _s: chain(), stream, 50, 3, 30, warm_ms=600.0)
     sec["pose_to_depth_to_pose_us"] = {"graph_replay_us": round(t_chain, 2), "eager_autograd_us": round(t_eager, 1),
                                        "crops_per_s_graph": round(BATCH / (t_chain * 1e-6), 1),
                                        "chain": "pose[256,26] -> fk_fwd -> key-point skinning -> sphere raster fwd (+ owner map) "

@@ -28,6 +28,32 @@ def build(force=False):
     return _SO
 
 
+# ---- oracle/_ref: the reference's own triangle kernel, compiled for gfx950 (oracle/Makefile, target ref_tri) ----------
+REF_CU = "/root/reference/mesh/cuda_kernel/depth_rasterization_cuda_kernel.cu"
+_REF_DIR = os.path.join(_HERE, "_ref")
+
+
+def build_ref():
+    """Builds oracle/_ref/libref_tri*.so when the reference is there (the build container); the GPU box gets the
+    built files with the snapshot.  Returns the path of the build of record, or None."""
+    so = os.path.join(_REF_DIR, "libref_tri.so")
+    if os.path.exists(REF_CU):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref_tri"])
+    return so if os.path.exists(so) else None
+
+
+def ref_tri_lib(contract=False):
+    """ctypes handle of the reference kernel build (contract=False: -ffp-contract=off, every operation as written;
+    True: clang's default contraction), or None when oracle/_ref was not built.  Needs a GPU to call."""
+    so = os.path.join(_REF_DIR, "libref_tri_contract.so" if contract else "libref_tri.so")
+    if not os.path.exists(so):
+        return None
+    h = ctypes.CDLL(so)
+    h.ref_tri_forward.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    h.ref_tri_forward.restype = ctypes.c_int
+    return h
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -12,10 +12,17 @@
  *     reference generated in the build container (tests/golden/ (the .npz files), made by
  *     tests/golden/make_goldens_*.py) -- bit-exact for the depth maps,
  *     tolerance for summed quantities (stated in the tests).
- *   - oracle_tri_raster_fwd: PARITY UNPINNED.  The reference kernel is CUDA
- *     (needs nvcc + CUDA headers, absent here; the repo holds no golden
- *     vectors for it).  It is cross-checked against an independent numpy
- *     restatement only (tests/test_oracle_tri.py).
+ *   - oracle_tri_raster_fwd: PINNED (round 4) against the reference's own
+ *     device code executed on the MI355X: oracle/_ref/libref_tri.so is
+ *     `kernel` + `atomicMin` of depth_rasterization_cuda_kernel.cu:1-113
+ *     compiled for gfx950 where the file lies (oracle/Makefile, target
+ *     ref_tri; -ffp-contract=off: every operation as the source writes it);
+ *     tests/test_tri_reference_gpu.py: bit-exact on the hand mesh at 640x640,
+ *     the quirk cases and random soups.  NOT reproducible here: nvcc's
+ *     default mul+add fusion (-fmad=true) -- its pattern is the compiler's;
+ *     clang's own fusion moves 2.6 % of the covered pixels by more than 1e-4
+ *     relative (same test file).  Also cross-checked against an independent
+ *     numpy restatement (tests/test_oracle_tri.py).
  *
  * Who may use this file: tests/, __graft_entry__.smoke(), bench.py's
  * cpu_baseline leg.  The product path never links or loads it.
@@ -276,7 +283,8 @@ int oracle_data_to_model_bwd(const float *depth, const float *centres, const flo
  *   max/min(double,double) are fmax/fmin (a NaN operand is dropped);
  *   double -> int32 conversion truncates toward zero and saturates (NaN -> 0);
  *   literals `0.`, `1.`, `width - 1.` promote the expression to double;
- *   no FMA contraction (nvcc would contract: see DESIGN.md, "unpinned").    */
+ *   no FMA contraction (the reference kernel compiled the same way gives these
+ *   bits on the GPU; nvcc's default would contract: DESIGN.md section 3).     */
 static inline int32_t cvt_rz_sat_i32(double d) {
   if (d != d) return 0;
   if (d >= 2147483647.0) return 2147483647;

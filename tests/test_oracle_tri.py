@@ -1,7 +1,8 @@
 """CPU: the triangle-raster oracle (C) against an INDEPENDENT numpy restatement of
 the reference kernel, and the oracle's skinning / camera / resize against the
-reference's goldens.  The kernel itself is parity-unpinned (no CUDA here): these
-tests make the two restatements agree bit for bit."""
+reference's goldens.  These tests make the two restatements agree bit for bit on
+the CPU; the pin to the reference's own kernel is tests/test_tri_reference_gpu.py
+(oracle/_ref: its device code compiled for gfx950, run on the MI355X)."""
 import numpy as np
 
 from conftest import bits, golden

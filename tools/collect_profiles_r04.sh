@@ -30,6 +30,10 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write_mvloss" -o mv -- python tools/prof_mvloss.py > "$O/pmc_write_mvloss.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc $SQA --output-format csv -d "$O/sq_a_mvloss" -o mv -- python tools/prof_mvloss.py > "$O/sq_a_mvloss.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc $SQB --output-format csv -d "$O/sq_b_mvloss" -o mv -- python tools/prof_mvloss.py > "$O/sq_b_mvloss.log" 2>&1
+# (b2') the same step untraced: wall per step with the two terms on one stream / side by side (the module's default) / on
+# unchanged observations; and the A/B of the two orders in one process
+{ timeout 120 python tools/prof_mvloss.py; OVERLAP=1 timeout 120 python tools/prof_mvloss.py; OVERLAP=1 CACHE=1 timeout 120 python tools/prof_mvloss.py;
+  timeout 200 python tools/ab_mvloss_overlap.py; } > "$O/mvloss_wall.log" 2>&1
 # (b3) the headline launches from a C loop (tools/cloop.c), unprofiled and under the tracer: the durations `frac_rocprof` uses
 timeout 200 python tools/prof_cloop.py > "$O/cloop_plain.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/cloop" -o cloop -- python tools/prof_cloop.py > "$O/cloop_traced.log" 2>&1

@@ -57,6 +57,10 @@ if os.path.isdir(os.path.join(O, "pmc_fetch_mvloss")):
                   "MutualProjectionLoss forward + backward, 1152 crops @256x256 (384 observed images of 256 KB = 100.7 MB), fresh "
                   "observations every call.  bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 half-count correction).")
     json.dump(d, open(os.path.join(P, "r04_pmc_traffic_config5_loss.json"), "w"), indent=1)
+if os.path.exists(os.path.join(O, "mvloss_wall.log")):
+    with open(os.path.join(O, "mvloss_wall.log")) as f, open(os.path.join(P, "r04_config5_loss_wall.txt"), "w") as g:
+        g.write("# tools/prof_mvloss.py (20 steps each) and tools/ab_mvloss_overlap.py (200 steps each), untraced\n")
+        g.writelines(l for l in f if "us" in l and "amdgpu.ids" not in l)
 if os.path.isdir(os.path.join(O, "stats_mvloss")):
     shr_rows(os.path.join(O, "stats_mvloss", "mv_kernel_stats.csv"), os.path.join(P, "r04_config5_loss_kernel_stats.csv"), ours)
 if os.path.isdir(os.path.join(O, "cloop")):
