@@ -85,7 +85,7 @@ def test_reference_kernel_quirks(ref, oracle):
     assert np.all(run_ref(ref, np.zeros((2, 0, 3, 3), np.float32), 8, 8) == 1000.0)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(40))
 def test_reference_kernel_on_random_soups(ref, oracle, seed):
     import depth_rasterization
     rs = np.random.RandomState(100 + seed)
