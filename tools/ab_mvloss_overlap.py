@@ -19,7 +19,7 @@ def run(tag):
     for _ in range(10): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(200): l = step()
-    torch.cuda.synchronize(); print("%s: %.1f us  loss %.9g" % (tag, (time.perf_counter() - t0) / 200 * 1e6, float(l)))
+    torch.cuda.synchronize(); print("%s: %.1f us  loss %.9g" % (tag, (time.perf_counter() - t0) / 200 * 1e6, float(l.detach())))
 for r in range(3):
     for mode, tag in ((False, "one stream"), (True, "render-and-compare on a side stream beside the point search")):
         ops.MV_OVERLAP = mode; run(tag)

@@ -60,7 +60,7 @@ if os.path.isdir(os.path.join(O, "pmc_fetch_mvloss")):
 if os.path.exists(os.path.join(O, "mvloss_wall.log")):
     with open(os.path.join(O, "mvloss_wall.log")) as f, open(os.path.join(P, "r04_config5_loss_wall.txt"), "w") as g:
         g.write("# tools/prof_mvloss.py (20 steps each) and tools/ab_mvloss_overlap.py (200 steps each), untraced\n")
-        g.writelines(l for l in f if "us" in l and "amdgpu.ids" not in l)
+        g.writelines(l for l in f if l.startswith(("MutualProjectionLoss", "one stream", "render-and-compare")))
 if os.path.isdir(os.path.join(O, "stats_mvloss")):
     shr_rows(os.path.join(O, "stats_mvloss", "mv_kernel_stats.csv"), os.path.join(P, "r04_config5_loss_kernel_stats.csv"), ours)
 if os.path.isdir(os.path.join(O, "cloop")):
