@@ -160,3 +160,27 @@ def test_reference_kernel_duration_beside_ours(ref, capsys):
         print("\n[256 crops x %d faces @640x640 on this GPU] reference kernel (fill + <<<B*F, 1>>>): %.2f ms; tri_raster_kernel: %.3f ms (%.0f x)"
               % (fv.shape[1], min(ts) * 1e3, ours, min(ts) * 1e3 / ours))
     assert ours < min(ts) * 1e3
+
+
+def test_reference_kernel_randomised_slice(ref, oracle):
+    """A bounded randomised run (the generator of tools/fuzz.py's `tri` family, fixed seed): every case three ways."""
+    import depth_rasterization
+    rs = np.random.RandomState(2024)
+    t0, cases = time.time(), 0
+    while cases < 400 and time.time() - t0 < 25.0:
+        W = int(rs.choice([5, 16, 33, 96, 200, 320])); H = int(rs.choice([7, 16, 40, 72, 160, 256]))
+        B = int(rs.randint(1, 4)); F = int(rs.choice([1, 31, 33, 64, 200, 500]))
+        c = rs.uniform(-0.2 * W, 1.2 * W, (B, F, 1, 1)) * np.array([1.0, H / W])
+        spread = rs.choice([0.7, 3.0, 12.0, 60.0], (B, F, 1, 1))
+        fv = np.concatenate([c + rs.normal(0, 1, (B, F, 3, 2)) * spread, rs.uniform(-50, 50, (B, F, 3, 1))], -1).astype(np.float32)
+        if rs.rand() < 0.3:
+            fv[:, :, :, 0] = np.round(fv[:, :, :, 0])
+        if rs.rand() < 0.2:
+            fv[:, ::7, 1] = fv[:, ::7, 0]
+        if rs.rand() < 0.1:
+            fv[:, ::5, 2, 2] = 0.0                               # a vertex at z = 0
+        r = run_ref(ref, fv, W, H)
+        assert np.array_equal(bits(r), bits(oracle.tri_raster_fwd(fv, W, H))), (cases, W, H, B, F)
+        assert np.array_equal(bits(r), bits(depth_rasterization.forward(W, H, dev(fv)).cpu().numpy())), (cases, W, H, B, F)
+        cases += 1
+    assert cases >= 50
