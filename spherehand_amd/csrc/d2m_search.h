@@ -184,43 +184,48 @@ __device__ __forceinline__ void d2m_search_core(const D2mCtx &cx, const float (&
       }
     }
   }
+  // The search above compares candidates through v_sqrt_f32 (<= 1 ulp); the point's TERM is then evaluated once more
+  // for its owner with a correctly rounded root and the oracle's association -- | sqrtf((dx dx + dy dy) + dz dz) - r |,
+  // mesh/render.py:131-137 on a host -- so that loss and gradient are the reference's arithmetic wherever the owner is
+  // (two spheres within an ulp of each other can swap; the term then differs by that ulp).  sqrt_rn() is exact on
+  // [0.01, 1e12]; a squared distance outside it (a point within 0.1 mm of a centre, or 1 km away, or not finite) takes
+  // hipcc's IEEE sqrtf -- behind a wave-uniform branch: as a select, its ~20-instruction expansion ran for every point.
+  float t2s[K], dists[K];
+  bool wide = false;
+#pragma unroll
+  for (int i = 0; i < K; i++) {
+    const float4 c = s_c[bj[i]];
+    const float dx = px[i] - c.x, dy = py[i] - c.y, dz = pz[i] - c.z;
+    t2s[i] = (dx * dx + dy * dy) + dz * dz;
+    dists[i] = sqrt_rn(t2s[i]);
+    wide |= !(t2s[i] >= 0.01f && t2s[i] <= 1e12f);
+  }
+  if (__ballot(wide) != 0ull) {
+#pragma unroll
+    for (int i = 0; i < K; i++) dists[i] = (t2s[i] >= 0.01f && t2s[i] <= 1e12f) ? dists[i] : __builtin_sqrtf(t2s[i]);
+  }
   bool nan = false;
   int lsum = 0;                                       // (K terms of at most 50 * 2^20 < 2^26 each: 32 bits hold them)
   static_assert(K <= 16, "the lane's loss terms are added in 32 bits first");
+  float term[K];
 #pragma unroll
   for (int i = 0; i < K; i++) {
-    nan |= valid[i] && best[i] != best[i];            // torch.clamp keeps NaN: the crop's loss is NaN
-    lsum += (valid[i] && best[i] == best[i]) ? __float2int_rn(fminf(fmaxf(best[i], 0.f), 50.f) * kLossScale) : 0;
+    term[i] = fabsf(dists[i] - s_c[bj[i]].w);
+    nan |= valid[i] && term[i] != term[i];            // torch.clamp keeps NaN: the crop's loss is NaN
+    lsum += (valid[i] && term[i] == term[i]) ? __float2int_rn(fminf(fmaxf(term[i], 0.f), 50.f) * kLossScale) : 0;
   }
   loss_fx += (long long)lsum;
   if (nan) *cx.s_nan = 1;
   if (WANT_GRAD) {
     int g[K][3];
     bool live[K];
-    // the sign decides the gradient's direction: correctly rounded root, as a host sqrtf.  sqrt_rn() is exact on
-    // [0.01, 1e12]; a squared distance outside it (a point within 0.1 mm of a centre, or 1 km away) takes hipcc's IEEE
-    // sqrtf -- behind a wave-uniform branch: as a select, its ~20-instruction expansion ran for every point
-    float t2s[K], dists[K];
-    bool wide = false;
-#pragma unroll
-    for (int i = 0; i < K; i++) {
-      const float4 c = s_c[bj[i]];
-      const float dx = px[i] - c.x, dy = py[i] - c.y, dz = pz[i] - c.z;
-      t2s[i] = (dx * dx + dy * dy) + dz * dz;
-      dists[i] = sqrt_rn(t2s[i]);
-      wide |= !(t2s[i] >= 0.01f && t2s[i] <= 1e12f);
-    }
-    if (__ballot(wide) != 0ull) {
-#pragma unroll
-      for (int i = 0; i < K; i++) dists[i] = (t2s[i] >= 0.01f && t2s[i] <= 1e12f) ? dists[i] : __builtin_sqrtf(t2s[i]);
-    }
 #pragma unroll
     for (int i = 0; i < K; i++) {
       const float4 c = s_c[bj[i]];
       const float dx = px[i] - c.x, dy = py[i] - c.y, dz = pz[i] - c.z;
       const float dist = dists[i];
       const float t = dist - c.w;
-      live[i] = valid[i] && best[i] <= 50.f && dist != 0.f && t != 0.f && dist < __builtin_inff();
+      live[i] = valid[i] && term[i] <= 50.f && dist != 0.f && t != 0.f && dist < __builtin_inff();
       const float k = (t > 0.f ? -kGradScale : kGradScale) * __builtin_amdgcn_rcpf(dist);
       g[i][0] = live[i] ? __float2int_rn(k * dx) : 0;
       g[i][1] = live[i] ? __float2int_rn(k * dy) : 0;

@@ -22,7 +22,9 @@ def test_data_to_model_vs_reference_and_oracle(oracle):
         dms, joints, radii = g[t + "_dms"], g[t + "_joints"], g[t + "_radii"]
         loss_sum, grad = ops.data_to_model(dev(dms), dev(joints), dev(radii), want_grad=True)
         o_sum = oracle.data_to_model_fwd(dms, joints, radii)
-        assert np.abs(loss_sum.cpu().numpy() - o_sum).max() <= 1e-5 * np.abs(o_sum).max()
+        # (every point's term is the oracle's arithmetic for its owner; the sums are integers of 2^-20 mm: what is left
+        # is the fp32 rounding of the per-crop result)
+        assert np.abs(loss_sum.double().cpu().numpy() - o_sum).max() <= 2e-7 * np.abs(o_sum).max()
         loss = loss_sum.double().sum().item() / dms.size
         assert abs(loss - float(g[t + "_loss"])) <= 1e-5 * float(g[t + "_loss"])
         o_grad = oracle.data_to_model_bwd(dms, joints, radii) * dms.size     # oracle: grad of the mean
@@ -47,7 +49,7 @@ def test_data_to_model_random(oracle, N, J, H, W):
     radii = rs.uniform(5, 25, J).astype(np.float32)
     loss_sum, grad = ops.data_to_model(dev(depth), dev(centres), dev(radii), want_grad=True)
     o_sum = oracle.data_to_model_fwd(depth, centres, radii)
-    assert np.abs(loss_sum.cpu().numpy() - o_sum).max() <= 1e-5 * np.abs(o_sum).max() + 1e-6
+    assert np.abs(loss_sum.double().cpu().numpy() - o_sum).max() <= 2e-7 * np.abs(o_sum).max() + 1e-6
     o_grad = oracle.data_to_model_bwd(depth, centres, radii) * depth.size
     assert np.abs(grad.cpu().numpy() - o_grad).max() <= 1e-5 * np.abs(o_grad).max() + 1e-6
 

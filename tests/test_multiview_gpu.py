@@ -140,7 +140,7 @@ def test_config5_full_size_against_the_oracle(oracle):
                        order against the oracle's fp64 sums);
       fused            render-and-compare: projected depth bits, per-crop sum of squares (2e-5) and its gradient
                        against the oracle's backward of 2 (depth - observed);
-      data -> model    per-crop loss sums (1e-5) and unit gradients (1e-5 of the largest entry, but for the unit vectors of
+      data -> model    per-crop loss sums (2e-7: fp32 output rounding) and unit gradients (1e-5 of the largest entry, but for the unit vectors of
                        pixels equidistant from two spheres) through the image index;
       the criterion    MutualProjectionLoss(is_mv=True): loss (1e-4) and d loss / d joints (1e-3 of the largest entry)
                        against the value ASSEMBLED from the oracle's pieces with the reference's weights (9 x MSE +
@@ -193,8 +193,10 @@ def test_config5_full_size_against_the_oracle(oracle):
     dg_ref = oracle.data_to_model_bwd(exp_h, sph_h[..., :3], radii.cpu().numpy()).astype(np.float64) * exp_h.size
     # (the oracle returns d mean / d centres; the kernel the unit gradient of the per-crop sums)
     dl, dg = ops.data_to_model(obs, cen, radii, want_grad=True, depth_index=index)
-    assert np.abs(dl.double().cpu().numpy() - dl_ref).max() <= 1e-5 * dl_ref.max()
-    # (a pixel equidistant from two spheres to within an ulp of the root -- v_sqrt_f32 in the kernel, sqrtf in the oracle --
+    # (every point's term is the oracle's arithmetic for its owner -- a correctly rounded root, the host's association --
+    # and the sums are integers: the per-crop results agree to the fp32 rounding of the output)
+    assert np.abs(dl.double().cpu().numpy() - dl_ref).max() <= 2e-7 * dl_ref.max()
+    # (a pixel equidistant from two spheres to within an ulp of the root -- the search compares through v_sqrt_f32 --
     # may be assigned to either: the loss is continuous there, the pixel's UNIT vector moves between two gradient
     # entries.  Ten million foreground pixels hold a few of those: entries off by more than the rounding bar must be
     # rare and off by no more than a couple of unit vectors)
