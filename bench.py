@@ -38,6 +38,7 @@ measure the kernels, not the ramp (`config.clock_warmup_ms`).
 """
 import argparse
 import ctypes
+import gc
 import json
 import os
 import sys
@@ -445,11 +446,15 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     with torch.cuda.graph(g, stream=stream):
         chain()
     t_chain = mean_launch_us(lambda _s: g.replay(), stream, 100, 3, 10)
-    # (host-bound: timed after 0.6 s of the same loop -- the host cores idle at 1.2 GHz while the graph replays above only
-    # wait for the GPU, and take a few tenths of a second of load to clock up: 208 -> 128 -> 104 us over three
-    # consecutive 500-iteration runs of tools/prof_eager.py on one box)
-    t_eager = mean_launch_us(lambda _s: chain(), stream, 50, 3, 30, warm_ms=600.0)
+    # (host-bound.  The host cores idle at 1.2 GHz while the graph replays above only wait for the GPU, and a process can
+    # sit for half a second on a slow or shared core before the scheduler moves it -- 161 us per iteration for the first
+    # 3000 iterations, 103 after, in one of three consecutive runs of the same loop on one box: timed after 1.2 s of
+    # the loop itself, seven 50-iteration batches, the MEDIAN batch reported with the fastest and slowest beside it)
+    eager_batches = sorted(mean_launch_us(lambda _s: chain(), stream, 50, 1, 30 if i == 0 else 0, warm_ms=1200.0 if i == 0 else 0.0)
+                           for i in range(7))
+    t_eager = eager_batches[3]
     sec["pose_to_depth_to_pose_us"] = {"graph_replay_us": round(t_chain, 2), "eager_autograd_us": round(t_eager, 1),
+                                       "eager_fastest_slowest_batch_us": [round(eager_batches[0], 1), round(eager_batches[-1], 1)],
                                        "crops_per_s_graph": round(BATCH / (t_chain * 1e-6), 1),
                                        "chain": "pose[256,26] -> fk_fwd -> key-point skinning -> sphere raster fwd (+ owner map) "
                                                 "-> bwd -> skinning bwd -> fk_bwd -> grad pose[256,26]"}
@@ -567,6 +572,11 @@ def main():
 
     from spherehand_amd import _lib
     lib = _lib.lib()
+    # Everything imported so far (torch: about a million tracked objects) goes to the permanent generation: a full
+    # collection of it in the middle of a timed loop is a 40-ms host stall with the GPU idle (tools' A/B runs: one
+    # 200-step run in six read 470 us per step instead of 276).  Collections stay ON; they only stop re-walking those.
+    gc.collect()
+    gc.freeze()
     spheres, grad = make_inputs(rank, dev)
     depth = torch.empty(BATCH, S, S, device=dev)
     owner = torch.empty(BATCH, S, S, device=dev, dtype=torch.uint8)

@@ -13,6 +13,7 @@ network/engine.py (Engine :52-477) re-designed for one process per GPU:
     optimizer_state_dict} (engine.py:438-460), written by rank 0 without the DDP
     `module.` prefix, so either side's files load in the other.
 """
+import gc
 import json
 import os
 import random
@@ -394,6 +395,10 @@ class Engine:
     # ------------------------------------------------------------------ drivers
     def train(self):
         last = None
+        # (the modules, data sets and torch itself are here to stay: out of the garbage collector's way -- a full
+        # collection walks ~1e6 objects, a 40-ms stall of the launching thread every few hundred steps)
+        gc.collect()
+        gc.freeze()
         for epoch in range(self.starting_epoch, self.epoch):
             if self.with_real and self.with_synt:
                 last = self._epoch_with_both(Mode.Train, epoch)
