@@ -1,5 +1,5 @@
 """A/B on one box: MutualProjectionLoss step with the render-and-compare kernel on a side stream beside the point search."""
-import os, sys, time, torch
+import gc, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spherehand_amd import hand_model, ops
 from spherehand_amd.datasets import SyntheticMultiviewDataset
@@ -20,6 +20,7 @@ def run(tag):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(200): l = step()
     torch.cuda.synchronize(); print("%s: %.1f us  loss %.9g" % (tag, (time.perf_counter() - t0) / 200 * 1e6, float(l.detach())))
+gc.collect(); gc.freeze()   # (a full collection of torch's objects is a 40-ms host stall: one run in six read 470 us)
 for r in range(3):
     for mode, tag in ((False, "one stream"), (True, "render-and-compare on a side stream beside the point search")):
         ops.MV_OVERLAP = mode; run(tag)

@@ -1,5 +1,5 @@
 """MutualProjectionLoss fwd+bwd at the per-GPU share of BASELINE config 5 (B=128 samples, V=3, S=256 -> 1152 crops)."""
-import os, sys, time, torch
+import gc, os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from spherehand_amd import hand_model
@@ -20,6 +20,7 @@ def step():
     joints.grad = None
     loss, _ = crit(cam, inv, joints, real, True)
     loss.backward()
+gc.collect(); gc.freeze()
 for _ in range(5): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): step()
