@@ -9,11 +9,14 @@ What is the reference's and what is not:
     face gather with the right-hand winding swap, clamp(max=100) and the bilinear
     640 -> S downsample are the REFERENCE's code (mesh/pointTransformation.py:39-46,
     :84-99; mesh/render.py:286, :298-311, :328-331).
-  * depth_rasterization.forward is the reference's CUDA extension, unbuildable in
-    this image (needs nvcc + CUDA headers).  For `raw640` / `depth_S` below the
-    extension slot is filled with OUR CPU oracle (oracle_tri_raster_fwd).  Those
-    arrays therefore pin everything AROUND the kernel, not the kernel: the
-    triangle kernel itself stays "parity unpinned" (DESIGN.md section 3).
+  * depth_rasterization.forward is the reference's CUDA extension; it cannot run in
+    this container (no GPU).  For `raw640` / `depth_S` below the extension slot is
+    filled with OUR CPU oracle (oracle_tri_raster_fwd): these arrays pin everything
+    AROUND the kernel.  The kernel itself is pinned on the GPU box since round 4:
+    tests/test_tri_reference_gpu.py runs the reference's own device code
+    (oracle/_ref/libref_tri.so) on `face_vertices` of this file and requires its
+    image to equal `raw640_first` -- and the oracle's, and the HIP kernel's -- bit
+    for bit.
 """
 import os
 import sys
