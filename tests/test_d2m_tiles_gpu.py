@@ -378,3 +378,33 @@ def test_render_and_compare_beside_the_point_search_gives_the_same_bits(is_mv):
             assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2]), it
     finally:
         ops.MV_OVERLAP = keep
+
+
+def test_loss_on_a_callers_own_stream_with_the_side_stream_beside_it():
+    """The caller's current stream is not the default one: the launches follow it (ops._stream), the side stream forks
+    from and joins it -- same bits as on the default stream, call after call."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.datasets import SyntheticMultiviewDataset
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    mesh = hand_model.load_mesh()
+    ds = SyntheticMultiviewDataset(mesh, 12, 128, seed=6, device="cuda")
+    crit = MutualProjectionLoss(128, mesh).cuda()
+    cam, inv, dms = ds.cam.cuda(), ds.inv_cam.cuda(), ds.dms.cuda()
+    base = ds.joints.cuda() + 1.0
+    want = []
+    for k in range(3):
+        j = (base + 0.3 * k).requires_grad_(True)
+        loss, proj = crit(cam, inv, j, dms, True)
+        loss.backward()
+        want.append((loss.detach().clone(), proj.detach().clone(), j.grad.clone()))
+    torch.cuda.synchronize()
+    own = torch.cuda.Stream()
+    own.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(own):
+        for k in range(3):
+            j = (base + 0.3 * k).requires_grad_(True)
+            loss, proj = crit(cam, inv, j, dms, True)
+            loss.backward()
+            got = (loss.detach(), proj.detach(), j.grad)
+            own.synchronize()
+            assert all(torch.equal(a, b) for a, b in zip(got, want[k])), k
