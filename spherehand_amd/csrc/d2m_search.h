@@ -185,7 +185,7 @@ __device__ __forceinline__ void d2m_search_core(const D2mCtx &cx, const float (&
     }
   }
   // The search above compares candidates through v_sqrt_f32 (<= 1 ulp); the point's TERM is then evaluated once more
-  // for its owner with a correctly rounded root and the oracle's association -- | sqrtf((dx dx + dy dy) + dz dz) - r |,
+  // for its owner with a correctly rounded root and the reference's association -- | sqrtf((dx dx + dy dy) + dz dz) - r |,
   // mesh/render.py:131-137 on a host -- so that loss and gradient are the reference's arithmetic wherever the owner is
   // (two spheres within an ulp of each other can swap; the term then differs by that ulp).  sqrt_rn() is exact on
   // [0.01, 1e12]; a squared distance outside it (a point within 0.1 mm of a centre, or 1 km away, or not finite) takes
