@@ -331,6 +331,13 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     crit.cache_points = True
     t_mv_cached = torch_us(mv_step, 50, 3, 10)
     crit.cache_points = False
+
+    def same_view_step():    # is_mv = False: the V same-view pairs only -- what the reference trains with after its
+        joints.grad = None   # first 1500 iterations (network/engine.py:361); all V*V projections are still returned
+        loss, _ = crit(cam, inv, joints, real, False)
+        loss.backward()
+    t_sv = torch_us(same_view_step, 50, 3, 10)
+    crit.cache_points = False
     with torch.no_grad():
         _, pts = crit.mutual_projection(cam, inv, joints.detach())
     obs = real.view(B5 * 3, S5, S5).contiguous()
@@ -366,6 +373,7 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
         "mutual_projection_loss_is": "forward + backward of MutualProjectionLoss on fresh observations every call (point-list "
                                      "cache off: what a training step pays); _same_observations_us = the same with the cache "
                                      "on and the observed images unchanged between calls (second hourglass stack, fitting loop)",
+        "mutual_projection_loss_same_view_pairs_only_fwd_bwd_us": round(t_sv, 1),
         "crops_per_s": round(n5 / (t_mv * 1e-6), 1),
         # two-step data->model (the path the loss takes): images read once (4 S^2 each) and their foreground written as
         # 8-byte points; the search reads every crop's image list (8 B per point) + the 41 records

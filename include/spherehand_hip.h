@@ -294,7 +294,10 @@ int shr_mv_project_compact(const float *cam, const float *inv_cam, const float *
  * same-view pairs, entry b*V+i):
  *   loss[0] = 9 MSE + d2m_weight * 9 d2m over all pairs (is_mv), or 3 x the same over the V same-view pairs,
  *   grad_joints[B,V,J,3] (may be NULL) = d loss / d joints (both sphere gradients weighted, added and pulled back
- *   through the detached view transforms).  fp64 accumulation of the scalar in a fixed order: deterministic. */
+ *   through the detached view transforms).  fp64 accumulation of the scalar in a fixed order: deterministic.
+ * is_mv: 1 = all pairs; 0 = the same-view pairs, picked out of sse_part / grad_spheres_part of all N pairs; 2 = the
+ * same-view pairs with sse_part [B*V][Rm] / grad_spheres_part [B*V][Rm][J][4] holding those pairs only (entry b*V+i:
+ * the caller ran shr_sphere_raster_mse on them alone) -- same values as 0. */
 int shr_mv_loss_combine(const float *cam, const float *inv_cam, const float *sse_part,
                         const float *grad_spheres_part, int Rm, const float *d2m_part,
                         const float *grad_d2m_part, int Rd, int B, int V, int J, int H, int W, int is_mv,

@@ -80,7 +80,8 @@ __global__ void mutual_project_bwd_kernel(const float *__restrict__ cam, const f
 // and grad_joints[b,i,k] = sum_j R(b,i,j)^T (w_m * d sse / d centre + w_d * d d2m / d centre) -- the sphere
 // gradients of the two kernels (R partials each) weighted, added and pulled back through the view transforms
 // (constants: detached at :68; the radii are buffers).  The loss is accumulated in fp64 in a fixed order.
-// d2m_part / gd2m_part hold one entry per pair (is_mv) or per DIAGONAL pair b*V+i (else).
+// d2m_part / gd2m_part hold one entry per pair (is_mv) or per DIAGONAL pair b*V+i (else); is_mv == 2: the same-view
+// pairs only AND sse_part / gsp_part compacted the same way (the caller ran the fused kernel on those pairs alone).
 __global__ void __launch_bounds__(256)
 mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ inv_cam,
                        const float *__restrict__ sse_part, const float4 *__restrict__ gsp_part, int Rm,
@@ -96,7 +97,8 @@ mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ 
     // (32-bit indices: the launcher keeps B V V J below 2^31 and the partial counts small; four loads in flight per
     // thread -- one element per iteration with 64-bit divisions for its pair chained ~20 round trips and ~60 long
     // divisions per thread: 11 us for config 5's 1152 pairs)
-    const int N = B * V * V, NE = N * Rm;
+    // (is_mv == 2: the same-view pairs only, and sse_part / gsp_part hold just those B*V entries, like the d2m parts)
+    const int N = B * V * V, NE = (is_mv == 2 ? B * V : N) * Rm;
     double am = 0.0, ad = 0.0;
     for (int e0 = threadIdx.x; e0 < NE; e0 += 1024) {
       float v[4];
@@ -104,7 +106,7 @@ mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ 
       for (int u = 0; u < 4; u++) {
         const int e = e0 + 256 * u;
         bool take = e < NE;
-        if (take && !is_mv) {
+        if (take && is_mv == 0) {
           const int n = e / Rm, j = n % V, i = (n / V) % V;
           take = i == j;
         }
@@ -112,7 +114,7 @@ mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ 
       }
       am += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
     }
-    const int DE = (is_mv ? N : B * V) * Rd;     // d2m entries: every pair, or the same-view pairs only
+    const int DE = (is_mv == 1 ? N : B * V) * Rd;     // d2m entries: every pair, or the same-view pairs only
     for (int e0 = threadIdx.x; e0 < DE; e0 += 1024) {
       float v[4];
 #pragma unroll
@@ -140,15 +142,16 @@ mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ 
   const int i = in ? (idx / J) % V : 0;
   const int b = in ? idx / (J * V) : 0;
   float g[3] = {0.f, 0.f, 0.f};
-  if (in && j < V && (is_mv || j == i)) {
+  if (in && j < V && (is_mv == 1 || j == i)) {
     const long long n = ((long long)b * V + i) * V + j;
+    const long long e = is_mv == 1 ? n : (long long)b * V + i;
+    const long long nm = is_mv == 2 ? e : n;
     float gx = 0.f, gy = 0.f, gz = 0.f;
     for (int r = 0; r < Rm; r++) {
-      const float4 a = gsp_part[(n * Rm + r) * J + k];
+      const float4 a = gsp_part[(nm * Rm + r) * J + k];
       gx += a.x; gy += a.y; gz += a.z;
     }
     float dx = 0.f, dy = 0.f, dz = 0.f;
-    const long long e = is_mv ? n : (long long)b * V + i;
     for (int r = 0; r < Rd; r++) {
       const float *a = gd2m_part + ((e * Rd + r) * J + k) * 3;
       dx += a[0]; dy += a[1]; dz += a[2];
@@ -178,14 +181,14 @@ extern "C" int shr_mv_loss_combine(const float *cam, const float *inv_cam, const
   using namespace shr;
   if (B == 0) return SHR_OK;
   if (!cam || !inv_cam || !sse_part || !grad_spheres_part || !d2m_part || !grad_d2m_part || !loss || B < 0 || V <= 0 ||
-      J <= 0 || H <= 0 || W <= 0 || Rm <= 0 || Rd <= 0)
+      J <= 0 || H <= 0 || W <= 0 || Rm <= 0 || Rd <= 0 || is_mv < 0 || is_mv > 2)
     return SHR_EINVAL;
   if (((uintptr_t)grad_spheres_part & 15u) != 0) return SHR_EINVAL;
   if ((long long)B * V * V * J > (1LL << 31) - 256) return SHR_ETOOLARGE;
   // MSELoss means and the reference's x9 / x3 (mesh/multiview_utility.py:100-101, :126-127); DataToModelLoss means
   // over the same pixel counts (mesh/render.py:142) times its x9 / x3 and the caller's 500 (:129)
   const double px = (double)H * W;
-  const double wm = is_mv ? 9.0 / ((double)B * V * V * px) : 3.0 / ((double)B * px);
+  const double wm = is_mv == 1 ? 9.0 / ((double)B * V * V * px) : 3.0 / ((double)B * px);
   const double wd = (double)d2m_weight * wm;
   const long long total = (long long)B * V * J;
   if (V > 8) return SHR_ETOOLARGE;   // (the pairs of a view sit side by side in 4 or 8 lanes)

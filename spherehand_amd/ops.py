@@ -251,6 +251,7 @@ def d2m_two_step_pays(depth):
 
 
 MV_OVERLAP = True        # MutualProjectionLossFused: render-and-compare beside the point search (see there)
+SAME_VIEW_SPLIT = True   # ... and, for the same-view pairs only, the compare on those pairs alone (see there)
 _SIDE = {}
 
 
@@ -383,26 +384,36 @@ class MutualProjectionLossFused(torch.autograd.Function):
                 _lib.check(lib.shr_mutual_project_fwd(_ptr(cam), _ptr(inv_cam), _ptr(joints), _ptr(radii), B, V, J,
                                                       _ptr(spheres), _stream()), "shr_mutual_project_fwd")
             depth = torch.empty((N, H, W), dtype=torch.float32, device=dev)
-            sse = torch.empty((N, Rm), dtype=torch.float32, device=dev)
-            gsp = torch.empty((N, Rm, J, 4), dtype=torch.float32, device=dev)
             # The two terms are independent: where the stack is large enough for the two-step path, the
             # render-and-compare kernel goes to a side stream and the point search's workgroups fill the CUs its last
             # round leaves idle (and the other way round): 282 -> 275 us at config 5's size, same bits (MV_OVERLAP).
             overlap = MV_OVERLAP and two_step
-            if overlap:
-                main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-                side.wait_stream(main)
-                mse_stream = side.cuda_stream
-            else:
-                mse_stream = _stream()
-            _lib.check(lib.shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), _ptr(depth),
-                                                 _ptr(sse), _ptr(gsp), mse_stream), "shr_sphere_raster_mse")
             if is_mv:
                 E, cen, cidx = N, spheres, index
             else:                # the V same-view pairs only: their records and observed-image numbers, gathered
                 E = B * V
                 cen = spheres.index_select(0, diag_index)
                 cidx = index.index_select(0, diag_index)
+            # Same-view pairs only (what the reference trains with after its first 1500 iterations,
+            # network/engine.py:361) on a large stack: the V*V projections are still returned, but only V of them are
+            # compared -- all N are rendered by the plain forward kernel on the side stream while the fused kernel
+            # takes the B*V same-view pairs alone (no depth output) on the caller's: 244 -> 220 us at config 5's size.
+            split = overlap and not is_mv and SAME_VIEW_SPLIT
+            Em = E if split else N
+            sse = torch.empty((Em, Rm), dtype=torch.float32, device=dev)
+            gsp = torch.empty((Em, Rm, J, 4), dtype=torch.float32, device=dev)
+            if overlap:
+                main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+                side.wait_stream(main)
+            if split:
+                _lib.check(lib.shr_sphere_raster_fwd_ex(_ptr(spheres), N, J, H, W, _ptr(depth), None, 0, side.cuda_stream),
+                           "shr_sphere_raster_fwd_ex")
+                _lib.check(lib.shr_sphere_raster_mse(_ptr(cen), E, J, H, W, _ptr(observed), _ptr(cidx), None,
+                                                     _ptr(sse), _ptr(gsp), _stream()), "shr_sphere_raster_mse")
+            else:
+                _lib.check(lib.shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), _ptr(depth),
+                                                     _ptr(sse), _ptr(gsp), side.cuda_stream if overlap else _stream()),
+                           "shr_sphere_raster_mse")
             if two_step:
                 ws = points_ws
                 Rd = d2m_points_parts(E)
@@ -423,7 +434,7 @@ class MutualProjectionLossFused(torch.autograd.Function):
             want = ctx.needs_input_grad[2]
             gj = torch.empty((B, V, J, 3), dtype=torch.float32, device=dev) if want else None
             _lib.check(lib.shr_mv_loss_combine(_ptr(cam), _ptr(inv_cam), _ptr(sse), _ptr(gsp), Rm, _ptr(d2m), _ptr(gd2m), Rd,
-                                               B, V, J, H, W, int(bool(is_mv)), float(d2m_weight), _ptr(loss), _ptr(gj),
+                                               B, V, J, H, W, 1 if is_mv else (2 if split else 0), float(d2m_weight), _ptr(loss), _ptr(gj),
                                                _stream()), "shr_mv_loss_combine")
         if want:
             ctx.save_for_backward(gj)

@@ -408,3 +408,35 @@ def test_loss_on_a_callers_own_stream_with_the_side_stream_beside_it():
             got = (loss.detach(), proj.detach(), j.grad)
             own.synchronize()
             assert all(torch.equal(a, b) for a, b in zip(got, want[k])), k
+
+
+@pytest.mark.parametrize("S,B", [(64, 5), (128, 12), (256, 4)])
+def test_same_view_pairs_compared_alone_give_the_same_results(S, B):
+    """is_mv = False (the reference after its first 1500 iterations): ops.SAME_VIEW_SPLIT renders all V*V projections
+    with the plain forward kernel and runs the fused render-and-compare kernel on the B*V same-view pairs alone
+    (shr_mv_loss_combine with is_mv = 2) -- projection bit-identical, loss and d loss / d joints bit-identical to the
+    one-launch wiring (same per-pair values, same order of summation)."""
+    from spherehand_amd import hand_model, ops
+    from spherehand_amd.datasets import SyntheticMultiviewDataset
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    mesh = hand_model.load_mesh()
+    ds = SyntheticMultiviewDataset(mesh, B, S, seed=8, device="cuda")
+    crit = MutualProjectionLoss(S, mesh).cuda()
+    cam, inv, dms = ds.cam.cuda(), ds.inv_cam.cuda(), ds.dms.cuda()
+    gen = torch.Generator("cuda").manual_seed(5)
+    keep = ops.SAME_VIEW_SPLIT
+    try:
+        for it in range(3):
+            base = ds.joints.cuda() + 2.0 * torch.randn(ds.joints.shape, device="cuda", generator=gen)
+            out = []
+            for mode in (False, True):
+                ops.SAME_VIEW_SPLIT = mode
+                j = base.clone().requires_grad_(True)
+                loss, proj = crit(cam, inv, j, dms, False)
+                loss.backward()
+                out.append((loss.detach().clone(), proj.detach().clone(), j.grad.clone()))
+            assert torch.equal(out[0][1], out[1][1]), it
+            assert torch.equal(out[0][2], out[1][2]), it
+            assert abs(out[0][0].item() - out[1][0].item()) <= 1e-6 * abs(out[0][0].item()), it
+    finally:
+        ops.SAME_VIEW_SPLIT = keep
