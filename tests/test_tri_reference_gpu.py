@@ -133,6 +133,14 @@ def test_contraction_changes_the_reference_kernels_output(ref, oracle, capsys):
               "relative difference: median %.2e, 99th pct %.2e, > 1e-4 at %d px, max %.3g"
               % (int(cov.sum()), int(((a < 1000) != (b < 1000)).sum()), int((bits(a) != bits(b)).sum()),
                  float(np.median(d)), float(np.percentile(d, 99)), int((d > 1e-4).sum()), float(d.max())))
+    # ... and what is left of it where the product uses the image: clamp(max=100) + bilinear 640 -> 128 (mesh/render.py:310-311)
+    import torch.nn.functional as F
+    ra, rb = (F.interpolate(torch.from_numpy(x).clamp(max=100.0).unsqueeze(1), size=(128, 128), mode="bilinear",
+                            align_corners=False).squeeze(1).numpy() for x in (a, b))
+    dr = np.abs(ra - rb)
+    with capsys.disabled():
+        print("[the same two images after clamp(100) + resize to 128 x 128] max |diff| %.3g mm; > 1e-3 mm at %d of %d px; > 0.1 mm at %d"
+              % (float(dr.max()), int((dr > 1e-3).sum()), dr.size, int((dr > 0.1).sum())))
     assert int(((a < 1000) != (b < 1000)).sum()) <= 16           # coverage is decided by comparisons the fusion barely touches
 
 
