@@ -400,7 +400,19 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     t_d2m = mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_partial(a[0], a[1], a[2], 3, a[3], n5, J, S, S, R,
                                                                                a[4], a[5], s), "d2m"), stream, 40, 3, 3)
     sec["data_to_model_kernel_1152_crops_128x128"] = dict(us=round(t_d2m, 1), **roof(n5 * (4 * S * S + 16 * J), t_d2m))
-    del ds, crit, obs
+    # the same loss through the two-step path (384 images compacted once, 1152 point-list searches): what
+    # ops.data_to_model takes from 2^23 observed pixels on -- at this size the fused loss gains nothing from it
+    # (111 us either way), the stand-alone term does
+    ws = ops.d2m_compact(obs)
+    ls1 = torch.empty(n5, device=dev); gr1 = torch.empty(n5, J, 3, device=dev)
+    t_c = mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_compact(a[0], B5 * 3, S, S, ws.data_ptr(), s), "compact"),
+                         stream, 40, 3, 3)
+    t_p = mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_from_points(ws.data_ptr(), B5 * 3, a[1], a[2], 3, a[3], n5, J, S, S, 1,
+                                                                                ls1.data_ptr(), gr1.data_ptr(), s), "points"),
+                         stream, 40, 3, 3)
+    sec["data_to_model_two_step_1152_crops_128x128"] = {"compact_us": round(t_c, 1), "search_us": round(t_p, 1),
+                                                        "us": round(t_c + t_p, 1)}
+    del ds, crit, obs, ws
 
     # ---- fused render-and-compare at the headline batch (256 crops @128x128, with the depth output) -------
     spheres, _ = make_inputs(0, dev)

@@ -215,7 +215,7 @@ def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
         raise RuntimeError("radii must have J entries")
     if depth_index is not None:
         _check_index(depth_index, N, depth.shape[0], "depth_index")
-    if N > 0 and d2m_two_step_pays(depth):
+    if N > 0 and d2m_two_step_pays(depth, shared=depth_index is not None and N >= 2 * depth.shape[0]):
         # compact every image once, search the point lists (bit-identical sums, see csrc/data_to_model.hip)
         ws = d2m_compact(depth)
         return data_to_model_from_points(ws, depth.shape[0], H, W, centres, radii, depth_index, want_grad)
@@ -244,10 +244,14 @@ def d2m_points_supported(depth):
         _lib.lib().shr_data_to_model_points_bytes(int(depth.shape[0]), int(depth.shape[1]), int(depth.shape[2])) > 0
 
 
-def d2m_two_step_pays(depth):
+def d2m_two_step_pays(depth, shared=False):
     """The two-step path costs a launch more than the streaming kernel and wins where the streaming kernel is bound by
-    its VALU work (large images compared with several sphere sets); small stacks stay with one launch."""
-    return D2M_TWO_STEP and depth.numel() >= D2M_TWO_STEP_MIN_PIXELS and d2m_points_supported(depth)
+    its VALU work (large images compared with several sphere sets); small stacks stay with one launch.  shared: the
+    stand-alone term with every image searched by at least two crops -- the compaction is paid once per image, the
+    search per crop: from half the size on (1152 crops on 384 images @128x128: 46 against 56 us; the fused loss, which
+    has other launches to feed, gains nothing there and keeps the full threshold)."""
+    least = D2M_TWO_STEP_MIN_PIXELS // 2 if shared else D2M_TWO_STEP_MIN_PIXELS
+    return D2M_TWO_STEP and depth.numel() >= least and d2m_points_supported(depth)
 
 
 MV_OVERLAP = True        # MutualProjectionLossFused: render-and-compare beside the point search (see there)
