@@ -102,3 +102,30 @@ def sparse_skin(mesh):
     np.add.at(start, vid + 1, 1)
     start = np.cumsum(start).astype(np.int32)
     return start, bid.astype(np.int32), np.ascontiguousarray(wv, np.float32)
+
+
+def unique_skin(mesh):
+    """The skin table of the DISTINCT vertices of the triangle mesh, and where each of the mesh's vertices went.
+
+    The reference's mesh stores every face's three corners as vertices of their own (10 144 records for 1 721 distinct
+    points); copies of a point carry byte-identical (bone, weight * vertex) entries, so skinning one of them gives the
+    bits of all.  Returns (vertex_start [NU+1] i32, bone [NSU] i32, wv [NSU,4] f32, index [NV] i64) with
+    skinned_all[:, v] == skinned_unique[:, index[v]] bit for bit (first-occurrence order)."""
+    start, bone, wv = sparse_skin(mesh)
+    NV = len(start) - 1
+    seen, keep, index = {}, [], np.empty(NV, np.int64)
+    for v in range(NV):
+        a, b = start[v], start[v + 1]
+        key = (bone[a:b].tobytes(), wv[a:b].tobytes())
+        u = seen.get(key)
+        if u is None:
+            u = seen[key] = len(keep)
+            keep.append(v)
+        index[v] = u
+    ustart = np.zeros(len(keep) + 1, np.int32)
+    ubone, uwv = [], []
+    for u, v in enumerate(keep):
+        a, b = start[v], start[v + 1]
+        ustart[u + 1] = ustart[u] + (b - a)
+        ubone.append(bone[a:b]); uwv.append(wv[a:b])
+    return ustart, np.concatenate(ubone).astype(np.int32), np.ascontiguousarray(np.concatenate(uwv), np.float32), index

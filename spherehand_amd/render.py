@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .hand_model import radii_of, sparse_skin
+from .hand_model import radii_of, sparse_skin, unique_skin
 from .kinematicsTransformation import keypoint_skinning
 
 
@@ -145,11 +145,18 @@ class DepthRasterization(nn.Module):
 
 class SparseSkinning(nn.Module):
     """LinearBlendSkinning (+ optional orthographic camera) of the full mesh on the
-    HIP kernel: forward(T[B,17,4,4], camera=None, rand_f=None) -> [B,NV,4]."""
+    HIP kernel: forward(T[B,17,4,4], camera=None, rand_f=None) -> [B,NV,4].
+    distinct=True: only the mesh's DISTINCT vertices (hand_model.unique_skin: 1 721 of 10 144 -- the reference stores
+    each face's corners separately) -> [B,NU,4]; `vertex_index` [NV] maps a mesh vertex to its row."""
 
-    def __init__(self, mesh, right_hand=True):
+    def __init__(self, mesh, right_hand=True, distinct=False):
         super().__init__()
-        start, bone, wv = sparse_skin(mesh)
+        if distinct:
+            start, bone, wv, index = unique_skin(mesh)
+            self.vertex_index = index
+        else:
+            start, bone, wv = sparse_skin(mesh)
+            self.vertex_index = None
         self.register_buffer('skin_vertex_start', torch.from_numpy(start))
         self.register_buffer('skin_bone', torch.from_numpy(bone))
         self.register_buffer('skin_wv', torch.from_numpy(wv))
@@ -169,9 +176,11 @@ class DepthRender(nn.Module):
 
     def __init__(self, mesh, image_size):
         super().__init__()
-        self.lbs = SparseSkinning(mesh)
+        # the skinned vertices never leave this module: the distinct ones are enough, the faces index them (identical
+        # face corners, hence identical images; 16 -> 4 us of skinning and a sixth of the vertex traffic per call)
+        self.lbs = SparseSkinning(mesh, distinct=True)
         self.camera = (320.0, 320.0, 640 / 300, 640 / 300)             # :325
-        self.rasterizer = DepthRasterization(image_size, image_size, mesh['faces'])
+        self.rasterizer = DepthRasterization(image_size, image_size, self.lbs.vertex_index[np.asarray(mesh['faces'], np.int64)])
 
     def forward(self, transformation_mats, rand_fx=None):
         skinned_points = self.lbs(transformation_mats, self.camera, rand_fx)

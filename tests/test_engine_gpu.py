@@ -119,7 +119,8 @@ def test_hand_synthesizer_values_against_the_oracle_chain(S):
     rand_f = torch.rand(B, device="cuda") * 0.2 + 0.9
     start, bone, wv = hand_model.sparse_skin(mesh)
     verts = oracle.lbs_project(T.cpu().numpy(), start, bone, wv, True, syn.dm_render.camera, rand_f.cpu().numpy())
-    faces = syn.dm_render.rasterizer.faces_i32.cpu().numpy().astype(np.int64)                  # [F,3], winding as rasterized
+    faces = np.asarray(mesh["faces"], np.int64)[:, [1, 0, 2]]        # [F,3] into the mesh's own vertex list, winding as
+    #                                                                  rasterized (right hand: mesh/render.py:298-300)
     fv = np.ascontiguousarray(verts[:, faces, 0:3], np.float32)                     # [B,F,3,3]
     raw = oracle.tri_raster_fwd(fv, 640, 640)
     ref = oracle.clamp_bilinear(raw, S, S, 100.0) * np.float32(0.01)

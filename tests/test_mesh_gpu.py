@@ -275,3 +275,24 @@ def test_fused_depth_render_dense_front_facing_grid(src, S):
     chain = torch.nn.functional.interpolate(torch.clamp(raw, max=100.0).unsqueeze(1), size=(S, S), mode="bilinear",
                                             align_corners=False).squeeze(1)
     assert torch.equal(fused, chain)
+
+
+def test_depth_render_on_the_distinct_vertices_equals_the_full_mesh():
+    """DepthRender skins the mesh's 1 721 distinct vertices (the reference stores each face's corners separately:
+    10 144 records with byte-identical skin entries per copy) and lets the faces index them: the skinned vertices of
+    the copies are bit-identical to the full table's, and so is the image."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.render import DepthRasterization, DepthRender, SparseSkinning
+    g = golden("g2_mesh.npz")
+    mesh = hand_model.load_mesh()
+    T, rf = dev(g["T"]), dev(g["rand_f"])
+    full = SparseSkinning(mesh).cuda()
+    for S in (64, 128, 256):
+        dr = DepthRender(mesh, S).cuda()
+        assert dr.lbs.num_vertices == 1721 and full.num_vertices == 10144
+        for rand_f in (None, rf):
+            vu = dr.lbs(T, dr.camera, rand_f)
+            va = full(T, dr.camera, rand_f)
+            assert torch.equal(vu[:, torch.from_numpy(dr.lbs.vertex_index).cuda()], va)
+            want = DepthRasterization(S, S, mesh["faces"]).cuda()(va)
+            assert torch.equal(dr(T, rand_f), want)
