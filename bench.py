@@ -455,17 +455,26 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     pose = sample_poses(BATCH, seed=0).to(dev).requires_grad_(True)
     gdepth = torch.randn(BATCH, S, S, device=dev)
 
-    def chain():
+    def chain():                     # four launches: pose -> records, raster forward, backward, records -> d/d pose
+        pose.grad = None
+        hbr.pose_depth(fkm, pose).backward(gdepth)
+
+    def chain_modules():             # the reference's module boundaries: T visits HBM, six launches
         pose.grad = None
         depth = ops.SphereDepthRaster.apply(hbr.spheres(fkm(pose)).contiguous(), S, S)
         depth.backward(gdepth)
-    for _ in range(3):
-        chain()
-    stream.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=stream):
-        chain()
-    t_chain = mean_launch_us(lambda _s: g.replay(), stream, 100, 3, 10)
+
+    def graph_us(fn):
+        for _ in range(3):
+            fn()
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            fn()
+        t = mean_launch_us(lambda _s: g.replay(), stream, 100, 3, 10)
+        del g
+        return t
+    t_chain, t_chain_modules = graph_us(chain), graph_us(chain_modules)
     # (host-bound.  The host cores idle at 1.2 GHz while the graph replays above only wait for the GPU, and a process can
     # sit for half a second on a slow or shared core before the scheduler moves it -- 161 us per iteration for the first
     # 3000 iterations, 103 after, in one of three consecutive runs of the same loop on one box: timed after 1.2 s of
@@ -473,12 +482,17 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     eager_batches = sorted(mean_launch_us(lambda _s: chain(), stream, 50, 1, 30 if i == 0 else 0, warm_ms=1200.0 if i == 0 else 0.0)
                            for i in range(7))
     t_eager = eager_batches[3]
+    t_eager_modules = sorted(mean_launch_us(lambda _s: chain_modules(), stream, 50, 1, 30 if i == 0 else 0,
+                                            warm_ms=300.0 if i == 0 else 0.0) for i in range(5))[2]
     sec["pose_to_depth_to_pose_us"] = {"graph_replay_us": round(t_chain, 2), "eager_autograd_us": round(t_eager, 1),
                                        "eager_fastest_slowest_batch_us": [round(eager_batches[0], 1), round(eager_batches[-1], 1)],
                                        "crops_per_s_graph": round(BATCH / (t_chain * 1e-6), 1),
-                                       "chain": "pose[256,26] -> fk_fwd -> key-point skinning -> sphere raster fwd (+ owner map) "
-                                                "-> bwd -> skinning bwd -> fk_bwd -> grad pose[256,26]"}
-    del g
+                                       "chain": "pose[256,26] -> pose_fwd (FK + key-point skinning, T in LDS) -> sphere raster fwd "
+                                                "(+ owner map) -> bwd -> pose_bwd -> grad pose[256,26]: 4 launches",
+                                       "module_by_module": {"graph_replay_us": round(t_chain_modules, 2),
+                                                            "eager_autograd_us": round(t_eager_modules, 1),
+                                                            "chain": "fk_fwd -> key-point skinning -> raster fwd -> bwd -> "
+                                                                     "skinning bwd -> fk_bwd: 6 launches, same bits"}}
 
     if os.environ.get("SHR_BENCH_SKIP_TRAIN"):      # counter passes: the step's ~700 launches only bloat the trace
         return sec
@@ -552,6 +566,22 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the large-batch and secondary measurements")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` started plainly (no launcher in front of it): start the N ranks here, exactly as the
+    # driver's own multi-GPU command does -- one process per GPU under torch.distributed.run on 127.0.0.1 -- and hand
+    # their output through (rank 0 prints the one JSON line).  --gpus 1 never takes this branch.
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", "4")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -587,7 +617,8 @@ def main():
         assert int(seen.item()) == world, "RCCL all-reduce saw %d ranks, expected %d" % (int(seen.item()), world)
         rccl_ranks = int(seen.item())
     else:
-        assert args.gpus == 1, "--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus)
+        assert args.gpus == 1, "launched as one rank (WORLD_SIZE=1) but --gpus %d: torch.distributed.run --nproc-per-node %d" \
+            % (args.gpus, args.gpus)
         rccl_ranks = 1
 
     from spherehand_amd import _lib

@@ -364,12 +364,30 @@ int shr_keypoint_spheres_bwd(const float *grad_spheres, int B, int NB, int J, co
  * Replaces HandTransformationMat.forward (mesh/kinematicsTransformation.py:157-177)
  * and its autograd backward.  params[B,26] (palm Euler xyz, palm translation, 5 x
  * (abduct, flex1, flex2, flex3)); offset, offset_inv [17,4,4] = the bones' offset
- * matrices and their inverses; T[B,17,4,4] (bones 0 and 1 = palm transform). */
+ * matrices and their inverses (16-byte aligned; AFFINE: last row 0 0 0 1, as every bone
+ * offset matrix and its inverse is -- the kernels never read that row);
+ * T[B,17,4,4] (bones 0 and 1 = palm transform). */
 int shr_fk_fwd(const float *params, int B, const float *offset, const float *offset_inv,
                float *T, void *stream);
-/* grad_params[B,26] = d<grad_T, T>/d params (analytic reverse mode). */
+/* grad_params[B,26] = d<grad_T, T>/d params (analytic reverse mode; the homogeneous row of
+ * T is constant and takes no gradient). */
 int shr_fk_bwd(const float *params, int B, const float *offset, const float *offset_inv,
                const float *grad_T, float *grad_params, void *stream);
+
+/* Pose -> sphere records in one launch per direction ---------------------------------------
+ * shr_fk_fwd followed by shr_keypoint_spheres_fwd without T visiting HBM: the fit chain
+ * HandBallPrimitiveRender(HandTransformationMat(pose)) of mesh/render.py:81-88 over
+ * mesh/kinematicsTransformation.py:169-177.  Same arithmetic as the two entries, same bits.
+ * bone[J] < 17, wv[J,4], radii[J] as for shr_keypoint_spheres_fwd; spheres[B,J,4];
+ * T: NULL, or [B,17,4,4] to receive the bone transforms as well. */
+int shr_pose_spheres_fwd(const float *params, int B, const float *offset, const float *offset_inv, int J,
+                         const int32_t *bone, const float *wv, const float *radii, int right_hand,
+                         float *spheres, float *T, void *stream);
+/* grad_params[B,26] = d<grad_spheres, spheres>/d params: shr_keypoint_spheres_bwd and
+ * shr_fk_bwd in one launch (bone_start[18], bone_points[J]: CSR as there). */
+int shr_pose_spheres_bwd(const float *params, int B, const float *offset, const float *offset_inv, int J,
+                         const int32_t *bone_start, const int32_t *bone_points, const float *wv,
+                         int right_hand, const float *grad_spheres, float *grad_params, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,245 +1,345 @@
-// fk.hip -- forward kinematics of the hand, forward + analytic backward.
+// fk.hip -- forward kinematics of the hand (pose -> bone transforms -> sphere records) and the analytic backward.
 //
-// Replaces (reference file:line): mesh/kinematicsTransformation.py:157-177
-// HandTransformationMat.forward (Palm :145-155, Finger :123-127, FingerJoint
-// :92-112, AxisRotationMatrix :29-54) -- ~100 tiny launches in the reference --
-// and the autograd backward of that graph.
+// Replaces (reference file:line): mesh/kinematicsTransformation.py:157-177 HandTransformationMat.forward (Palm
+// :145-155, Finger :123-127, FingerJoint :92-112, AxisRotationMatrix :29-54) -- ~100 tiny launches in the reference --
+// the autograd backward of that graph and, in the fused entries, the key-point skinning + cat of
+// HandBallPrimitiveRender (mesh/render.py:65-88; keypoint_skin.hip has the stand-alone kernels and the formulae).
 //
 //   params[B,26] = palm Euler x,y,z | palm translation | 5 x (abduct, flex1..3)
-//   T[B,17,4,4]  : bones 0,1 = palm P = Trans * Rz * Ry * Rx ; finger f (bones
-//                  2+3f..4+3f): G1 = P*A1, G2 = G1*A2, G3 = G2*A3 with
-//                  A_k = offset_k^-1 * L_k * offset_k, L1 = R_abduct(a0)*R_x(a1),
-//                  L2 = R_x(a2), L3 = R_x(a3).
+//   T[B,17,4,4]  : bones 0,1 = palm P = Trans * Rz * Ry * Rx ; finger g (bones 2+3g..4+3g): G1 = P*A1, G2 = G1*A2,
+//                  G3 = G2*A3 with A_k = offset_k^-1 * L_k * offset_k, L1 = R_abduct(a0)*R_x(a1), L2 = R_x(a2),
+//                  L3 = R_x(a3).  Every factor is affine (last row 0 0 0 1: the bones' offset matrices are).
 //
-// 8 lanes per sample: lanes 0-4 own a finger (and recompute the palm), lane 5 adds
-// the palm bones' gradient; the palm gradient is summed over the 8 lanes by an
-// xor butterfly.  Reverse mode: dL/dG3 -> A3, G2 ; ... ; every rotation's angle
-// gradient is <dL/dR, dR/dtheta>.
+// Round 5 rebuild.  Rounds 1-4 gave a sample 8 lanes, five of which each ran ~25 dependent 4x4 products serially,
+// 8 workgroups in all: 7.1 us forward, 14.6 us backward for 256 poses -- the longest kernel of the pose -> depth ->
+// pose chain was not a rasterizer.  Two observations remove almost all of that work:
+//   * row i of a product depends on row i of the left factor only, so a chain G_k = G_k-1 * (I_k L_k O_k) is three
+//     INDEPENDENT row chains  g <- ((g * I_k) * L_k) * O_k  -- a 4-vector times an affine matrix is 12 FMAs, times an
+//     axis-aligned rotation 5 multiplies/FMAs -- and no 4x4 product is ever formed (28 operations per bone and row
+//     where forming A_k and multiplying took 3 x 64);
+//   * the same holds in reverse mode: the adjoint of a row chain is a row chain, and an angle's gradient is the
+//     2-term expression  <out_bar, d out / d theta> = ob_p * out_q - ob_q * out_p  of the rotated pair, summed over
+//     the three rows.
+// One wave per sample (256 poses = 256 single-wave workgroups, one per CU): lane 4 g + i owns row i of finger g
+// (g = 5: the palm), 23 lanes take one sincos each first.  The axis-aligned rotations keep the reference's matrix
+// entries, including its diagonal d = (1 - c) + c on the axis (:40-52), so the result is the reference's up to the
+// association of the sums (FMAs here; the reference's own bmm order is the library's): <= 1e-4 mm from the
+// reference's fp32 T on entries up to 150, 3e-5 from the fp64 value (the reference itself: 1e-4).
 #include "common.h"
 
 namespace shr {
 
-struct M4 { float m[16]; };
-
-__device__ __forceinline__ M4 mul(const M4 &a, const M4 &b) {
-  M4 c;
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; k++) s += a.m[4 * i + k] * b.m[4 * k + j];
-      c.m[4 * i + j] = s;
-    }
-  return c;
+// u * M for an affine M with rows m0, m1, m2 (and an implied 0 0 0 1): u = (r0, r1, r2, t)
+__device__ __forceinline__ float4 row_times(const float4 u, const float4 m0, const float4 m1, const float4 m2) {
+  float4 o;
+  o.x = __builtin_fmaf(u.z, m2.x, __builtin_fmaf(u.y, m1.x, u.x * m0.x));
+  o.y = __builtin_fmaf(u.z, m2.y, __builtin_fmaf(u.y, m1.y, u.x * m0.y));
+  o.z = __builtin_fmaf(u.z, m2.z, __builtin_fmaf(u.y, m1.z, u.x * m0.z));
+  o.w = __builtin_fmaf(u.z, m2.w, __builtin_fmaf(u.y, m1.w, u.x * m0.w)) + u.w;
+  return o;
 }
-__device__ __forceinline__ M4 mul_bt(const M4 &a, const M4 &b) {  // a * b^T
-  M4 c;
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; k++) s += a.m[4 * i + k] * b.m[4 * j + k];
-      c.m[4 * i + j] = s;
-    }
-  return c;
-}
-__device__ __forceinline__ M4 mul_at(const M4 &a, const M4 &b) {  // a^T * b
-  M4 c;
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; k++) s += a.m[4 * k + i] * b.m[4 * k + j];
-      c.m[4 * i + j] = s;
-    }
-  return c;
-}
-__device__ __forceinline__ M4 load4(const float *p) {
-  M4 r;
-#pragma unroll
-  for (int i = 0; i < 16; i++) r.m[i] = p[i];
-  return r;
-}
-__device__ __forceinline__ void store4(float *p, const M4 &a) {
-#pragma unroll
-  for (int i = 0; i < 16; i++) p[i] = a.m[i];
+// its adjoint: u_bar given o_bar
+__device__ __forceinline__ float4 row_times_adj(const float4 ob, const float4 m0, const float4 m1, const float4 m2) {
+  float4 u;
+  u.x = __builtin_fmaf(ob.w, m0.w, __builtin_fmaf(ob.z, m0.z, __builtin_fmaf(ob.y, m0.y, ob.x * m0.x)));
+  u.y = __builtin_fmaf(ob.w, m1.w, __builtin_fmaf(ob.z, m1.z, __builtin_fmaf(ob.y, m1.y, ob.x * m1.x)));
+  u.z = __builtin_fmaf(ob.w, m2.w, __builtin_fmaf(ob.z, m2.z, __builtin_fmaf(ob.y, m2.y, ob.x * m2.x)));
+  u.w = ob.w;
+  return u;
 }
 
-// mesh/kinematicsTransformation.py:29-54 for a unit axis (x, y, z)
-__device__ __forceinline__ M4 axis_rot(float x, float y, float z, float angle) {
-  const float c = cosf(angle), s = sinf(angle), i = 1.0f - c;
-  M4 r;
-#pragma unroll
-  for (int k = 0; k < 16; k++) r.m[k] = 0.f;
-  r.m[15] = 1.0f;
-  r.m[0] = (x * x) * i + c;     r.m[1] = (x * y) * i - z * s; r.m[2] = (x * z) * i + y * s;
-  r.m[4] = (x * y) * i + z * s; r.m[5] = (y * y) * i + c;     r.m[6] = (y * z) * i - x * s;
-  r.m[8] = (x * z) * i - y * s; r.m[9] = (y * z) * i + x * s; r.m[10] = (z * z) * i + c;
-  return r;
+// (sin, cos, (1 - cos) + cos) of one angle: the three numbers the reference's axis-aligned rotation matrix holds
+struct Rot { float s, c, d; };
+
+// u * R for the reference's rotation about +x: R = [[d,0,0],[0,c,-s],[0,s,c]] (AxisRotationMatrix with axis 1 0 0)
+__device__ __forceinline__ float4 rot_x(const float4 u, const Rot r) {
+  return make_float4(u.x * r.d, __builtin_fmaf(u.z, r.s, u.y * r.c), __builtin_fmaf(u.z, r.c, -(u.y * r.s)), u.w);
 }
-// <G, dR/dangle> over the 3x3 block
-__device__ __forceinline__ float axis_rot_grad(float x, float y, float z, float angle, const M4 &g) {
-  const float c = cosf(angle), s = sinf(angle);
-  // dR = axis axis^T * s - s I + c [axis]x
-  float d[9] = {(x * x) * s - s, (x * y) * s - z * c, (x * z) * s + y * c,
-                (x * y) * s + z * c, (y * y) * s - s, (y * z) * s - x * c,
-                (x * z) * s - y * c, (y * z) * s + x * c, (z * z) * s - s};
-  float acc = 0.f;
-#pragma unroll
-  for (int r = 0; r < 3; r++)
-#pragma unroll
-    for (int k = 0; k < 3; k++) acc += g.m[4 * r + k] * d[3 * r + k];
-  return acc;
+__device__ __forceinline__ float4 rot_x_adj(const float4 ob, const Rot r) {
+  return make_float4(ob.x * r.d, __builtin_fmaf(-ob.z, r.s, ob.y * r.c), __builtin_fmaf(ob.z, r.c, ob.y * r.s), ob.w);
+}
+__device__ __forceinline__ float rot_x_dangle(const float4 ob, const float4 out) { return ob.y * out.z - ob.z * out.y; }
+// about +z: R = [[c,-s,0],[s,c,0],[0,0,d]]
+__device__ __forceinline__ float4 rot_z(const float4 u, const Rot r) {
+  return make_float4(__builtin_fmaf(u.y, r.s, u.x * r.c), __builtin_fmaf(u.y, r.c, -(u.x * r.s)), u.z * r.d, u.w);
+}
+__device__ __forceinline__ float4 rot_z_adj(const float4 ob, const Rot r) {
+  return make_float4(__builtin_fmaf(-ob.y, r.s, ob.x * r.c), __builtin_fmaf(ob.y, r.c, ob.x * r.s), ob.z * r.d, ob.w);
+}
+__device__ __forceinline__ float rot_z_dangle(const float4 ob, const float4 out) { return ob.x * out.y - ob.y * out.x; }
+// about +y: R = [[c,0,s],[0,d,0],[-s,0,c]]
+__device__ __forceinline__ float4 rot_y(const float4 u, const Rot r) {
+  return make_float4(__builtin_fmaf(-u.z, r.s, u.x * r.c), u.y * r.d, __builtin_fmaf(u.z, r.c, u.x * r.s), u.w);
+}
+__device__ __forceinline__ float4 rot_y_adj(const float4 ob, const Rot r) {
+  return make_float4(__builtin_fmaf(ob.z, r.s, ob.x * r.c), ob.y * r.d, __builtin_fmaf(ob.z, r.c, -(ob.x * r.s)), ob.w);
+}
+__device__ __forceinline__ float rot_y_dangle(const float4 ob, const float4 out) { return ob.z * out.x - ob.x * out.z; }
+
+// The abduction axis is +z for fingers 0, 1, 4 and -y for fingers 2, 3 (:162-164).  About -y the matrix is
+// [[c,0,-s],[0,d,0],[s,0,c]] = the +z form with the y and z components exchanged on both sides.
+__device__ __forceinline__ float4 swap_yz(const float4 u, bool on) { return on ? make_float4(u.x, u.z, u.y, u.w) : u; }
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+constexpr int kBones = 17;
+constexpr int kAngles = 23;          // palm Euler angles + 5 x 4 finger angles
+// the slot of parameter a in the sincos table (the three translations have none)
+__device__ __forceinline__ int angle_slot(int a) { return a < 3 ? a : a - 3; }
+
+// One sample's sincos table: lanes 0..22 take one angle each.
+__device__ __forceinline__ void sincos_phase(const float *__restrict__ p, int lane, Rot *sc) {
+  if (lane < kAngles) {
+    const float a = p[lane < 3 ? lane : lane + 3];
+    float s, c;
+    sincosf(a, &s, &c);
+    Rot r;
+    r.s = s;
+    r.c = c;
+    r.d = (1.0f - c) + c;            // xx * i + c with xx = 1, i = 1 - c (:37-41)
+    sc[lane] = r;
+  }
 }
 
-__device__ __forceinline__ void abduct_axis(int f, float &x, float &y, float &z) {  // :162-164
-  x = 0.f;
-  y = (f == 2 || f == 3) ? -1.f : 0.f;
-  z = (f == 2 || f == 3) ? 0.f : 1.f;
+// Row i of the palm transform P = Trans * (Rz * (Ry * Rx)) (:148-152) as a row chain: e_i * Rz, * Ry, * Rx.
+struct PalmRow { float4 a, b, r; };   // after Rz, Ry, Rx (r.w = the translation)
+__device__ __forceinline__ PalmRow palm_row(int i, const Rot rx, const Rot ry, const Rot rz, float t) {
+  PalmRow o;
+  o.a = i == 0 ? make_float4(rz.c, -rz.s, 0.f, 0.f) : i == 1 ? make_float4(rz.s, rz.c, 0.f, 0.f) : make_float4(0.f, 0.f, rz.d, 0.f);
+  o.b = rot_y(o.a, ry);
+  o.r = rot_x(o.b, rx);
+  o.r.w = t;
+  return o;
 }
 
-__device__ __forceinline__ M4 palm_matrix(const float *p, M4 &Rx, M4 &Ry, M4 &Rz) {
-  Rx = axis_rot(1.f, 0.f, 0.f, p[0]);
-  Ry = axis_rot(0.f, 1.f, 0.f, p[1]);
-  Rz = axis_rot(0.f, 0.f, 1.f, p[2]);
-  M4 R = mul(Rz, mul(Ry, Rx));       // :148-150
-  M4 Tr;
-#pragma unroll
-  for (int k = 0; k < 16; k++) Tr.m[k] = (k % 5 == 0) ? 1.f : 0.f;
-  Tr.m[3] = p[3]; Tr.m[7] = p[4]; Tr.m[11] = p[5];
-  return mul(Tr, R);                 // :152
+// The (I, O) rows of a finger's three bones, one lane's copy (the lanes of a finger read the same addresses)
+struct BoneConst { float4 i0, i1, i2, o0, o1, o2; };
+__device__ __forceinline__ BoneConst load_bone(const float *__restrict__ offset, const float *__restrict__ offset_inv, int nb) {
+  BoneConst k;
+  k.i0 = ld4(offset_inv + 16 * nb);     k.i1 = ld4(offset_inv + 16 * nb + 4); k.i2 = ld4(offset_inv + 16 * nb + 8);
+  k.o0 = ld4(offset + 16 * nb);         k.o1 = ld4(offset + 16 * nb + 4);     k.o2 = ld4(offset + 16 * nb + 8);
+  return k;
 }
 
-__global__ void __launch_bounds__(256)
-fk_fwd_kernel(const float *__restrict__ params, int B, const float *__restrict__ offset,
-              const float *__restrict__ offset_inv, float *__restrict__ T) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = gid >> 3, f = gid & 7;
-  if (b >= B || f > 5) return;
+// ---- forward -----------------------------------------------------------------------------------------------
+// One wave per sample.  WANT_T: write T[b] (17 x 4 x 4).  WANT_SPH: the key-point records too (T stays in LDS).
+template <bool WANT_T, bool WANT_SPH>
+__global__ void __launch_bounds__(64)
+pose_fwd_kernel(const float *__restrict__ params, const float *__restrict__ offset, const float *__restrict__ offset_inv,
+                float *__restrict__ T, const int *__restrict__ bone, const float4 *__restrict__ wv,
+                const float *__restrict__ radii, float sx, int J, float4 *__restrict__ spheres) {
+  __shared__ Rot sc[kAngles];
+  __shared__ float4 rows[kBones * 3];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int g = lane >> 2, i = lane & 3;
   const float *p = params + (size_t)b * 26;
-  float *Tb = T + (size_t)b * 17 * 16;
-  M4 Rx, Ry, Rz;
-  const M4 P = palm_matrix(p, Rx, Ry, Rz);
-  if (f == 5) {  // bones 0 and 1 both carry the palm transform (:153-155)
-    store4(Tb, P);
-    store4(Tb + 16, P);
-    return;
+  const bool chain = lane < 24 && i < 3, finger = chain && g < 5;
+  // everything the chain reads, requested before the sincos
+  const int b0 = 2 + 3 * (finger ? g : 0);
+  BoneConst k1, k2, k3;
+  if (finger) {
+    k1 = load_bone(offset, offset_inv, b0);
+    k2 = load_bone(offset, offset_inv, b0 + 1);
+    k3 = load_bone(offset, offset_inv, b0 + 2);
   }
-  const float *a = p + 6 + 4 * f;
-  const int b0 = 2 + 3 * f;
-  float ax, ay, az;
-  abduct_axis(f, ax, ay, az);
-  const M4 L1 = mul(axis_rot(ax, ay, az, a[0]), axis_rot(1.f, 0.f, 0.f, a[1]));
-  M4 G = mul(P, mul(mul(load4(offset_inv + 16 * b0), L1), load4(offset + 16 * b0)));   // :108-111
-  store4(Tb + 16 * b0, G);
-  G = mul(G, mul(mul(load4(offset_inv + 16 * (b0 + 1)), axis_rot(1.f, 0.f, 0.f, a[2])), load4(offset + 16 * (b0 + 1))));
-  store4(Tb + 16 * (b0 + 1), G);
-  G = mul(G, mul(mul(load4(offset_inv + 16 * (b0 + 2)), axis_rot(1.f, 0.f, 0.f, a[3])), load4(offset + 16 * (b0 + 2))));
-  store4(Tb + 16 * (b0 + 2), G);
+  const float t = chain ? p[3 + i] : 0.f;
+  int kb = 0;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  float rad = 0.f;
+  if (WANT_SPH && lane < J) {
+    kb = bone[lane];
+    v = wv[lane];
+    rad = radii[lane];
+  }
+  sincos_phase(p, lane, sc);
+  __syncthreads();
+  float4 *Tb = reinterpret_cast<float4 *>(T + (size_t)b * kBones * 16);
+  if (chain) {
+    const PalmRow P = palm_row(i, sc[0], sc[1], sc[2], t);
+    if (!finger) {                     // bones 0 and 1 both carry the palm transform (:153-155)
+      if (WANT_SPH) rows[i] = rows[3 + i] = P.r;
+      if (WANT_T) Tb[i] = Tb[4 + i] = P.r;
+    } else {
+      const int a0 = 3 + 4 * g;        // sincos slot of the finger's first angle (parameter 6 + 4 g)
+      const bool yaxis = g == 2 || g == 3;
+      float4 u = row_times(P.r, k1.i0, k1.i1, k1.i2);                       // :108-111, row by row
+      u = swap_yz(rot_z(swap_yz(u, yaxis), sc[a0]), yaxis);
+      u = rot_x(u, sc[a0 + 1]);
+      const float4 G1 = row_times(u, k1.o0, k1.o1, k1.o2);
+      u = rot_x(row_times(G1, k2.i0, k2.i1, k2.i2), sc[a0 + 2]);
+      const float4 G2 = row_times(u, k2.o0, k2.o1, k2.o2);
+      u = rot_x(row_times(G2, k3.i0, k3.i1, k3.i2), sc[a0 + 3]);
+      const float4 G3 = row_times(u, k3.o0, k3.o1, k3.o2);
+      if (WANT_SPH) {
+        rows[3 * b0 + i] = G1; rows[3 * b0 + 3 + i] = G2; rows[3 * b0 + 6 + i] = G3;
+      }
+      if (WANT_T) {
+        Tb[4 * b0 + i] = G1; Tb[4 * b0 + 4 + i] = G2; Tb[4 * b0 + 8 + i] = G3;
+      }
+    }
+  } else if (WANT_T && lane < 24) {    // i == 3: the homogeneous rows of the group's bones
+    const float4 h = make_float4(0.f, 0.f, 0.f, 1.f);
+    if (g == 5) {
+      Tb[3] = Tb[7] = h;
+    } else {
+      const int q = 2 + 3 * g;
+      Tb[4 * q + 3] = Tb[4 * q + 7] = Tb[4 * q + 11] = h;
+    }
+  }
+  if (!WANT_SPH) return;
+  __syncthreads();
+  // keypoint_spheres_fwd_kernel's arithmetic on the rows in LDS: the same records, bit for bit, as the two launches
+  for (int j = lane; j < J; j += 64) {
+    if (j >= 64) {
+      kb = bone[j];
+      v = wv[j];
+      rad = radii[j];
+    }
+    const float4 r0 = rows[3 * kb], r1 = rows[3 * kb + 1], r2 = rows[3 * kb + 2];
+    const float x = ((r0.x * v.x + r0.y * v.y) + r0.z * v.z) + r0.w * v.w;
+    const float y = ((r1.x * v.x + r1.y * v.y) + r1.z * v.z) + r1.w * v.w;
+    const float z = ((r2.x * v.x + r2.y * v.y) + r2.z * v.z) + r2.w * v.w;
+    spheres[(size_t)b * J + j] = make_float4(sx * x, y, z, rad);
+  }
 }
 
-__global__ void __launch_bounds__(256)
-fk_bwd_kernel(const float *__restrict__ params, int B, const float *__restrict__ offset,
-              const float *__restrict__ offset_inv, const float *__restrict__ grad_T,
-              float *__restrict__ grad_params) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = gid >> 3, f = gid & 7;
-  const bool active = b < B;
-  const int bb = active ? b : 0;
-  const float *p = params + (size_t)bb * 26;
-  const float *gT = grad_T + (size_t)bb * 17 * 16;
-  M4 Rx, Ry, Rz;
-  const M4 P = palm_matrix(p, Rx, Ry, Rz);
-  M4 Pbar;
-#pragma unroll
-  for (int k = 0; k < 16; k++) Pbar.m[k] = 0.f;
-  float ga[4] = {0.f, 0.f, 0.f, 0.f};
-  if (active && f == 5) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) Pbar.m[k] = gT[k] + gT[16 + k];
-  } else if (active && f < 5) {
-    const float *a = p + 6 + 4 * f;
-    const int b0 = 2 + 3 * f;
-    float ax, ay, az;
-    abduct_axis(f, ax, ay, az);
-    const M4 Ra = axis_rot(ax, ay, az, a[0]), Rb = axis_rot(1.f, 0.f, 0.f, a[1]);
-    const M4 O1 = load4(offset + 16 * b0), I1 = load4(offset_inv + 16 * b0);
-    const M4 O2 = load4(offset + 16 * (b0 + 1)), I2 = load4(offset_inv + 16 * (b0 + 1));
-    const M4 O3 = load4(offset + 16 * (b0 + 2)), I3 = load4(offset_inv + 16 * (b0 + 2));
-    const M4 A1 = mul(mul(I1, mul(Ra, Rb)), O1);
-    const M4 A2 = mul(mul(I2, axis_rot(1.f, 0.f, 0.f, a[2])), O2);
-    const M4 A3 = mul(mul(I3, axis_rot(1.f, 0.f, 0.f, a[3])), O3);
-    const M4 G1 = mul(P, A1), G2 = mul(G1, A2);
-    M4 g3 = load4(gT + 16 * (b0 + 2)), g2 = load4(gT + 16 * (b0 + 1)), g1 = load4(gT + 16 * b0);
-    // G3 = G2 A3
-    const M4 A3bar = mul_at(G2, g3);
-    M4 t = mul_bt(g3, A3);
-#pragma unroll
-    for (int k = 0; k < 16; k++) g2.m[k] += t.m[k];
-    // G2 = G1 A2
-    const M4 A2bar = mul_at(G1, g2);
-    t = mul_bt(g2, A2);
-#pragma unroll
-    for (int k = 0; k < 16; k++) g1.m[k] += t.m[k];
-    // G1 = P A1
-    const M4 A1bar = mul_at(P, g1);
-    Pbar = mul_bt(g1, A1);
-    // A_k = I_k L_k O_k  ->  Lbar = I^T Abar O^T
-    const M4 L3bar = mul_bt(mul_at(I3, A3bar), O3);
-    const M4 L2bar = mul_bt(mul_at(I2, A2bar), O2);
-    const M4 L1bar = mul_bt(mul_at(I1, A1bar), O1);
-    ga[3] = axis_rot_grad(1.f, 0.f, 0.f, a[3], L3bar);
-    ga[2] = axis_rot_grad(1.f, 0.f, 0.f, a[2], L2bar);
-    // L1 = Ra Rb
-    ga[0] = axis_rot_grad(ax, ay, az, a[0], mul_bt(L1bar, Rb));
-    ga[1] = axis_rot_grad(1.f, 0.f, 0.f, a[1], mul_at(Ra, L1bar));
+// ---- backward ----------------------------------------------------------------------------------------------
+// grad_params[b] from grad_T[b] (FROM_SPH = false) or from grad_spheres[b] (true: keypoint_spheres_bwd_kernel's sums
+// are formed in LDS first, same order, same bits).
+template <bool FROM_SPH>
+__global__ void __launch_bounds__(64)
+pose_bwd_kernel(const float *__restrict__ params, const float *__restrict__ offset, const float *__restrict__ offset_inv,
+                const float *__restrict__ grad_T, const float4 *__restrict__ grad_spheres,
+                const int *__restrict__ bone_start, const int *__restrict__ bone_points, const float4 *__restrict__ wv,
+                float sx, int J, float *__restrict__ grad_params) {
+  __shared__ Rot sc[kAngles];
+  __shared__ float4 gT[kBones * 3];    // d loss / d T[b, bone, row < 3, :]
+  __shared__ float4 pbar[6 * 3];       // the six groups' contributions to d loss / d P
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int g = lane >> 2, i = lane & 3;
+  const float *p = params + (size_t)b * 26;
+  const bool chain = lane < 24 && i < 3, finger = chain && g < 5;
+  const int b0 = 2 + 3 * (finger ? g : 0);
+  BoneConst k1, k2, k3;
+  if (finger) {
+    k1 = load_bone(offset, offset_inv, b0);
+    k2 = load_bone(offset, offset_inv, b0 + 1);
+    k3 = load_bone(offset, offset_inv, b0 + 2);
   }
-  // palm gradient: sum over the sample's 8 lanes
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    float v = Pbar.m[k];
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    Pbar.m[k] = v;
+  const float t = chain ? p[3 + i] : 0.f;
+  if (lane < kBones * 3) {             // lane = 3 * bone + row
+    const int nb = lane / 3, r = lane - 3 * nb;
+    if (FROM_SPH) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int k1e = bone_start[nb + 1];
+      for (int k = bone_start[nb]; k < k1e; k++) {
+        const int j = bone_points[k];
+        const float4 gs = grad_spheres[(size_t)b * J + j];
+        const float4 w = wv[j];
+        const float gr = r == 0 ? sx * gs.x : r == 1 ? gs.y : gs.z;
+        a.x += gr * w.x; a.y += gr * w.y; a.z += gr * w.z; a.w += gr * w.w;
+      }
+      gT[lane] = a;
+    } else {
+      gT[lane] = ld4(grad_T + ((size_t)b * kBones + nb) * 16 + 4 * r);
+    }
   }
-  if (!active) return;
+  sincos_phase(p, lane, sc);
+  __syncthreads();
+  PalmRow P;
+  float ga0 = 0.f, ga1 = 0.f, ga2 = 0.f, ga3 = 0.f;
+  if (chain) {
+    P = palm_row(i, sc[0], sc[1], sc[2], t);
+    if (!finger) {
+      const float4 x = gT[i], y = gT[3 + i];
+      pbar[15 + i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    } else {
+      const int a0 = 3 + 4 * g;
+      const bool yaxis = g == 2 || g == 3;
+      const Rot ra = sc[a0], rb = sc[a0 + 1], r2 = sc[a0 + 2], r3 = sc[a0 + 3];
+      // forward, keeping what the adjoints read
+      const float4 w1 = swap_yz(rot_z(swap_yz(row_times(P.r, k1.i0, k1.i1, k1.i2), yaxis), ra), yaxis);
+      const float4 v1 = rot_x(w1, rb);
+      const float4 G1 = row_times(v1, k1.o0, k1.o1, k1.o2);
+      const float4 v2 = rot_x(row_times(G1, k2.i0, k2.i1, k2.i2), r2);
+      const float4 G2 = row_times(v2, k2.o0, k2.o1, k2.o2);
+      const float4 v3 = rot_x(row_times(G2, k3.i0, k3.i1, k3.i2), r3);
+      // reverse
+      float4 Gb = gT[3 * b0 + 6 + i];
+      float4 vb = row_times_adj(Gb, k3.o0, k3.o1, k3.o2);
+      ga3 = rot_x_dangle(vb, v3);
+      float4 ub = row_times_adj(rot_x_adj(vb, r3), k3.i0, k3.i1, k3.i2);
+      Gb = gT[3 * b0 + 3 + i];
+      Gb = make_float4(Gb.x + ub.x, Gb.y + ub.y, Gb.z + ub.z, Gb.w + ub.w);
+      vb = row_times_adj(Gb, k2.o0, k2.o1, k2.o2);
+      ga2 = rot_x_dangle(vb, v2);
+      ub = row_times_adj(rot_x_adj(vb, r2), k2.i0, k2.i1, k2.i2);
+      Gb = gT[3 * b0 + i];
+      Gb = make_float4(Gb.x + ub.x, Gb.y + ub.y, Gb.z + ub.z, Gb.w + ub.w);
+      vb = row_times_adj(Gb, k1.o0, k1.o1, k1.o2);
+      ga1 = rot_x_dangle(vb, v1);
+      const float4 wb = swap_yz(rot_x_adj(vb, rb), yaxis);     // adjoint of w1, in the swapped frame
+      ga0 = rot_z_dangle(wb, swap_yz(w1, yaxis));
+      ub = row_times_adj(swap_yz(rot_z_adj(wb, ra), yaxis), k1.i0, k1.i1, k1.i2);
+      pbar[3 * g + i] = ub;
+    }
+  }
+  // an angle's gradient: the sum over the three rows (lanes 4 g + 0..2; lane 4 g + 3 holds zeros)
+  ga0 = dpp_add<0x4E, 0xF>(dpp_add<0xB1, 0xF>(ga0));
+  ga1 = dpp_add<0x4E, 0xF>(dpp_add<0xB1, 0xF>(ga1));
+  ga2 = dpp_add<0x4E, 0xF>(dpp_add<0xB1, 0xF>(ga2));
+  ga3 = dpp_add<0x4E, 0xF>(dpp_add<0xB1, 0xF>(ga3));
   float *gp = grad_params + (size_t)b * 26;
-  if (f < 5) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) gp[6 + 4 * f + k] = ga[k];
+  if (lane < 20 && i == 0) {
+    float2 *o = reinterpret_cast<float2 *>(gp + 6 + 4 * g);    // 8-byte aligned: 26 floats per sample
+    o[0] = make_float2(ga0, ga1);
+    o[1] = make_float2(ga2, ga3);
   }
-  if (f == 5) {
-    // P = Tr * R, R = Rz Ry Rx: translation gradient = Pbar[:3,3]; Rbar = Pbar[:3,:3]
-    // (Tr's rotation block is the identity, so the 3x3 block passes through)
-    M4 Rbar = Pbar;
-    Rbar.m[3] = Rbar.m[7] = Rbar.m[11] = 0.f;
-    Rbar.m[12] = Rbar.m[13] = Rbar.m[14] = Rbar.m[15] = 0.f;
-    const M4 Ryx = mul(Ry, Rx);
-    const M4 Ryxbar = mul_at(Rz, Rbar);
-    gp[2] = axis_rot_grad(0.f, 0.f, 1.f, p[2], mul_bt(Rbar, Ryx));
-    gp[1] = axis_rot_grad(0.f, 1.f, 0.f, p[1], mul_bt(Ryxbar, Rx));
-    gp[0] = axis_rot_grad(1.f, 0.f, 0.f, p[0], mul_at(Ry, Ryxbar));
-    gp[3] = Pbar.m[3]; gp[4] = Pbar.m[7]; gp[5] = Pbar.m[11];
+  __syncthreads();
+  // palm: d loss / d P row i = the palm bones' own gradient + the five fingers', in fixed order
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  if (chain && g == 5) {
+    float4 Pb = pbar[15 + i];
+#pragma unroll
+    for (int f = 0; f < 5; f++) {
+      const float4 c = pbar[3 * f + i];
+      Pb = make_float4(Pb.x + c.x, Pb.y + c.y, Pb.z + c.z, Pb.w + c.w);
+    }
+    gp[3 + i] = Pb.w;                                           // P = Trans * R: the translation column
+    const Rot rx = sc[0], ry = sc[1], rz = sc[2];
+    Pb.w = 0.f;
+    gx = rot_x_dangle(Pb, P.r);
+    const float4 bb = rot_x_adj(Pb, rx);
+    gy = rot_y_dangle(bb, P.b);
+    const float4 ab = rot_y_adj(bb, ry);
+    // row i of Rz: (c,-s,0) | (s,c,0) | (0,0,d): d/dz = (-s,-c,0) | (c,-s,0) | 0
+    gz = i == 0 ? -(ab.x * rz.s) - ab.y * rz.c : i == 1 ? ab.x * rz.c - ab.y * rz.s : 0.f;
+  }
+  gx = dpp_add<0x4E, 0xF>(dpp_add<0xB1, 0xF>(gx));
+  gy = dpp_add<0x4E, 0xF>(dpp_add<0xB1, 0xF>(gy));
+  gz = dpp_add<0x4E, 0xF>(dpp_add<0xB1, 0xF>(gz));
+  if (lane == 20) {
+    gp[0] = gx; gp[1] = gy; gp[2] = gz;
   }
 }
 
 }  // namespace shr
 
+static int fk_check(const void *params, int B, const void *offset, const void *offset_inv) {
+  if (!params || !offset || !offset_inv || B < 0) return SHR_EINVAL;
+  if ((((uintptr_t)offset | (uintptr_t)offset_inv) & 15u) != 0) return SHR_EINVAL;
+  if (B > (1 << 24)) return SHR_ETOOLARGE;
+  return SHR_OK;
+}
+
 extern "C" int shr_fk_fwd(const float *params, int B, const float *offset, const float *offset_inv, float *T,
                           void *stream) {
   using namespace shr;
   if (B == 0) return SHR_OK;
-  if (!params || !offset || !offset_inv || !T || B < 0) return SHR_EINVAL;
-  if (B > (1 << 27)) return SHR_ETOOLARGE;
-  hipLaunchKernelGGL(fk_fwd_kernel, dim3((unsigned)((B * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, B,
-                     offset, offset_inv, T);
+  if (!T || (((uintptr_t)T) & 15u) != 0) return SHR_EINVAL;
+  if (int rc = fk_check(params, B, offset, offset_inv)) return rc;
+  hipLaunchKernelGGL((pose_fwd_kernel<true, false>), dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, params, offset,
+                     offset_inv, T, nullptr, nullptr, nullptr, 1.0f, 0, nullptr);
   return (int)hipGetLastError();
 }
 
@@ -247,9 +347,45 @@ extern "C" int shr_fk_bwd(const float *params, int B, const float *offset, const
                           const float *grad_T, float *grad_params, void *stream) {
   using namespace shr;
   if (B == 0) return SHR_OK;
-  if (!params || !offset || !offset_inv || !grad_T || !grad_params || B < 0) return SHR_EINVAL;
-  if (B > (1 << 27)) return SHR_ETOOLARGE;
-  hipLaunchKernelGGL(fk_bwd_kernel, dim3((unsigned)((B * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, B,
-                     offset, offset_inv, grad_T, grad_params);
+  if (!grad_T || !grad_params || (((uintptr_t)grad_T) & 15u) != 0 || (((uintptr_t)grad_params) & 7u) != 0) return SHR_EINVAL;
+  if (int rc = fk_check(params, B, offset, offset_inv)) return rc;
+  hipLaunchKernelGGL((pose_bwd_kernel<false>), dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, params, offset,
+                     offset_inv, grad_T, nullptr, nullptr, nullptr, nullptr, 1.0f, 0, grad_params);
+  return (int)hipGetLastError();
+}
+
+extern "C" int shr_pose_spheres_fwd(const float *params, int B, const float *offset, const float *offset_inv, int J,
+                                    const int32_t *bone, const float *wv, const float *radii, int right_hand,
+                                    float *spheres, float *T, void *stream) {
+  using namespace shr;
+  if (B == 0 || J == 0) return SHR_OK;
+  if (!bone || !wv || !radii || !spheres || J < 0) return SHR_EINVAL;
+  if ((((uintptr_t)wv | (uintptr_t)spheres | (uintptr_t)T) & 15u) != 0) return SHR_EINVAL;
+  if (int rc = fk_check(params, B, offset, offset_inv)) return rc;
+  if ((long long)B * J > (1LL << 30)) return SHR_ETOOLARGE;
+  const float sx = right_hand ? -1.0f : 1.0f;
+  if (T)
+    hipLaunchKernelGGL((pose_fwd_kernel<true, true>), dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, params, offset,
+                       offset_inv, T, bone, reinterpret_cast<const float4 *>(wv), radii, sx, J,
+                       reinterpret_cast<float4 *>(spheres));
+  else
+    hipLaunchKernelGGL((pose_fwd_kernel<false, true>), dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, params, offset,
+                       offset_inv, nullptr, bone, reinterpret_cast<const float4 *>(wv), radii, sx, J,
+                       reinterpret_cast<float4 *>(spheres));
+  return (int)hipGetLastError();
+}
+
+extern "C" int shr_pose_spheres_bwd(const float *params, int B, const float *offset, const float *offset_inv, int J,
+                                    const int32_t *bone_start, const int32_t *bone_points, const float *wv,
+                                    int right_hand, const float *grad_spheres, float *grad_params, void *stream) {
+  using namespace shr;
+  if (B == 0) return SHR_OK;
+  if (!bone_start || !bone_points || !wv || !grad_spheres || !grad_params || J < 0) return SHR_EINVAL;
+  if ((((uintptr_t)wv | (uintptr_t)grad_spheres) & 15u) != 0 || (((uintptr_t)grad_params) & 7u) != 0) return SHR_EINVAL;
+  if (int rc = fk_check(params, B, offset, offset_inv)) return rc;
+  if ((long long)B * J > (1LL << 30)) return SHR_ETOOLARGE;
+  hipLaunchKernelGGL((pose_bwd_kernel<true>), dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, params, offset,
+                     offset_inv, nullptr, reinterpret_cast<const float4 *>(grad_spheres), bone_start, bone_points,
+                     reinterpret_cast<const float4 *>(wv), right_hand ? -1.0f : 1.0f, J, grad_params);
   return (int)hipGetLastError();
 }

@@ -605,6 +605,45 @@ class ForwardKinematics(torch.autograd.Function):
         return out, None, None
 
 
+class PoseSpheres(torch.autograd.Function):
+    """params [B,26] -> the rasterizer's records spheres [B,J,4]: ForwardKinematics followed by KeypointSpheres as ONE
+    launch per direction (shr_pose_spheres_fwd / _bwd): the bone transforms stay in LDS.  The fit chain
+    HandBallPrimitiveRender(HandTransformationMat(pose)) (mesh/render.py:81-88 over
+    mesh/kinematicsTransformation.py:169-177); records and gradient are bit-identical to the two Functions chained."""
+
+    @staticmethod
+    def forward(ctx, params, offset, offset_inv, bone, wv, radii, bone_start, bone_points, right_hand):
+        params = params.contiguous().float()
+        for t, name in ((params, "parameters"), (offset, "offset"), (offset_inv, "offset_inv"), (wv, "key-points"),
+                        (radii, "radii")):
+            _check_input(t, name)
+        if params.dim() != 2 or params.shape[1] != 26:
+            raise RuntimeError("parameters must be [B,26]")
+        B, J = params.shape[0], bone.shape[0]
+        if bone_start.shape[0] != 18 or wv.shape != (J, 4) or radii.numel() != J:
+            raise RuntimeError("key-point tables do not match the 17 bones")
+        with _on(params.device):
+            sph = torch.empty((B, J, 4), dtype=torch.float32, device=params.device)
+            _lib.check(_lib.lib().shr_pose_spheres_fwd(_ptr(params), B, _ptr(offset), _ptr(offset_inv), J, _ptr(bone), _ptr(wv),
+                                                       _ptr(radii), int(bool(right_hand)), _ptr(sph), None, _stream()),
+                       "shr_pose_spheres_fwd")
+        ctx.save_for_backward(params, offset, offset_inv, wv, bone_start, bone_points)
+        ctx.dims = (B, J, int(bool(right_hand)))
+        return sph
+
+    @staticmethod
+    def backward(ctx, grad_spheres):
+        params, offset, offset_inv, wv, bone_start, bone_points = ctx.saved_tensors
+        B, J, right = ctx.dims
+        g = grad_spheres.contiguous().float()
+        with _on(g.device):
+            out = torch.empty((B, 26), dtype=torch.float32, device=g.device)
+            _lib.check(_lib.lib().shr_pose_spheres_bwd(_ptr(params), B, _ptr(offset), _ptr(offset_inv), J, _ptr(bone_start),
+                                                       _ptr(bone_points), _ptr(wv), right, _ptr(g), _ptr(out), _stream()),
+                       "shr_pose_spheres_bwd")
+        return out, None, None, None, None, None, None, None, None
+
+
 def mesh_depth_fwd(vertices, faces, out_size, src_size=640, clamp_max=100.0):
     """vertices [B,NV,4] (src_size pixel space) + faces [F,3] int32 -> depth [B,S,S]: triangle
     raster at src_size, clamp(max), bilinear resize to S, fused (only the sampled pixels)."""

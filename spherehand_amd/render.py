@@ -63,6 +63,22 @@ class HandBallPrimitiveRender(nn.Module):
         B = pts.shape[0]
         return torch.cat([pts[:, :, 0:3], self.radiuses.expand(B, -1).unsqueeze(-1)], dim=2)
 
+    def pose_spheres(self, hand_transformation_mat, parameters):
+        """spheres(hand_transformation_mat(parameters)) without the bone transforms visiting HBM: pose [B,26] -> sphere
+        records [B,41,4], one launch per direction (ops.PoseSpheres; the same records and pose gradient, bit for bit,
+        as the two modules chained).  `hand_transformation_mat`: the kinematicsTransformation.HandTransformationMat
+        whose offset matrices the bones carry."""
+        fk, lbs = hand_transformation_mat, self.lbs
+        if not (parameters.is_cuda and parameters.dtype == torch.float32 and lbs.single_bone and fk.offset.shape[0] == 17):
+            return self.spheres(fk(parameters))
+        return ops.PoseSpheres.apply(parameters, fk.offset, fk.offset_inv, lbs.kp_bone, lbs.skin_wv, self.radiuses.view(-1),
+                                     lbs.kp_bone_start, lbs.kp_bone_points, lbs.right_hand)
+
+    def pose_depth(self, hand_transformation_mat, parameters):
+        """pose [B,26] -> depth maps [B,H,W] (the differentiable output of forward(), without the part maps): the fit
+        chain's three launches per direction."""
+        return ops.SphereDepthRaster.apply(self.pose_spheres(hand_transformation_mat, parameters), self.height, self.width)
+
     def forward(self, transformation_mats):
         sph = self.spheres(transformation_mats).contiguous()
         B = sph.shape[0]

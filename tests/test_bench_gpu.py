@@ -55,7 +55,27 @@ def test_bench_one_rank_over_rccl():
     assert d["value"] > 1e6 and 0 < d["roofline"]["frac"] < 1
 
 
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher in front of it (how the driver starts its N = 1 run): bench.py itself
+    re-executes under torch.distributed.run with two ranks and still prints ONE JSON line from rank 0 (gloo + a pinned
+    device through the test hooks: this box has one GPU)."""
+    env = dict(os.environ, SHR_BENCH_BACKEND="gloo", SHR_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
+               SHR_BENCH_DDP_STEPS="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["config"]["rccl_ranks"] == 2
+    assert abs(d["value"] - 2 * 256 * 20 / (d["ms_per_step"] * 1e-3 * 20)) <= 1e-3 * d["value"]
+
+
 def test_bench_rejects_a_world_size_mismatch():
+    """one rank launched (WORLD_SIZE=1 in the environment) but --gpus 2 asked for: refused, not silently a 1-GPU number"""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0 and "nproc-per-node" in (r.stderr + r.stdout)

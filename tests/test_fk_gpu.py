@@ -145,3 +145,74 @@ def test_keypoint_spheres_kernel_vs_torch_skinning(fk):
         ops.KeypointSpheres.apply(T1.detach()[:, :5], hbr.lbs.kp_bone, hbr.lbs.skin_wv, hbr.radiuses.view(-1),
                                   hbr.lbs.kp_bone_start, hbr.lbs.kp_bone_points, True)
 
+
+
+def test_pose_spheres_one_launch_equals_the_two_modules(fk):
+    """ops.PoseSpheres (shr_pose_spheres_fwd / _bwd: pose -> sphere records and back, the bone transforms never in HBM)
+    against HandTransformationMat followed by KeypointSpheres: records, the optional T output and the pose gradient
+    BIT-identical (one device function, the same LDS rows); the records against the reference's own centres (g3) at the
+    FK tolerance; ragged batch sizes (one wave per sample, no tail handling to get wrong), the empty batch, a left hand."""
+    from spherehand_amd import hand_model, ops, _lib
+    from spherehand_amd.render import HandBallPrimitiveRender
+    g = golden("g3_batch256.npz")
+    hbr = HandBallPrimitiveRender(hand_model.load_mesh()["bones"], 128, 128).cuda()
+    for n in (256, 1, 3, 65):
+        p1 = dev(g["params"][:n]).requires_grad_(True)
+        p2 = dev(g["params"][:n]).requires_grad_(True)
+        one = hbr.pose_spheres(fk, p1)
+        two = hbr.spheres(fk(p2))
+        assert one.shape == (n, 41, 4) and torch.equal(one, two)
+        G = torch.randn(n, 41, 4, device="cuda", generator=torch.Generator(device="cuda").manual_seed(11 + n))
+        (one * G).sum().backward()
+        (two * G).sum().backward()
+        assert torch.equal(p1.grad, p2.grad)
+        assert np.abs(one[..., :3].detach().cpu().numpy() - g["centres"][:n, :, :3]).max() <= 3e-4
+    # T as a second output of the forward entry
+    p = dev(g["params"])
+    lbs = hbr.lbs
+    sph = torch.empty(256, 41, 4, device="cuda")
+    T = torch.empty(256, 17, 4, 4, device="cuda")
+    _lib.check(_lib.lib().shr_pose_spheres_fwd(p.data_ptr(), 256, fk.offset.data_ptr(), fk.offset_inv.data_ptr(), 41,
+                                               lbs.kp_bone.data_ptr(), lbs.skin_wv.data_ptr(), hbr.radiuses.data_ptr(), 1,
+                                               sph.data_ptr(), T.data_ptr(), ops._stream()), "shr_pose_spheres_fwd")
+    assert torch.equal(T, fk(p)) and torch.equal(sph, hbr.spheres(fk(p)))
+    assert torch.equal(T[:, :, 3], torch.tensor([0., 0., 0., 1.], device="cuda").expand(256, 17, 4))
+    assert hbr.pose_spheres(fk, p[:0]).shape == (0, 41, 4)
+    # pose -> depth through the one-launch chain = the modules chained
+    d1 = hbr.pose_depth(fk, p[:32])
+    _, d2 = hbr(fk(p[:32]))
+    assert torch.equal(d1, d2)
+    # left hand: x keeps its sign
+    left = HandBallPrimitiveRender(hand_model.load_mesh()["bones"], 128, 128).cuda()
+    left.lbs.right_hand = False
+    a, b2 = left.pose_spheres(fk, p[:8]), left.spheres(fk(p[:8]))
+    assert torch.equal(a, b2) and torch.equal(a[..., 0], -hbr.pose_spheres(fk, p[:8])[..., 0])
+    with pytest.raises(RuntimeError):
+        ops.PoseSpheres.apply(p[:, :25].contiguous(), fk.offset, fk.offset_inv, lbs.kp_bone, lbs.skin_wv,
+                              hbr.radiuses.view(-1), lbs.kp_bone_start, lbs.kp_bone_points, True)
+
+
+def test_fk_gradient_vs_fp64_autograd(fk):
+    """The analytic backward (row chains in reverse, fk.hip) against torch autograd of the same map in fp64, for a
+    random upstream on T and on the sphere records: <= 2e-6 of the largest entry (fp32 rounding of ~30 terms)."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.render import HandBallPrimitiveRender
+    g = golden("g3_batch256.npz")
+    hbr = HandBallPrimitiveRender(hand_model.load_mesh()["bones"], 128, 128).cuda()
+    fk64 = type(fk)([b["offset_matrix"].astype(np.float32) for b in hand_model.load_mesh()["bones"]]).cuda().double()
+    fk64.offset_inv = fk.offset_inv.double()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    p = dev(g["params"]).requires_grad_(True)
+    q = dev(g["params"]).double().requires_grad_(True)
+    G = torch.randn(256, 17, 4, 4, device="cuda", generator=gen)
+    (fk(p) * G).sum().backward()
+    (fk64.forward_torch(q) * G.double()).sum().backward()
+    assert (p.grad.double() - q.grad).abs().max().item() <= 2e-6 * q.grad.abs().max().item()
+    p.grad = None
+    q.grad = None
+    Gs = torch.randn(256, 41, 4, device="cuda", generator=gen)
+    (hbr.pose_spheres(fk, p) * Gs).sum().backward()
+    pts = hbr.lbs.double()(fk64.forward_torch(q))
+    hbr.lbs.float()
+    (pts[..., :3] * Gs[..., :3].double()).sum().backward()
+    assert (p.grad.double() - q.grad).abs().max().item() <= 2e-6 * q.grad.abs().max().item()

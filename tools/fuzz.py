@@ -381,9 +381,15 @@ def ks_case():
     (sph * G).sum().backward(); (ref * G).sum().backward()
     ok = (sph - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item()) + 2e-5 and \
         (T1.grad - T2.grad).abs().max().item() <= 2e-6 * max(1.0, T2.grad.abs().max().item())
+    # the one-launch chain pose -> records (fk.hip, shr_pose_spheres_*) = the two modules chained, bit for bit
+    q1 = dev(p).requires_grad_(True); q2 = dev(p).requires_grad_(True)
+    one = hbr.pose_spheres(_fk, q1); two = hbr.spheres(_fk(q2))
+    (one * G).sum().backward(); (two * G).sum().backward()
+    ok = ok and torch.equal(one, two) and torch.equal(q1.grad, q2.grad)
     if not ok:
         fails += 1
-        print("KEYPOINT-SPHERES MISMATCH", dict(B=B), (sph - ref).abs().max().item(), (T1.grad - T2.grad).abs().max().item())
+        print("KEYPOINT-SPHERES MISMATCH", dict(B=B), (sph - ref).abs().max().item(), (T1.grad - T2.grad).abs().max().item(),
+              torch.equal(one, two), torch.equal(q1.grad, q2.grad))
 
 
 FAMILIES = (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case),
