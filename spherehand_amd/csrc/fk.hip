@@ -84,8 +84,7 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 
 constexpr int kBones = 17;
 constexpr int kAngles = 23;          // palm Euler angles + 5 x 4 finger angles
-// the slot of parameter a in the sincos table (the three translations have none)
-__device__ __forceinline__ int angle_slot(int a) { return a < 3 ? a : a - 3; }
+constexpr int kMaxPoints = 128;      // key-points the one-launch backward stages per sample (the hand has 41)
 
 // One sample's sincos table: lanes 0..22 take one angle each.
 __device__ __forceinline__ void sincos_phase(const float *__restrict__ p, int lane, Rot *sc) {
@@ -215,6 +214,8 @@ pose_bwd_kernel(const float *__restrict__ params, const float *__restrict__ offs
   __shared__ Rot sc[kAngles];
   __shared__ float4 gT[kBones * 3];    // d loss / d T[b, bone, row < 3, :]
   __shared__ float4 pbar[6 * 3];       // the six groups' contributions to d loss / d P
+  __shared__ float4 sg[FROM_SPH ? kMaxPoints : 1], sw[FROM_SPH ? kMaxPoints : 1];
+  __shared__ int sj[FROM_SPH ? kMaxPoints : 1];
   const int b = blockIdx.x, lane = threadIdx.x;
   const int g = lane >> 2, i = lane & 3;
   const float *p = params + (size_t)b * 26;
@@ -227,24 +228,56 @@ pose_bwd_kernel(const float *__restrict__ params, const float *__restrict__ offs
     k3 = load_bone(offset, offset_inv, b0 + 2);
   }
   const float t = chain ? p[3 + i] : 0.f;
-  if (lane < kBones * 3) {             // lane = 3 * bone + row
-    const int nb = lane / 3, r = lane - 3 * nb;
+  if (FROM_SPH) {
+    // Stage the sample's gradient records (as they lie: one coalesced load) and the key-points in bone order
+    // (entry k = point bone_points[k]) in LDS, in flight while the sincos run.  (Walking the CSR lists straight from
+    // HBM was a chain of dependent loads per point -- 11 for the palm -- and 3 us of this kernel's 6.2.)
+    for (int k = lane; k < J && k < kMaxPoints; k += 64) {
+      const int j = bone_points[k];
+      sg[k] = grad_spheres[(size_t)b * J + k];
+      sj[k] = j;
+      sw[k] = wv[j];
+    }
+  }
+  int ks = 0, ke = 0;
+  float4 gdirect = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nb = lane / 3, r = lane - 3 * nb;   // lane = 3 * bone + row
+  if (lane < kBones * 3) {
     if (FROM_SPH) {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int k1e = bone_start[nb + 1];
-      for (int k = bone_start[nb]; k < k1e; k++) {
-        const int j = bone_points[k];
-        const float4 gs = grad_spheres[(size_t)b * J + j];
-        const float4 w = wv[j];
-        const float gr = r == 0 ? sx * gs.x : r == 1 ? gs.y : gs.z;
-        a.x += gr * w.x; a.y += gr * w.y; a.z += gr * w.z; a.w += gr * w.w;
-      }
-      gT[lane] = a;
+      ks = bone_start[nb];
+      ke = bone_start[nb + 1];
     } else {
-      gT[lane] = ld4(grad_T + ((size_t)b * kBones + nb) * 16 + 4 * r);
+      gdirect = ld4(grad_T + ((size_t)b * kBones + nb) * 16 + 4 * r);
     }
   }
   sincos_phase(p, lane, sc);
+  if (FROM_SPH) __syncthreads();
+  if (lane < kBones * 3) {
+    if (FROM_SPH) {
+      // keypoint_spheres_bwd_kernel's sums, point by point in index order (the same bits); four entries are read
+      // ahead and the ones past the bone's end are skipped by predicate
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = ks; k < ke; k += 4) {
+        float4 gs[4], w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int kk = min(k + q, kMaxPoints - 1);
+          gs[q] = sg[min(sj[kk], kMaxPoints - 1)];
+          w[q] = sw[kk];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float gr = r == 0 ? sx * gs[q].x : r == 1 ? gs[q].y : gs[q].z;
+          const bool on = k + q < ke;
+          const float nx = a.x + gr * w[q].x, ny = a.y + gr * w[q].y, nz = a.z + gr * w[q].z, nw = a.w + gr * w[q].w;
+          a = on ? make_float4(nx, ny, nz, nw) : a;
+        }
+      }
+      gT[lane] = a;
+    } else {
+      gT[lane] = gdirect;
+    }
+  }
   __syncthreads();
   PalmRow P;
   float ga0 = 0.f, ga1 = 0.f, ga2 = 0.f, ga3 = 0.f;
@@ -381,6 +414,7 @@ extern "C" int shr_pose_spheres_bwd(const float *params, int B, const float *off
   using namespace shr;
   if (B == 0) return SHR_OK;
   if (!bone_start || !bone_points || !wv || !grad_spheres || !grad_params || J < 0) return SHR_EINVAL;
+  if (J > kMaxPoints) return SHR_ETOOLARGE;
   if ((((uintptr_t)wv | (uintptr_t)grad_spheres) & 15u) != 0 || (((uintptr_t)grad_params) & 7u) != 0) return SHR_EINVAL;
   if (int rc = fk_check(params, B, offset, offset_inv)) return rc;
   if ((long long)B * J > (1LL << 30)) return SHR_ETOOLARGE;

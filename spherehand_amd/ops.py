@@ -644,6 +644,52 @@ class PoseSpheres(torch.autograd.Function):
         return out, None, None, None, None, None, None, None, None
 
 
+class PoseDepthRaster(torch.autograd.Function):
+    """params [B,26] -> depth [B,H,W]: PoseSpheres followed by SphereDepthRaster as ONE autograd node (two launches per
+    direction; an eager fitting loop pays the Python / autograd cost of one Function instead of two).  Same kernels,
+    same bits as the two Functions chained."""
+
+    @staticmethod
+    def forward(ctx, params, offset, offset_inv, bone, wv, radii, bone_start, bone_points, right_hand, H, W):
+        params = params.contiguous().float()
+        _check_input(params, "parameters")
+        if params.dim() != 2 or params.shape[1] != 26:
+            raise RuntimeError("parameters must be [B,26]")
+        B, J = params.shape[0], bone.shape[0]
+        if bone_start.shape[0] != 18 or wv.shape != (J, 4) or radii.numel() != J:
+            raise RuntimeError("key-point tables do not match the 17 bones")
+        lib, right = _lib.lib(), int(bool(right_hand))
+        want = ctx.needs_input_grad[0]
+        with _on(params.device):
+            s = _stream()
+            sph = torch.empty((B, J, 4), dtype=torch.float32, device=params.device)
+            depth = torch.empty((B, H, W), dtype=torch.float32, device=params.device)
+            owner = torch.empty((B, H, W), dtype=torch.uint8, device=params.device) if want else None
+            _lib.check(lib.shr_pose_spheres_fwd(_ptr(params), B, _ptr(offset), _ptr(offset_inv), J, _ptr(bone), _ptr(wv),
+                                                _ptr(radii), right, _ptr(sph), None, s), "shr_pose_spheres_fwd")
+            _lib.check(lib.shr_sphere_raster_fwd_ex(_ptr(sph), B, J, H, W, _ptr(depth), _ptr(owner),
+                                                    RASTER_OWNER_TOUCHED_ROWS if want else 0, s), "shr_sphere_raster_fwd")
+        if want:
+            ctx.save_for_backward(params, offset, offset_inv, wv, bone_start, bone_points, sph, owner)
+            ctx.dims = (B, J, right, H, W)
+        return depth
+
+    @staticmethod
+    def backward(ctx, grad_depth):
+        params, offset, offset_inv, wv, bone_start, bone_points, sph, owner = ctx.saved_tensors
+        B, J, right, H, W = ctx.dims
+        g = grad_depth.contiguous()
+        lib = _lib.lib()
+        with _on(g.device):
+            s = _stream()
+            gs = torch.empty((B, J, 4), dtype=torch.float32, device=g.device)
+            out = torch.empty((B, 26), dtype=torch.float32, device=g.device)
+            _lib.check(lib.shr_sphere_raster_bwd(_ptr(sph), _ptr(g), _ptr(owner), B, J, H, W, _ptr(gs), s), "shr_sphere_raster_bwd")
+            _lib.check(lib.shr_pose_spheres_bwd(_ptr(params), B, _ptr(offset), _ptr(offset_inv), J, _ptr(bone_start),
+                                                _ptr(bone_points), _ptr(wv), right, _ptr(gs), _ptr(out), s), "shr_pose_spheres_bwd")
+        return (out,) + (None,) * 10
+
+
 def mesh_depth_fwd(vertices, faces, out_size, src_size=640, clamp_max=100.0):
     """vertices [B,NV,4] (src_size pixel space) + faces [F,3] int32 -> depth [B,S,S]: triangle
     raster at src_size, clamp(max), bilinear resize to S, fused (only the sampled pixels)."""

@@ -77,7 +77,12 @@ class HandBallPrimitiveRender(nn.Module):
     def pose_depth(self, hand_transformation_mat, parameters):
         """pose [B,26] -> depth maps [B,H,W] (the differentiable output of forward(), without the part maps): the fit
         chain's three launches per direction."""
-        return ops.SphereDepthRaster.apply(self.pose_spheres(hand_transformation_mat, parameters), self.height, self.width)
+        fk, lbs = hand_transformation_mat, self.lbs
+        if not (parameters.is_cuda and parameters.dtype == torch.float32 and lbs.single_bone and fk.offset.shape[0] == 17
+                and parameters.shape[0] > 0):
+            return ops.SphereDepthRaster.apply(self.pose_spheres(fk, parameters), self.height, self.width)
+        return ops.PoseDepthRaster.apply(parameters, fk.offset, fk.offset_inv, lbs.kp_bone, lbs.skin_wv, self.radiuses.view(-1),
+                                         lbs.kp_bone_start, lbs.kp_bone_points, lbs.right_hand, self.height, self.width)
 
     def forward(self, transformation_mats):
         sph = self.spheres(transformation_mats).contiguous()

@@ -224,7 +224,7 @@ def test_synth_post_kernels_match_the_torch_modules():
             a = hm(T, rand_f, 1.0, 0.01)                      # kernels
         with torch.enable_grad():
             b = hm(T, rand_f, 1.0, 0.01)                      # torch ops
-        for x, y, tol in zip(a, b, (2e-6, 1e-7, 2e-4)):
+        for x, y, tol in zip(a, b, (2e-6, 1.2e-7, 2e-4)):      # (depth heat-map: values up to 1, one ulp there)
             assert x.shape == y.shape and (x - y).abs().max().item() <= tol
     # depth noise: identical to the torch formula fed the same normal draws
     dm = (torch.rand(5, 64, 64, device="cuda") * 1.4).contiguous()

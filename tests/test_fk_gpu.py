@@ -179,9 +179,15 @@ def test_pose_spheres_one_launch_equals_the_two_modules(fk):
     assert torch.equal(T[:, :, 3], torch.tensor([0., 0., 0., 1.], device="cuda").expand(256, 17, 4))
     assert hbr.pose_spheres(fk, p[:0]).shape == (0, 41, 4)
     # pose -> depth through the one-launch chain = the modules chained
-    d1 = hbr.pose_depth(fk, p[:32])
-    _, d2 = hbr(fk(p[:32]))
-    assert torch.equal(d1, d2)
+    q1 = dev(g["params"][:32]).requires_grad_(True)
+    q2 = dev(g["params"][:32]).requires_grad_(True)
+    d1 = hbr.pose_depth(fk, q1)                    # ops.PoseDepthRaster: one autograd node, two launches per direction
+    _, d2 = hbr(fk(q2))
+    assert torch.equal(d1, d2) and torch.equal(hbr.pose_depth(fk, p[:32]), d2)
+    gd = torch.randn(32, 128, 128, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    d1.backward(gd)
+    d2.backward(gd)
+    assert torch.equal(q1.grad, q2.grad) and q1.grad.abs().max().item() > 0
     # left hand: x keeps its sign
     left = HandBallPrimitiveRender(hand_model.load_mesh()["bones"], 128, 128).cuda()
     left.lbs.right_hand = False
