@@ -297,7 +297,9 @@ int shr_mv_project_compact(const float *cam, const float *inv_cam, const float *
  *   through the detached view transforms).  fp64 accumulation of the scalar in a fixed order: deterministic.
  * is_mv: 1 = all pairs; 0 = the same-view pairs, picked out of sse_part / grad_spheres_part of all N pairs; 2 = the
  * same-view pairs with sse_part [B*V][Rm] / grad_spheres_part [B*V][Rm][J][4] holding those pairs only (entry b*V+i:
- * the caller ran shr_sphere_raster_mse on them alone) -- same values as 0. */
+ * the caller ran shr_sphere_raster_mse on them alone) -- same values as 0.
+ * Limits: V <= 8 (the pairs of a view are summed by a 4- or 8-lane butterfly; SHR_ETOOLARGE beyond -- the reference
+ * runs V = 3, mesh/multiview_utility.py:107), 4*B*V*V*J*max(Rm,Rd) below 2^31 (SHR_ETOOLARGE). */
 int shr_mv_loss_combine(const float *cam, const float *inv_cam, const float *sse_part,
                         const float *grad_spheres_part, int Rm, const float *d2m_part,
                         const float *grad_d2m_part, int Rd, int B, int V, int J, int H, int W, int is_mv,

@@ -136,6 +136,7 @@ class MultiTaskLoss(nn.Module):
                 values.append(loss)
                 projected_dms.append(dm)
             entries.append(('mv_projection', w['mv_projection'], values))
+            self.mv_projection_loss.invalidate()     # (the stacks shared one compaction; nothing stays pinned between steps)
         if self.mv_consistency_loss is not None and real_target is not None:
             entries.append(('mv_consistency', w['mv_consistency'] if is_mv else 0,
                             [self.mv_consistency_loss(real_target['camera_poses'], xyz, None)

@@ -192,6 +192,7 @@ extern "C" int shr_mv_loss_combine(const float *cam, const float *inv_cam, const
   const double wd = (double)d2m_weight * wm;
   const long long total = (long long)B * V * J;
   if (V > 8) return SHR_ETOOLARGE;   // (the pairs of a view sit side by side in 4 or 8 lanes)
+  if ((long long)B * V * V * (Rm > Rd ? Rm : Rd) * J * 4 > (1LL << 31) - 4096) return SHR_ETOOLARGE;   // 32-bit entry counts and offsets
   const long long lanes = total * (V <= 4 ? 4 : 8);
   if (lanes > (1LL << 31) - 512) return SHR_ETOOLARGE;
   hipLaunchKernelGGL(mv_loss_combine_kernel, dim3((unsigned)((lanes + 255) / 256 + 1)), dim3(256), 0, (hipStream_t)stream,

@@ -62,10 +62,19 @@ class MutualProjectionLoss(nn.Module):
         # The data->model term first compacts every observed image into a point list (ops.d2m_compact): work that
         # depends on the observations only.  While forward() is handed the SAME observations again -- the reference
         # calls the loss once per hourglass stack with one real_dms (network/create_network_and_criterion.py:206-218),
-        # a fitting loop iterates on fixed images -- the lists are kept: same storage, same version counter, and the
-        # cache holds a reference to the tensor so that its memory cannot be recycled for other data meanwhile.
+        # a fitting loop iterates on fixed images -- the lists are kept.  A hit needs ALL of: the same storage, offset
+        # and shape, the same version counter, the same stream as the call that filled the lists (another stream
+        # would race with the compaction), and no stream capture in progress (a captured graph must contain its own
+        # compaction: its replays run on new contents of the same buffer).  A write that bypasses the version
+        # counter (`.data`, a raw pointer, another library) is invisible to all of that: call invalidate() after one,
+        # or set cache_points = False.  The cache holds the observed tensor and its workspace (8 bytes per pixel)
+        # alive until the next call or invalidate(); MultiTaskLoss drops it once a step's stacks are through.
         self.cache_points = True
-        self._points = None        # (observed tensor, version, workspace)
+        self._points = None        # (observed tensor, version, workspace, stream)
+
+    def invalidate(self):
+        """Forget the cached point lists (and release the observed tensor and the workspace they pin)."""
+        self._points = None
 
     def forward(self, camera_poses, inv_camera_poses, joints, depth_maps, is_mv=True):
         B, V = camera_poses.shape[0], camera_poses.shape[1]
@@ -79,11 +88,11 @@ class MutualProjectionLoss(nn.Module):
             if W % 4 == 0 and observed.data_ptr() % 16 == 0 and \
                     ops._lib.lib().shr_sphere_raster_mse_regions(int(H), int(W)) > 0:
                 index, diag = self._indices(B, V, joints.device)
-                ws, fresh = self._point_lists(observed) if ops.d2m_two_step_pays(observed) else (None, False)
+                ws, fresh, keep = self._point_lists(observed) if ops.d2m_two_step_pays(observed) else (None, False, None)
                 loss, projected = ops.MutualProjectionLossFused.apply(camera_poses, inv_camera_poses, joints, observed, radii,
                                                                       index, diag, bool(is_mv), 500.0, ws, fresh)
-                if fresh:        # (kept only once the call that fills them has been issued)
-                    self._points = (observed, observed._version, ws) if self.cache_points else None
+                if keep is not None:        # (kept only once the call that fills them has been issued)
+                    self._points = keep
                 return loss, projected.view(B, V, V, H, W)
         projected_dms, projected_joints = mp(camera_poses, inv_camera_poses, joints)
         J = projected_joints.shape[3]
@@ -107,12 +116,23 @@ class MutualProjectionLoss(nn.Module):
         return loss, projected_dms
 
     def _point_lists(self, observed):
-        c = self._points
-        if self.cache_points and c is not None and c[0].untyped_storage().data_ptr() == observed.untyped_storage().data_ptr() \
+        """-> (workspace, fresh, entry to keep after the filling call or None)."""
+        c, self._points = self._points, None                   # a miss drops what was cached (and what it pins)
+        capturing = torch.cuda.is_current_stream_capturing()
+        stream = ops._stream()
+        try:
+            version = observed._version
+        except RuntimeError:                                   # inference-mode tensors carry no version counter
+            version = None
+        if self.cache_points and c is not None and not capturing and version is not None and c[1] == version \
+                and c[3] == stream and c[0].untyped_storage().data_ptr() == observed.untyped_storage().data_ptr() \
                 and c[0].storage_offset() == observed.storage_offset() and c[0].shape == observed.shape \
-                and c[0].device == observed.device and c[1] == observed._version:
-            return c[2], False
-        return ops.d2m_points_workspace(observed), True   # filled by the fused Function, with the view projection's launch
+                and c[0].device == observed.device:
+            self._points = c
+            return c[2], False, None
+        ws = ops.d2m_points_workspace(observed)   # filled by the fused Function, with the view projection's launch
+        keep = (observed, version, ws, stream) if self.cache_points and not capturing and version is not None else None
+        return ws, True, keep
 
     def _indices(self, B, V, dev):
         key = (B, V, str(dev))

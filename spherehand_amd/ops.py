@@ -15,8 +15,11 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-_raw_stream = torch._C._cuda_getCurrentRawStream     # (device index) -> hipStream_t of torch's current stream
-_cur_device = torch._C._cuda_getDevice
+# (device index) -> hipStream_t of torch's current stream, and the current device index.  The two private accessors
+# are 13 us per call cheaper than the public spelling (see _stream); a torch build without them (CPU-only wheels, a
+# rename) falls back to the public one -- importing this module never fails for that.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda d: torch.cuda.current_stream(d).cuda_stream)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 
 
 def _stream():
@@ -201,7 +204,11 @@ D2M_TWO_STEP = True   # data->model: compact the images once + search the point 
 def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
     """depth [N,H,W], centres [N,J,3], radii [J] -> loss_sum [N] (and the unit
     gradient d loss_sum[n]/d centres [N,J,3]).  With depth_index [N] int32, depth is
-    [M,H,W] and crop n reads image depth_index[n]."""
+    [M,H,W] and crop n reads image depth_index[n].
+    Two paths by stack size (d2m_two_step_pays): the two-step path returns ONE integer sum per crop; the streaming
+    kernel returns R = shr_data_to_model_parts partial sums per crop (R = 2 from 192x192 pixels on), each an exact
+    integer sum, ADDED here in fp32.  The two agree bit for bit where R = 1 and to one fp32 rounding of the crop's
+    total where R = 2 -- a crop's value may move by that rounding with the batch size that selects the path."""
     _check_input(depth, "depth")
     _check_input(centres, "centres")
     _check_input(radii, "radii")
@@ -216,7 +223,7 @@ def data_to_model(depth, centres, radii, want_grad=False, depth_index=None):
     if depth_index is not None:
         _check_index(depth_index, N, depth.shape[0], "depth_index")
     if N > 0 and d2m_two_step_pays(depth, shared=depth_index is not None and N >= 2 * depth.shape[0]):
-        # compact every image once, search the point lists (bit-identical sums, see csrc/data_to_model.hip)
+        # compact every image once, search the point lists (the same integer sums, see csrc/data_to_model.hip)
         ws = d2m_compact(depth)
         return data_to_model_from_points(ws, depth.shape[0], H, W, centres, radii, depth_index, want_grad)
     lib = _lib.lib()

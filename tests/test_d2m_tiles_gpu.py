@@ -440,3 +440,60 @@ def test_same_view_pairs_compared_alone_give_the_same_results(S, B):
             assert abs(out[0][0].item() - out[1][0].item()) <= 1e-6 * abs(out[0][0].item()), it
     finally:
         ops.SAME_VIEW_SPLIT = keep
+
+
+@pytest.mark.parametrize("is_mv", [True, False])
+@pytest.mark.parametrize("cache", [True, False])
+def test_loss_module_captured_in_a_hipgraph_replays_on_new_inputs(is_mv, cache):
+    """MutualProjectionLoss forward + backward captured in ONE hipGraph -- two-step data->model path, render-and-compare
+    on the side stream (fork and join captured with it), the same-view split when is_mv is off, the point-list cache on
+    and off -- after an eager warm-up that leaves a filled cache behind (the case where a stale hit would keep the
+    compaction out of the graph).  Every replay on NEW joints and NEW observations copied into the static buffers must
+    equal the eager result of a fresh module on those inputs bit for bit: loss, projections, d loss / d joints."""
+    from spherehand_amd import hand_model, ops
+    from spherehand_amd.datasets import SyntheticMultiviewDataset
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    mesh = hand_model.load_mesh()
+    B, S = 12, 128
+    ds = [SyntheticMultiviewDataset(mesh, B, S, seed=20 + k, device="cuda") for k in range(3)]
+    cam, inv = ds[0].cam.cuda(), ds[0].inv_cam.cuda()
+    keep = ops.D2M_TWO_STEP_MIN_PIXELS
+    ops.D2M_TWO_STEP_MIN_PIXELS = 1 << 18                        # the two-step path at this (small) size
+    try:
+        crit = MutualProjectionLoss(S, mesh).cuda()
+        crit.cache_points = cache
+        ref = MutualProjectionLoss(S, mesh).cuda()
+        ref.cache_points = False
+        static_j = (ds[0].joints.cuda() + 0.5).requires_grad_(True)
+        static_dms = ds[0].dms.cuda().clone()
+        assert ops.d2m_two_step_pays(static_dms.view(B * 3, S, S))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                             # eager warm-up: fills the cache when it is on
+            for _ in range(2):
+                loss, _ = crit(cam, inv, static_j, static_dms, is_mv)
+                loss.backward()
+                static_j.grad = None
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss, proj = crit(cam, inv, static_j, static_dms, is_mv)
+            loss.backward()
+        for k in (1, 2, 0, 1):
+            with torch.no_grad():
+                static_j.copy_(ds[k].joints.cuda() + 0.25 * k)
+                static_dms.copy_(ds[k].dms.cuda())
+            g.replay()
+            torch.cuda.synchronize()
+            j = (ds[k].joints.cuda() + 0.25 * k).requires_grad_(True)
+            want_loss, want_proj = ref(cam, inv, j, ds[k].dms.cuda(), is_mv)
+            want_loss.backward()
+            assert torch.equal(loss, want_loss.detach()), (k, loss.item(), want_loss.item())
+            assert torch.equal(proj, want_proj.detach()), k
+            assert torch.equal(static_j.grad, j.grad), k
+        # and eagerly again afterwards, on changed observations in the same buffer (version counter moved by copy_)
+        l2, _ = crit(cam, inv, static_j.detach(), static_dms, is_mv)
+        assert torch.equal(l2, ref(cam, inv, static_j.detach(), static_dms.clone(), is_mv)[0])
+    finally:
+        ops.D2M_TWO_STEP_MIN_PIXELS = keep

@@ -140,3 +140,36 @@ def test_pair_losses_kernel_matches_the_modules():
     assert ref[0] > 0 and ref[1] > 0
     assert (b.grad - ref[2]).abs().max().item() <= 1e-5 * max(1.0, ref[2].abs().max().item())
     assert b.grad[:, 1:].abs().max().item() == 0          # the other views are not looked at
+
+
+def test_fuzz_case_r04_one_sphere_256x256(oracle):
+    """The one case a round-4 fuzz campaign saved (gpurun_out/fuzz_d2m_fail.npz, 08:12 that round: J = 1 @256x256, 5.8 %
+    foreground) -- kept as data (tests/golden/fuzz_d2m_case_r04.npz: depth, centre, radius) and replayed through every
+    path: streaming kernel in three launch shapes, loss-only launch, two-step path, all against the oracle at the
+    family's tolerances.  The saved outputs already met the oracle tolerance (one gradient ulp): the campaign's flag was
+    its launch-shape comparison on a build of that morning; on this tree the case passes, and stays here."""
+    from spherehand_amd import ops
+    g = golden("fuzz_d2m_case_r04.npz")
+    depth, cen, rad = g["depth"], g["cen"], g["rad"]
+    ol = oracle.data_to_model_fwd(depth, cen, rad)
+    og = oracle.data_to_model_bwd(depth, cen, rad) * depth.size
+    outs = []
+    try:
+        for waves, units in ((0, 0), (4, 1), (16, 8), (8, 3)):
+            ops.set_tuning(ops.TUNE_D2M_WAVES, waves)
+            ops.set_tuning(ops.TUNE_D2M_BAND_UNITS, units)
+            loss, grad = ops.data_to_model(dev(depth), dev(cen), dev(rad), want_grad=True)
+            loss_only = ops.data_to_model(dev(depth), dev(cen), dev(rad))
+            assert torch.equal(loss, loss_only)
+            outs.append((loss.cpu().numpy(), grad.cpu().numpy()))
+    finally:
+        ops.set_tuning(ops.TUNE_D2M_WAVES, 0)
+        ops.set_tuning(ops.TUNE_D2M_BAND_UNITS, 0)
+    ws = ops.d2m_compact(dev(depth))
+    outs.append(tuple(t.cpu().numpy() for t in ops.data_to_model_from_points(ws, 1, 256, 256, dev(cen), dev(rad), None, True)))
+    for loss, grad in outs:
+        assert np.abs(loss - ol).max() <= 2e-7 * np.abs(ol).max() + 1e-6
+        assert np.abs(grad - og).max() <= 1e-5 * np.abs(og).max() + 1e-6
+        # across launch shapes: two fp32 partial sums per crop at this size, the split moves with the shape
+        assert np.abs(loss - outs[0][0]).max() <= 1e-6 * np.abs(ol).max()
+        assert np.abs(grad - outs[0][1]).max() <= 1e-6 * np.abs(og).max() + 1e-6
