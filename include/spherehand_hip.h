@@ -45,7 +45,8 @@ int shr_device_info(char *name_host, int name_len, int *num_cu_host);
 
 /* Launch-shape tuning / test hooks (process-wide, not thread-safe; results never
  * depend on them).  *_LDS_BYTES cap the LDS a workgroup of the z-buffer kernels
- * may take (decides rows per region and workgroups per CU); FORCE_GENERAL = 1
+ * may take (decides rows per region and workgroups per CU; FWD_LDS_BYTES 0 = the
+ * default); FORCE_GENERAL = 1
  * routes every call to the general tile kernels. */
 #define SHR_TUNE_FWD_LDS_BYTES 1
 #define SHR_TUNE_FWD_OWNER_LDS_BYTES 2
@@ -176,6 +177,13 @@ int shr_data_to_model_from_points(const void *workspace, int M, const int32_t *d
                                   const float *centres, int centre_stride, const float *radii,
                                   int N, int J, int H, int W, int parts, float *loss_parts,
                                   float *grad_parts, void *stream);
+/* The same with crop n searching with record set centre_index[n] of `centres` (NULL: n): the V same-view pairs of a
+ * [B,V,V] batch of projections without gathering their records first (MutualProjectionLoss with is_mv = False,
+ * mesh/multiview_utility.py:107-127). */
+int shr_data_to_model_from_points_indexed(const void *workspace, int M, const int32_t *depth_index,
+                                          const int32_t *centre_index, const float *centres, int centre_stride,
+                                          const float *radii, int N, int J, int H, int W, int parts,
+                                          float *loss_parts, float *grad_parts, void *stream);
 
 /* Fused render-and-compare: the model->data term of mesh/multiview_utility.py:98-101 and
  * :107-113 (MSELoss(BallRender(...).min(), observed)) with its whole backward, one
@@ -194,6 +202,13 @@ int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W,
                           const float *target, const int32_t *target_index,
                           float *depth, float *sse_partial,
                           float *grad_spheres_partial, void *stream);
+/* The same over a SELECTION of the batch: workgroup n (0 <= n < N) renders crop c = crop_index[n] (NULL: n) -- records
+ * spheres[c], observed image target_index[c] (or c), depth[c] when depth is given -- and reports into slot n of
+ * sse_partial / grad_spheres_partial ([N][R], [N][R][J][4]).  The same-view pairs of MutualProjectionLoss with
+ * is_mv = False (mesh/multiview_utility.py:107-113) out of the [B,V,V] projections, no gather in front. */
+int shr_sphere_raster_mse_indexed(const float *spheres, const int32_t *crop_index, int N, int J, int H, int W,
+                                  const float *target, const int32_t *target_index, float *depth,
+                                  float *sse_partial, float *grad_spheres_partial, void *stream);
 
 /* CollisionLoss and BoneLengthLoss (mesh/render.py:145-206) on M samples of J sphere centres (sample m at
  * joints + m*sample_stride floats, [J][3]) with their gradients, one launch.  Collision pairs: spheres

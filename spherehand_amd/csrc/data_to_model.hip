@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 d2m_points_kernel(const uint2 *__restrict__ points, const int *__restrict__ counts, int P,
                   const int *__restrict__ depth_index, const float *__restrict__ centres, int centre_stride,
                   const float *__restrict__ radii, int J, int H, int W, int parts, float *__restrict__ loss_sum,
-                  float *__restrict__ grad_centres) {
+                  float *__restrict__ grad_centres, const int *__restrict__ centre_index) {
   constexpr int K = 4, GS = 64 * K;
   __shared__ float4 s_c[SHR_MAX_SPHERES];
   __shared__ int s_odd, s_nan;
@@ -452,7 +452,8 @@ d2m_points_kernel(const uint2 *__restrict__ points, const int *__restrict__ coun
   if (wave == 0) {
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane < J) {
-      const float *p = centres + ((size_t)n * J + lane) * centre_stride;
+      // (centre_index: crop n searches with record set centre_index[n] of the batch, shr_data_to_model_from_points_indexed)
+      const float *p = centres + ((size_t)(centre_index ? centre_index[n] : n) * J + lane) * centre_stride;
       c = make_float4(p[0], p[1], p[2], radii[lane]);
     }
     s_c[lane] = c;
@@ -663,6 +664,14 @@ extern "C" int shr_data_to_model_from_points(const void *workspace, int M, const
                                              const float *centres, int centre_stride, const float *radii, int N,
                                              int J, int H, int W, int parts, float *loss_parts, float *grad_parts,
                                              void *stream) {
+  return shr_data_to_model_from_points_indexed(workspace, M, depth_index, nullptr, centres, centre_stride, radii, N, J, H, W,
+                                               parts, loss_parts, grad_parts, stream);
+}
+
+extern "C" int shr_data_to_model_from_points_indexed(const void *workspace, int M, const int32_t *depth_index,
+                                                     const int32_t *centre_index, const float *centres, int centre_stride,
+                                                     const float *radii, int N, int J, int H, int W, int parts,
+                                                     float *loss_parts, float *grad_parts, void *stream) {
   using namespace shr;
   if (N == 0) return SHR_OK;
   if (!workspace || !centres || !radii || !loss_parts || N < 0 || M <= 0 || J <= 0 || H <= 0 || W <= 0) return SHR_EINVAL;
@@ -676,7 +685,7 @@ extern "C" int shr_data_to_model_from_points(const void *workspace, int M, const
   const long long wgs = (long long)N * parts;
   const int waves = g_d2m_waves ? g_d2m_waves : (wgs >= 2048 ? 4 : (wgs >= 768 ? 8 : 16));
 #define D2P_LAUNCH(G, NW) hipLaunchKernelGGL((d2m_points_kernel<G, NW>), grid, dim3(NW * 64), 0, s, points, counts, H * W, \
-                                             depth_index, centres, centre_stride, radii, J, H, W, parts, loss_parts, grad_parts)
+                                             depth_index, centres, centre_stride, radii, J, H, W, parts, loss_parts, grad_parts, centre_index)
   if (grad_parts) { if (waves >= 16) D2P_LAUNCH(true, 16); else if (waves >= 8) D2P_LAUNCH(true, 8); else D2P_LAUNCH(true, 4); }
   else { if (waves >= 16) D2P_LAUNCH(false, 16); else if (waves >= 8) D2P_LAUNCH(false, 8); else D2P_LAUNCH(false, 4); }
 #undef D2P_LAUNCH

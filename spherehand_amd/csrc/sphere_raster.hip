@@ -10,7 +10,11 @@ using namespace shr;
 namespace {
 
 struct Tuning {
-  int fwd_lds_bytes = 80 * 1024;        // depth-only forward: a whole 128x128 crop per workgroup (7.8 vs 9.6 us at 40 KB), two per CU
+  // depth-only forward: the LDS budget the ROW REGIONS are sized for.  A whole 128x128 crop per workgroup takes 73 KB
+  // (7.8 vs 9.6 us at 40 KB), two per CU; a 256x256 crop is cut into two 128-row regions (142 KB at the full pitch ->
+  // the box variant at half of the LDS, two per CU: 60 us for 1152 crops).  Round 4's 80 KB cut it into four 64-row
+  // regions whose whole-region z-buffer + run table took 92 KB: ONE workgroup per CU and 109 us (tools/exp_fwd256.py).
+  int fwd_lds_bytes = 160 * 1024;
   int fwd_owner_lds_bytes = 0;          // forward + owner map (64-bit keys); 0 = by batch size (below)
   int bwd_lds_bytes = 128 * 1024;       // backward staging (grad f32 + owner u8)
   int force_general = 0;                // 1: always the tile kernels (tests)
@@ -143,7 +147,11 @@ int launch_zbuf_fwd_t(const float4 *sp, int N, int J, int H, int W, float *depth
   if constexpr (VEC4 && POW2) {
     const size_t tab = (size_t)J * kWave * sizeof(uint2);
     static_assert(kZWaves == 16 && kBgWaves == 7, "the table kernel's wave roles");
-    if (g_tune.run_table != 0 && (int)grid.x >= N && g_tune.fwd_waves == kZWaves && lds + tab <= (size_t)kMaxLds &&
+    // (not when the table is what keeps a second workgroup off the CU in a launch that has two per CU: 1152 crops
+    // @256x256 in 64-row regions, 109 us with it, 70 without -- the table pays one workgroup's runs, not its neighbour)
+    const bool costs_a_neighbour = lds <= half && lds + tab > half && (long long)N * regions >= 2LL * num_cus();
+    if (g_tune.run_table != 0 && (g_tune.run_table > 0 || !costs_a_neighbour) && (int)grid.x >= N &&
+        g_tune.fwd_waves == kZWaves && lds + tab <= (size_t)kMaxLds &&
         ((size_t)zcells * key) % 16 == 0 && rows < 4096 && (long long)H * (W + kRowPad) < (1LL << 24))
       return launch_zbuf_fwd_p<OWNER, true, true, false, false, true>(sp, N, J, H, W, depth, argmin, rows, lds + tab, zcells, grid,
                                                                       flags, s);
@@ -210,7 +218,7 @@ int launch_zbuf_bwd(const float4 *sp, const float *grad, const uint8_t *argmin, 
 
 extern "C" int shr_set_tuning(int key, int value) {
   switch (key) {
-    case SHR_TUNE_FWD_LDS_BYTES: g_tune.fwd_lds_bytes = value; return SHR_OK;
+    case SHR_TUNE_FWD_LDS_BYTES: g_tune.fwd_lds_bytes = value > 0 ? value : Tuning().fwd_lds_bytes; return SHR_OK;   // 0: the default
     case SHR_TUNE_FWD_OWNER_LDS_BYTES: g_tune.fwd_owner_lds_bytes = value; return SHR_OK;
     case SHR_TUNE_BWD_LDS_BYTES: g_tune.bwd_lds_bytes = value; return SHR_OK;
     case SHR_TUNE_FORCE_GENERAL: g_tune.force_general = value; return SHR_OK;
@@ -348,6 +356,13 @@ extern "C" int shr_sphere_raster_mse_regions(int H, int W) {
 extern "C" int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W, const float *target,
                                      const int32_t *target_index, float *depth, float *sse_partial,
                                      float *grad_spheres_partial, void *stream) {
+  return shr_sphere_raster_mse_indexed(spheres, nullptr, N, J, H, W, target, target_index, depth, sse_partial,
+                                       grad_spheres_partial, stream);
+}
+
+extern "C" int shr_sphere_raster_mse_indexed(const float *spheres, const int32_t *crop_index, int N, int J, int H, int W,
+                                             const float *target, const int32_t *target_index, float *depth,
+                                             float *sse_partial, float *grad_spheres_partial, void *stream) {
   using namespace shr;
   if (N == 0) return SHR_OK;
   if (!spheres || !target || !sse_partial || !grad_spheres_partial || N < 0 || J <= 0 || H <= 0 || W <= 0)
@@ -382,21 +397,21 @@ extern "C" int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, 
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(1024), blds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
                        target_index, rows, log2_if_pow2(W / 4), zcells, g_tune.fwd_shares, g_tune.bwd_shares, depth,
-                       sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H));
+                       sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H), crop_index);
   } else if (is_pow2(W) && is_pow2(H)) {
     auto k = sphere_zbuf_mse_kernel<true, false>;
     const hipError_t e = allow_big_lds(k, &attr_a);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
                        target_index, rows, log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, depth, sse_partial,
-                       reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H));
+                       reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H), crop_index);
   } else {
     auto k = sphere_zbuf_mse_kernel<false, false>;
     const hipError_t e = allow_big_lds(k, &attr_b);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
                        target_index, rows, log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, depth, sse_partial,
-                       reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H));
+                       reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H), crop_index);
   }
   return (int)hipGetLastError();
 }

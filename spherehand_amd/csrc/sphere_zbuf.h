@@ -1389,7 +1389,8 @@ __device__ __forceinline__ void
 sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_, const float *__restrict__ target,
                      const int *__restrict__ target_index, float *__restrict__ depth,
                      float *__restrict__ sse_out, float4 *__restrict__ grad_out, int rows_per_region_,
-                     int w4_shift_, int shares_fwd, int shares_bwd, int zcells_, AxisK axk) {
+                     int w4_shift_, int shares_fwd, int shares_bwd, int zcells_, AxisK axk,
+                     const int *__restrict__ crop_index) {
   using Key = unsigned long long;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *s_sph = reinterpret_cast<float4 *>(smem);
@@ -1426,12 +1427,15 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   const bool valid = lane < J;
   const bool pf_wave = wave_s == kZWaves - 1;
   const bool has_next = PERSIST && n + crop_step < N;
+  // crop_index (shr_sphere_raster_mse_indexed): workgroup n renders crop c = crop_index[n] of the batch -- its records,
+  // its observed image, its slot of the depth output -- and reports into slot n of the partial results
+  const int c = crop_index ? crop_index[n] : n;
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
   if (valid && (wave_s == 0 || bg_wave))   // the others: wave 0's LDS copy, later
-    sph = crop_it == 0 ? spheres[(size_t)n * J + lane] : s_next[lane];
+    sph = crop_it == 0 ? spheres[(size_t)c * J + lane] : s_next[lane];
   // (behind the records' request: the index is a scalar load, the output pointers are not among the preloaded arguments)
-  const float *tgt = target + (size_t)(target_index ? target_index[n] : n) * H * W + (size_t)r0 * W;
-  float *out = depth ? depth + (size_t)n * H * W + (size_t)r0 * W : nullptr;
+  const float *tgt = target + (size_t)(target_index ? target_index[c] : c) * H * W + (size_t)r0 * W;
+  float *out = depth ? depth + (size_t)c * H * W + (size_t)r0 * W : nullptr;
   if (BOX) asm volatile("" : "+v"(ax.mul), "+v"(ay.mul), "+v"(ax.half), "+v"(ay.half));   // (SGPR budget, see the forward)
   if (tid < kZWaves * J) s_part[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // (16 waves x J <= 64 spheres)
   {  // background everywhere (BOX: every cell a box of this region can use)
@@ -1506,7 +1510,8 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   __syncthreads();
   if (!(wave_s == 0 || bg_wave)) sph = s_sph[lane];
   float4 sph_next = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (pf_wave && has_next && valid) sph_next = spheres[(size_t)(n + crop_step) * J + lane];
+  if (pf_wave && has_next && valid)
+    sph_next = spheres[(size_t)(crop_index ? crop_index[n + crop_step] : n + crop_step) * J + lane];
   const bool general = s_flag[0] != 0;
   const bool may_tie = rfl(s_flag[12]) != 0;
   ua = rfl(s_flag[2]);
@@ -1731,9 +1736,9 @@ __global__ void __launch_bounds__(1024)
 sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J, int H, int W, const float *__restrict__ target,
                        const int *__restrict__ target_index, int rows_per_region, int w4_shift, int shares_fwd,
                        int shares_bwd, float *__restrict__ depth, float *__restrict__ sse_out,
-                       float4 *__restrict__ grad_out, AxisK axk) {
+                       float4 *__restrict__ grad_out, AxisK axk, const int *__restrict__ crop_index) {
   sphere_zbuf_mse_body<POW2, PERSIST, false>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
-                                             rows_per_region, w4_shift, shares_fwd, shares_bwd, 0, axk);
+                                             rows_per_region, w4_shift, shares_fwd, shares_bwd, 0, axk, crop_index);
 }
 
 // two of these per CU: eight waves per SIMD, i.e. at most 64 VGPRs -- and few enough SGPRs: left alone the kernel takes
@@ -1744,10 +1749,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)
 sphere_zbuf_mse_box_kernel(const float4 *__restrict__ spheres, int N, int J, int H, int W, const float *__restrict__ target,
                            const int *__restrict__ target_index, int rows_per_region, int w4_shift, int zcells,
                            int shares_fwd, int shares_bwd, float *__restrict__ depth, float *__restrict__ sse_out,
-                           float4 *__restrict__ grad_out, AxisK axk) {
+                           float4 *__restrict__ grad_out, AxisK axk, const int *__restrict__ crop_index) {
   static_assert(POW2, "box variant: power-of-two images");
   sphere_zbuf_mse_body<POW2, false, true>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
-                                          rows_per_region, w4_shift, shares_fwd, shares_bwd, zcells, axk);
+                                          rows_per_region, w4_shift, shares_fwd, shares_bwd, zcells, axk, crop_index);
 }
 
 }  // namespace shr

@@ -87,10 +87,10 @@ class MutualProjectionLoss(nn.Module):
             radii = mp.radiuses.view(-1)
             if W % 4 == 0 and observed.data_ptr() % 16 == 0 and \
                     ops._lib.lib().shr_sphere_raster_mse_regions(int(H), int(W)) > 0:
-                index, diag = self._indices(B, V, joints.device)
+                index, diag, diag_target = self._indices(B, V, joints.device)
                 ws, fresh, keep = self._point_lists(observed) if ops.d2m_two_step_pays(observed) else (None, False, None)
                 loss, projected = ops.MutualProjectionLossFused.apply(camera_poses, inv_camera_poses, joints, observed, radii,
-                                                                      index, diag, bool(is_mv), 500.0, ws, fresh)
+                                                                      index, diag, bool(is_mv), 500.0, ws, fresh, diag_target)
                 if keep is not None:        # (kept only once the call that fills them has been issued)
                     self._points = keep
                 return loss, projected.view(B, V, V, H, W)
@@ -140,10 +140,11 @@ class MutualProjectionLoss(nn.Module):
             b = torch.arange(B, device=dev, dtype=torch.int32).view(B, 1, 1)
             j = torch.arange(V, device=dev, dtype=torch.int32).view(1, 1, V)
             self._index = (b * V + j).expand(B, V, V).reshape(-1).contiguous()          # pair (b,i,j) -> image b*V+j
-            self._diag_index = torch.arange(B * V * V, device=dev).view(B, V, V).diagonal(dim1=1, dim2=2).reshape(-1) \
-                .contiguous()                                                           # the V same-view pairs
+            self._diag_index = torch.arange(B * V * V, device=dev, dtype=torch.int32).view(B, V, V) \
+                .diagonal(dim1=1, dim2=2).reshape(-1).contiguous()                      # the V same-view pairs
+            self._diag_target = self._index.index_select(0, self._diag_index.long()).contiguous()   # ... and their images
             self._index_key = key
-        return self._index, self._diag_index
+        return self._index, self._diag_index, self._diag_target
 
 
 class MultiviewConsistencyLoss(nn.Module):

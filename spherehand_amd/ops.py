@@ -349,7 +349,8 @@ class DataToModel(torch.autograd.Function):
 
 
 class MutualProjectionLossFused(torch.autograd.Function):
-    """(cam, inv_cam [B,V,4,4], joints [B,V,J,3], observed [B*V,H,W], radii [J], index [B*V*V] int32, is_mv) ->
+    """(cam, inv_cam [B,V,4,4], joints [B,V,J,3], observed [B*V,H,W], radii [J], index [B*V*V] int32 (pair -> observed
+    image), diag_index [B*V] int32 (the same-view pairs' numbers), is_mv, ..., diag_target [B*V] int32 = index[diag_index]) ->
     (loss, projected depth [B*V*V,H,W]): MutualProjectionLoss (mesh/multiview_utility.py:90-130) as FIVE launches
     -- view projection, (compaction of the observed images into point lists,) fused render-and-compare, data->model,
     and the assembly kernel that weights, adds and pulls both sphere gradients back to the joints (the whole backward
@@ -360,7 +361,7 @@ class MutualProjectionLossFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cam, inv_cam, joints, observed, radii, index, diag_index, is_mv, d2m_weight, points_ws=None,
-                points_fresh=False):
+                points_fresh=False, diag_target=None):
         cam, inv_cam, joints = (t.detach().contiguous().float() for t in (cam, inv_cam, joints))
         observed, radii = observed.contiguous().float(), radii.contiguous().float()
         for t, name in ((cam, "camera_poses"), (inv_cam, "inv_camera_poses"), (joints, "joints"), (observed, "depth_maps"),
@@ -370,6 +371,10 @@ class MutualProjectionLossFused(torch.autograd.Function):
         H, W = observed.shape[-2], observed.shape[-1]
         N = B * V * V
         lib = _lib.lib()
+        if diag_index.dtype != torch.int32:
+            diag_index = diag_index.to(torch.int32)
+        if diag_target is None and not is_mv:
+            diag_target = index.index_select(0, diag_index.long())
         Rm = lib.shr_sphere_raster_mse_regions(int(H), int(W))
         dev = joints.device
         if N == 0 or J == 0:     # (the entry points return at once on an empty batch: nothing would write the outputs)
@@ -399,16 +404,16 @@ class MutualProjectionLossFused(torch.autograd.Function):
             # render-and-compare kernel goes to a side stream and the point search's workgroups fill the CUs its last
             # round leaves idle (and the other way round): 282 -> 275 us at config 5's size, same bits (MV_OVERLAP).
             overlap = MV_OVERLAP and two_step
-            if is_mv:
-                E, cen, cidx = N, spheres, index
-            else:                # the V same-view pairs only: their records and observed-image numbers, gathered
-                E = B * V
-                cen = spheres.index_select(0, diag_index)
-                cidx = index.index_select(0, diag_index)
             # Same-view pairs only (what the reference trains with after its first 1500 iterations,
-            # network/engine.py:361) on a large stack: the V*V projections are still returned, but only V of them are
-            # compared -- all N are rendered by the plain forward kernel on the side stream while the fused kernel
-            # takes the B*V same-view pairs alone (no depth output) on the caller's: 244 -> 220 us at config 5's size.
+            # network/engine.py:361): E = B*V pairs enter the loss, all V*V projections are still returned.  The pairs
+            # are SELECTED by index inside the kernels (diag_index: pair e = crop diag_index[e] of the batch; diag_target:
+            # its observed image) -- no gather of their records in front (two torch launches and 16 us until round 4).
+            if is_mv:
+                E, cidx, cen_index = N, index, None
+            else:
+                E, cidx, cen_index = B * V, diag_target, diag_index
+            # On a large stack the compare runs on those pairs alone (no depth output) on the caller's stream while the
+            # plain forward kernel renders all N projections on the side stream (SAME_VIEW_SPLIT).
             split = overlap and not is_mv and SAME_VIEW_SPLIT
             Em = E if split else N
             sse = torch.empty((Em, Rm), dtype=torch.float32, device=dev)
@@ -419,8 +424,9 @@ class MutualProjectionLossFused(torch.autograd.Function):
             if split:
                 _lib.check(lib.shr_sphere_raster_fwd_ex(_ptr(spheres), N, J, H, W, _ptr(depth), None, 0, side.cuda_stream),
                            "shr_sphere_raster_fwd_ex")
-                _lib.check(lib.shr_sphere_raster_mse(_ptr(cen), E, J, H, W, _ptr(observed), _ptr(cidx), None,
-                                                     _ptr(sse), _ptr(gsp), _stream()), "shr_sphere_raster_mse")
+                _lib.check(lib.shr_sphere_raster_mse_indexed(_ptr(spheres), _ptr(diag_index), E, J, H, W, _ptr(observed),
+                                                             _ptr(index), None, _ptr(sse), _ptr(gsp), _stream()),
+                           "shr_sphere_raster_mse_indexed")
             else:
                 _lib.check(lib.shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), _ptr(depth),
                                                      _ptr(sse), _ptr(gsp), side.cuda_stream if overlap else _stream()),
@@ -430,12 +436,13 @@ class MutualProjectionLossFused(torch.autograd.Function):
                 Rd = d2m_points_parts(E)
                 d2m = torch.empty((E, Rd), dtype=torch.float32, device=dev)
                 gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
-                _lib.check(lib.shr_data_to_model_from_points(_ptr(ws), int(observed.shape[0]), _ptr(cidx), _ptr(cen), 4, _ptr(radii),
-                                                             E, J, H, W, Rd, _ptr(d2m), _ptr(gd2m), _stream()),
-                           "shr_data_to_model_from_points")
+                _lib.check(lib.shr_data_to_model_from_points_indexed(_ptr(ws), int(observed.shape[0]), _ptr(cidx), _ptr(cen_index),
+                                                                     _ptr(spheres), 4, _ptr(radii), E, J, H, W, Rd, _ptr(d2m),
+                                                                     _ptr(gd2m), _stream()), "shr_data_to_model_from_points")
                 if overlap:
                     main.wait_stream(side)
             else:
+                cen = spheres if is_mv else spheres.index_select(0, diag_index.long())
                 Rd = lib.shr_data_to_model_parts(E, int(H), int(W))
                 d2m = torch.empty((E, Rd), dtype=torch.float32, device=dev)
                 gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
@@ -456,9 +463,9 @@ class MutualProjectionLossFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_depth):
         if g_loss is None:
-            return (None,) * 11
+            return (None,) * 12
         (gj,) = ctx.saved_tensors
-        return None, None, gj * g_loss, None, None, None, None, None, None, None, None
+        return (None, None, gj * g_loss) + (None,) * 9
 
 
 class MutualProject(torch.autograd.Function):

@@ -176,7 +176,7 @@ def test_config5_full_size_against_the_oracle(oracle):
     del g, d2, a2
     # ---- fused render-and-compare against the observed images (crop (b,i,j) vs image b*V+j)
     obs = real.view(B * V, S, S).contiguous()
-    index, _ = crit._indices(B, V, sph.device)
+    index = crit._indices(B, V, sph.device)[0]
     obs_h = obs.cpu().numpy()
     idx_h = index.cpu().numpy()
     e_h = od.astype(np.float64) - obs_h[idx_h]

@@ -27,7 +27,7 @@ def ops(request):
     o.set_tuning(o.TUNE_FORCE_GENERAL, 1 if request.param == "general" else 0)
     o._shr_test_general = request.param == "general"
     small = request.param == "zbuf-small-lds"
-    o.set_tuning(o.TUNE_FWD_LDS_BYTES, 16 * 1024 if small else 80 * 1024)
+    o.set_tuning(o.TUNE_FWD_LDS_BYTES, 16 * 1024 if small else 0)
     o.set_tuning(o.TUNE_FWD_OWNER_LDS_BYTES, 24 * 1024 if small else 0)
     o.set_tuning(o.TUNE_BWD_LDS_BYTES, 16 * 1024 if small else 128 * 1024)
     o.set_tuning(o.TUNE_FWD_WAVES, 4 if request.param == "zbuf-4-waves" else 16)
@@ -45,7 +45,7 @@ def ops(request):
     o.set_tuning(o.TUNE_BWD_WAVES, 0)
     o.set_tuning(o.TUNE_FWD_WAVES, 16)
     o.set_tuning(o.TUNE_FORCE_GENERAL, 0)
-    o.set_tuning(o.TUNE_FWD_LDS_BYTES, 80 * 1024)
+    o.set_tuning(o.TUNE_FWD_LDS_BYTES, 0)
     o.set_tuning(o.TUNE_FWD_OWNER_LDS_BYTES, 0)
     o.set_tuning(o.TUNE_BWD_LDS_BYTES, 128 * 1024)
 

@@ -29,7 +29,7 @@ def sphere_case():
     if rs.rand() < 0.1: sp[rs.randint(N), rs.randint(J), rs.randint(4)] = rs.choice([np.nan, np.inf, -np.inf, 1e30])   # the general path
     mode = rs.randint(0, 4)
     ops.set_tuning(ops.TUNE_FORCE_GENERAL, 1 if mode == 1 else 0)
-    ops.set_tuning(ops.TUNE_FWD_LDS_BYTES, 16 * 1024 if mode == 2 else 80 * 1024)
+    ops.set_tuning(ops.TUNE_FWD_LDS_BYTES, 16 * 1024 if mode == 2 else 0)
     ops.set_tuning(ops.TUNE_FWD_OWNER_LDS_BYTES, 24 * 1024 if mode == 2 else 0)
     ops.set_tuning(ops.TUNE_BWD_LDS_BYTES, 16 * 1024 if mode == 2 else 128 * 1024)
     ops.set_tuning(ops.TUNE_FWD_WAVES, 4 if mode == 3 else 16)
@@ -398,7 +398,7 @@ FAMILIES = (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mes
 
 def reset_tuning():
     """the sphere family varies the launch shapes through shr_set_tuning: back to the launcher's choices"""
-    for key, val in ((ops.TUNE_FORCE_GENERAL, 0), (ops.TUNE_FWD_LDS_BYTES, 80 * 1024), (ops.TUNE_FWD_OWNER_LDS_BYTES, 0),
+    for key, val in ((ops.TUNE_FORCE_GENERAL, 0), (ops.TUNE_FWD_LDS_BYTES, 0), (ops.TUNE_FWD_OWNER_LDS_BYTES, 0),
                      (ops.TUNE_BWD_LDS_BYTES, 128 * 1024), (ops.TUNE_FWD_WAVES, 16), (ops.TUNE_FWD_ZBUF_BYTES, 0),
                      (ops.TUNE_BWD_WAVES, 0), (ops.TUNE_MSE_BOX, -1)):
         ops.set_tuning(key, val)
