@@ -253,7 +253,49 @@ def large_batch(lib, _lib, dev, stream):
                        "bwd_us_per_256": round(b * 256 / n, 3), "fwd_frac": roof(bf, f)["frac"],
                        "bwd_frac": roof(bb, b)["frac"], "crops_per_s_fwd_bwd": round(n / ((f + b) * 1e-6), 1)}
         del sph, depth, owner, grad, gs
+    out["1152@256"] = config5_size_kernels(lib, _lib, dev, stream, mesh)
     return out
+
+
+def config5_size_kernels(lib, _lib, dev, stream, mesh, reps=25, batches=4):
+    """The rasterizer kernels at config 5's OWN size: 1152 crops @256x256 (128 samples x 3 x 3 view pairs, the
+    projections MutualProjectionLoss renders).  Plain forward without an owner map (what the loss's same-view mode and
+    MutualProjection's no-grad call launch), forward + owner bytes on the touched rows, backward; HIP events over
+    reps x batches back-to-back launches (tools/collect_profiles_r05.sh runs the same launches >= 1000 times under
+    rocprofv3: profiles/r05_config5_size_kernel_stats.csv)."""
+    from spherehand_amd.datasets import SyntheticMultiviewDataset
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    B5, S5 = 128, 256
+    ds = SyntheticMultiviewDataset(mesh, B5, S5, seed=0, device=dev)
+    crit = MutualProjectionLoss(S5, mesh).to(dev)
+    n = B5 * 9
+    with torch.no_grad():
+        _, pts = crit.mutual_projection(ds.cam.to(dev), ds.inv_cam.to(dev), ds.joints.to(dev) + 1.0)
+    rad = crit.data_to_model_criterion.radiuses.view(-1)
+    sph = torch.cat([pts.squeeze(-1).reshape(n, J, 3), rad.view(1, J, 1).expand(n, J, 1)], -1).contiguous()
+    del ds, crit, pts
+    depth = torch.empty(n, S5, S5, device=dev)
+    owner = torch.empty(n, S5, S5, device=dev, dtype=torch.uint8)
+    grad = torch.randn(n, S5, S5, device=dev)
+    gs = torch.empty(n, J, 4, device=dev)
+    p = [t.data_ptr() for t in (sph, depth, owner, grad, gs)]
+    owner.fill_(254)
+    _lib.check(lib.shr_sphere_raster_fwd_ex(p[0], n, J, S5, S5, p[1], p[2], OWNER_TOUCHED_ROWS, stream.cuda_stream), "fwd")
+    stream.synchronize()
+    written = float((owner != 254).float().mean())
+    f0 = mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_fwd_ex(p[0], n, J, S5, S5, p[1], None, 0, s), "fwd"),
+                        stream, reps, batches, 3, warm_ms=40.0)
+    f1 = mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_fwd_ex(p[0], n, J, S5, S5, p[1], p[2], OWNER_TOUCHED_ROWS, s),
+                                             "fwd"), stream, reps, batches, 3, warm_ms=40.0)
+    b = mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_bwd(p[0], p[3], p[2], n, J, S5, S5, p[4], s), "bwd"),
+                       stream, reps, batches, 3, warm_ms=40.0)
+    b0, b1 = n * (4 * S5 * S5 + 16 * J), int(n * (4 * S5 * S5 + written * S5 * S5 + 16 * J))
+    bb = int(n * (4 * S5 * S5 + written * S5 * S5 + 32 * J))
+    return {"crops": n, "image": [S5, S5], "launches_timed": reps * batches,
+            "fwd_depth_only": dict(us=round(f0, 1), **roof(b0, f0)),
+            "fwd_with_owner_bytes_on_touched_rows": dict(us=round(f1, 1), owner_rows_written=round(written, 4), **roof(b1, f1)),
+            "bwd": dict(us=round(b, 1), **roof(bb, b)),
+            "crops_per_s_fwd_bwd": round(n / ((f1 + b) * 1e-6), 1)}
 
 
 def secondary(lib, _lib, dev, stream, graph_step_us):
@@ -693,6 +735,13 @@ def main():
         # the same K steps with the PUBLIC forward (complete owner map), timed like the headline
         def step_full():
             fwd_full(sh); bwd(sh)
+        # (the same clock warm-up as the headline region: this one follows a run of single-kernel loops and read 13.5 M on
+        # the driver's box against 16.7 M here in round 4 -- a cold region, not a slower step)
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < CLOCK_WARMUP_MS:
+            for _ in range(50):
+                step_full()
+            stream.synchronize()
         elapsed_full = timed_steps(step_full, args.steps, args.warmup, dist, dev)
         big = sec = None
         if rank == 0 and world == 1 and dist is None and not args.no_secondary:
@@ -702,8 +751,18 @@ def main():
             with torch.cuda.graph(g2, stream=stream):
                 fwd(sh); bwd(sh)
             graph_us = mean_launch_us(lambda _s: g2.replay(), stream, 200, 3, 20)
+            # what a graph launch costs by itself: EIGHT steps in one graph, per step -- the difference to the one-step
+            # graph is the fixed cost of a hipGraphLaunch on this runtime (a submission of its own with its barrier
+            # packets, where direct launches pipeline in the queue), not the kernels
+            g8 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g8, stream=stream):
+                for _ in range(8):
+                    fwd(sh); bwd(sh)
+            graph8_us = mean_launch_us(lambda _s: g8.replay(), stream, 50, 3, 5) / 8.0
+            del g8
             big = large_batch(lib, _lib, dev, stream)
             sec = secondary(lib, _lib, dev, stream, graph_us)
+            sec["headline_step_in_a_graph_of_8_steps_us"] = round(graph8_us, 3)
 
     coll = None
     if dist is not None and not args.no_secondary:
