@@ -273,6 +273,17 @@ def _side_stream(dev):
     return _SIDE[k]
 
 
+_SIDE_EVENT = {}
+
+
+def _side_event(dev):
+    """One reusable event per device for the 'projection done' edge between the two streams."""
+    k = dev.index if dev.index is not None else _cur_device()
+    if k not in _SIDE_EVENT:
+        _SIDE_EVENT[k] = torch.cuda.Event()
+    return _SIDE_EVENT[k]
+
+
 def d2m_points_workspace(depth):
     """An UNFILLED workspace (uint8 tensor) for the point lists of depth [M,H,W] (shr_data_to_model_points_bytes)."""
     _check_input(depth, "depth")
@@ -392,18 +403,37 @@ class MutualProjectionLossFused(torch.autograd.Function):
             points_ws, points_fresh = d2m_points_workspace(observed), True
         with _on(dev):
             spheres = torch.empty((N, J, 4), dtype=torch.float32, device=dev)
-            if two_step and points_fresh:
+            depth = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+            # Two streams where the stack is large enough for the two-step path (MV_OVERLAP; same bits either way):
+            #   caller's stream   view projection -> render-and-compare (the LONG kernel: nothing it waits for crosses
+            #                     a queue) [-> the plain forward of all pairs in the same-view split]
+            #   side stream       compaction of the observed images (needs nothing from this call) -> [projection
+            #                     done] -> point search
+            # Round 4 had projection + compaction on the caller's stream and the render-and-compare kernel on the
+            # side: it started 12 us after the compaction's end (cross-queue dependency) and the join cost another 11
+            # on the critical path (rocprofv3 timeline, tools/timeline_mvloss.sh).
+            overlap = MV_OVERLAP and two_step
+            main = side = None
+            s_main = _stream()
+            s_d2m = s_main
+            if overlap:
+                main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+                side.wait_stream(main)
+                s_d2m = side.cuda_stream
+            if two_step and points_fresh and not overlap:
                 _lib.check(lib.shr_mv_project_compact(_ptr(cam), _ptr(inv_cam), _ptr(joints), _ptr(radii), B, V, J,
                                                       _ptr(spheres), _ptr(observed), int(observed.shape[0]), H, W,
-                                                      _ptr(points_ws), _stream()), "shr_mv_project_compact")
+                                                      _ptr(points_ws), s_main), "shr_mv_project_compact")
             else:
+                if two_step and points_fresh:
+                    _lib.check(lib.shr_data_to_model_compact(_ptr(observed), int(observed.shape[0]), H, W, _ptr(points_ws), s_d2m),
+                               "shr_data_to_model_compact")
                 _lib.check(lib.shr_mutual_project_fwd(_ptr(cam), _ptr(inv_cam), _ptr(joints), _ptr(radii), B, V, J,
-                                                      _ptr(spheres), _stream()), "shr_mutual_project_fwd")
-            depth = torch.empty((N, H, W), dtype=torch.float32, device=dev)
-            # The two terms are independent: where the stack is large enough for the two-step path, the
-            # render-and-compare kernel goes to a side stream and the point search's workgroups fill the CUs its last
-            # round leaves idle (and the other way round): 282 -> 275 us at config 5's size, same bits (MV_OVERLAP).
-            overlap = MV_OVERLAP and two_step
+                                                      _ptr(spheres), s_main), "shr_mutual_project_fwd")
+            if overlap:
+                ev = _side_event(dev)
+                ev.record(main)
+                side.wait_event(ev)               # the point search reads the projected records
             # Same-view pairs only (what the reference trains with after its first 1500 iterations,
             # network/engine.py:361): E = B*V pairs enter the loss, all V*V projections are still returned.  The pairs
             # are SELECTED by index inside the kernels (diag_index: pair e = crop diag_index[e] of the batch; diag_target:
@@ -412,25 +442,21 @@ class MutualProjectionLossFused(torch.autograd.Function):
                 E, cidx, cen_index = N, index, None
             else:
                 E, cidx, cen_index = B * V, diag_target, diag_index
-            # On a large stack the compare runs on those pairs alone (no depth output) on the caller's stream while the
-            # plain forward kernel renders all N projections on the side stream (SAME_VIEW_SPLIT).
+            # On a large stack the compare runs on those pairs alone (no depth output) and the plain forward kernel
+            # renders all N projections behind it (SAME_VIEW_SPLIT).
             split = overlap and not is_mv and SAME_VIEW_SPLIT
             Em = E if split else N
             sse = torch.empty((Em, Rm), dtype=torch.float32, device=dev)
             gsp = torch.empty((Em, Rm, J, 4), dtype=torch.float32, device=dev)
-            if overlap:
-                main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-                side.wait_stream(main)
             if split:
-                _lib.check(lib.shr_sphere_raster_fwd_ex(_ptr(spheres), N, J, H, W, _ptr(depth), None, 0, side.cuda_stream),
-                           "shr_sphere_raster_fwd_ex")
                 _lib.check(lib.shr_sphere_raster_mse_indexed(_ptr(spheres), _ptr(diag_index), E, J, H, W, _ptr(observed),
-                                                             _ptr(index), None, _ptr(sse), _ptr(gsp), _stream()),
+                                                             _ptr(index), None, _ptr(sse), _ptr(gsp), s_main),
                            "shr_sphere_raster_mse_indexed")
+                _lib.check(lib.shr_sphere_raster_fwd_ex(_ptr(spheres), N, J, H, W, _ptr(depth), None, 0, s_main),
+                           "shr_sphere_raster_fwd_ex")
             else:
                 _lib.check(lib.shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), _ptr(depth),
-                                                     _ptr(sse), _ptr(gsp), side.cuda_stream if overlap else _stream()),
-                           "shr_sphere_raster_mse")
+                                                     _ptr(sse), _ptr(gsp), s_main), "shr_sphere_raster_mse")
             if two_step:
                 ws = points_ws
                 Rd = d2m_points_parts(E)
@@ -438,7 +464,7 @@ class MutualProjectionLossFused(torch.autograd.Function):
                 gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
                 _lib.check(lib.shr_data_to_model_from_points_indexed(_ptr(ws), int(observed.shape[0]), _ptr(cidx), _ptr(cen_index),
                                                                      _ptr(spheres), 4, _ptr(radii), E, J, H, W, Rd, _ptr(d2m),
-                                                                     _ptr(gd2m), _stream()), "shr_data_to_model_from_points")
+                                                                     _ptr(gd2m), s_d2m), "shr_data_to_model_from_points")
                 if overlap:
                     main.wait_stream(side)
             else:
@@ -447,7 +473,7 @@ class MutualProjectionLossFused(torch.autograd.Function):
                 d2m = torch.empty((E, Rd), dtype=torch.float32, device=dev)
                 gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
                 _lib.check(lib.shr_data_to_model_partial(_ptr(observed), _ptr(cidx), _ptr(cen), 4, _ptr(radii), E, J, H, W, Rd,
-                                                         _ptr(d2m), _ptr(gd2m), _stream()), "shr_data_to_model_partial")
+                                                         _ptr(d2m), _ptr(gd2m), s_main), "shr_data_to_model_partial")
             loss = torch.empty(1, dtype=torch.float32, device=dev)
             want = ctx.needs_input_grad[2]
             gj = torch.empty((B, V, J, 3), dtype=torch.float32, device=dev) if want else None
