@@ -9,8 +9,8 @@
 // The reference launches one single-thread block per face that walks the face's
 // pixel columns serially and CAS-loops a float min per pixel.  Here a wave takes
 // 32 faces: lanes = faces for the set-up (cull, sort by x, inverse barycentric
-// matrix), then lanes = pixels of the faces' boxes for the span test and lanes =
-// pixels inside their span for the depth (see tri_raster_kernel below).
+// matrix), then lanes = the faces' pixel COLUMNS for the spans and lanes = the
+// pixels inside the spans for the depth (raster_batch below).
 // Every pixel repeats the reference's per-column span test and per-pixel
 // arithmetic verbatim (fp32, one rounding per written operator, IEEE division; the
 // `1. / x` the reference evaluates in fp64 and rounds to fp32 equals the fp32
@@ -21,6 +21,8 @@
 #include "common.h"
 
 namespace shr {
+
+typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
 
 // CUDA double -> int32 conversion (cvt.rzi.s32.f64): truncate, saturate, NaN -> 0.
 // The operands here are fp32 values promoted to double, so fp32 compares suffice.
@@ -114,22 +116,28 @@ __device__ __forceinline__ void zmin(float *cell, float v) {
   else atomicMin(reinterpret_cast<int *>(cell), (int)b);
 }
 
-// .cu:72-90: is row yi inside column xi's span of the face?  (x0, y0), (x1, y1): the first two vertices sorted by
-// x; the slopes and their flags from face_setup.
-__device__ __forceinline__ bool span_inside(float x0, float y0, float x1, float y1, float s01, float s12, float s02,
-                                            int sflags, int xi, int yi, int height) {
+// .cu:72-90: the rows [yi_min, yi_max] of column xi's span of the face.  (x0, y0), (x1, y1): the first two vertices
+// sorted by x; the slopes and their flags from face_setup.
+__device__ __forceinline__ void span_rows(float x0, float y0, float x1, float y1, float s01, float s12, float s02,
+                                          int sflags, int xi, int height, int &yi_min, int &yi_max) {
   const float xf = (float)xi;
   float yi1;
   if (xf <= x1) yi1 = (sflags & 1) ? s01 * (xf - x0) + y0 : y1;
   else yi1 = (sflags & 2) ? s12 * (xf - x1) + y1 : y1;
   const float yi2 = s02 * (xf - x0) + y0;
-  const int yi_min = cvt_rz_sat(fmaxf(0.f, ceilf(fminf(yi1, yi2))));
-  const int yi_max = cvt_rz_sat(fminf(fmaxf(yi1, yi2), (float)height - 1.f));
+  yi_min = cvt_rz_sat(fmaxf(0.f, ceilf(fminf(yi1, yi2))));
+  yi_max = cvt_rz_sat(fminf(fmaxf(yi1, yi2), (float)height - 1.f));
+}
+// ... and whether row yi is inside it
+__device__ __forceinline__ bool span_inside(float x0, float y0, float x1, float y1, float s01, float s12, float s02,
+                                            int sflags, int xi, int yi, int height) {
+  int yi_min, yi_max;
+  span_rows(x0, y0, x1, y1, s01, s12, s02, sflags, xi, height, yi_min, yi_max);
   return yi >= yi_min && yi <= yi_max;
 }
 
-// .cu:97-110 for a pixel inside its column's span
-__device__ __forceinline__ void span_pixel(const float pz[3], const float fi[9], int xi, int yi, int width, float *zimg) {
+// .cu:97-110 for a pixel inside its column's span: the depth the reference offers to its atomicMin (NaN: none)
+__device__ __forceinline__ float span_depth(const float pz[3], const float fi[9], int xi, int yi) {
   const float xf = (float)xi, yf = (float)yi;
   float w[3];
   float w_sum = 0.f;
@@ -141,23 +149,148 @@ __device__ __forceinline__ void span_pixel(const float pz[3], const float fi[9],
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) w[k] = w[k] / w_sum;
-  const float zp = 1.0f / ((w[0] / pz[0] + w[1] / pz[1]) + w[2] / pz[2]);
-  if (zp == zp) zmin(zimg + (size_t)yi * width + xi, zp);  // fminf(NaN, old) = old
+  return 1.0f / ((w[0] / pz[0] + w[1] / pz[1]) + w[2] / pz[2]);
 }
 
-// A visible face of the hand mesh covers a ~16x16-pixel box at 640x640 and one box pixel in
-// three lies inside its column's span.  A wave sets 64 faces up with lanes = faces and parks
-// each face's values in an LDS row; then
-//   pass A, lanes = box pixels: faces up to 256 box pixels are worked through in GROUPS of 16
-//     consecutive box pixels, four groups -- of one face or of four -- per pass (larger faces:
-//     the whole wave on 8x8 patches, values through SGPRs); a lane only runs the SPAN TEST
-//     (3 of the 10 IEEE divisions) and queues (face, x, y) in LDS if its pixel is inside;
-//   pass B, lanes = queued pixels, 64 at a time, every lane busy: the 7 divisions of the
-//     barycentric weights and the perspective depth, then the atomic.
-constexpr int kFaceRow = 28;          // x0 y0 x1 y1 x2 y2 s01 s12 | z0 z1 z2 fi[9] | box x0, r_lo, bw, area, first group, 2^20 / bw, s02, slope flags
-constexpr int kGroupsPerFace = 16;    // faces with a box above 256 pixels are visited alone
-constexpr int kFacesPerWave = 32;     // 5 KB of LDS per wave (rows, group table, queue): eight waves per SIMD fit
+// A wave sets up to 32 faces up with lanes = faces and parks each face's values in an LDS row (raster_batch below).
+constexpr int kFaceRow = 28;          // x0 y0 x1 y1 x2 y2 s01 s12 | z0 z1 z2 fi[9] | x of column item 0, r_lo, r_hi, s02 | slope flags
+constexpr int kFacesPerWave = 32;     // 4.5 KB of LDS per wave (rows, queue): eight waves per SIMD fit
+// a wave's private scratch: face rows | pixel queue
+constexpr int kScratchFaceBytes = kFacesPerWave * kFaceRow * 4;                    // 3584
+constexpr int kScratchQueueBytes = 128 * 8;                                        // 1024
+constexpr int kWaveScratchBytes = kScratchFaceBytes + kScratchQueueBytes;
 
+// One batch: lane l < 32 brings face set-up `s` (`have`: the lane holds a face; rows [s.r_lo, s.r_hi] already clipped
+// to what the caller wants rasterized); every pixel inside its column's span goes to sink(xi, yi, depth) once.
+// `scratch`: this wave's kWaveScratchBytes of LDS (16-byte aligned); nothing of it is live between two batches.
+// inclusive prefix sum over the 64 lanes (4 DPP steps inside each row of 16, then the row totals)
+__device__ __forceinline__ int wave_scan_incl(int v, int lane) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+  const int r0s = __builtin_amdgcn_readlane(v, 15), r1s = __builtin_amdgcn_readlane(v, 31), r2s = __builtin_amdgcn_readlane(v, 47);
+  const int row = lane >> 4;
+  return v + (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
+}
+// Item k of a sequence cut into 64 consecutive runs whose inclusive ends the lanes hold (non-decreasing; `mine`: this
+// lane's run exists): the run that holds k = the number of runs that END at or before k.  Those that end at or
+// before k0 (wave-uniform, <= k) are counted by one ballot, the few that end inside [k0, k0 + 63] one by one.
+__device__ __forceinline__ int run_of(int incl, bool mine, int k0, int k) {
+  int run = __popcll(__ballot(mine && incl <= k0));
+  unsigned long long inner = __ballot(mine && incl > k0 && incl <= k0 + 63);
+  while (inner) {
+    const int c = __builtin_ctzll(inner);
+    inner &= inner - 1;
+    run += (__builtin_amdgcn_readlane(incl, c) <= k) ? 1 : 0;
+  }
+  return run;
+}
+
+// One batch, the reference's own loop structure spread over a wave (.cu:70-111: for each column of the face its span
+// of rows, for each row of the span a pixel):
+//   columns  lanes = the COLUMNS of the batch's faces, 64 at a time whatever face they belong to: the column's span
+//            (span_rows: two edge interpolations, the slopes divided once per face in the set-up), clipped to the
+//            face's row range, and a prefix sum over the spans' lengths;
+//   pixels   lanes = the pixels INSIDE those spans, 64 at a time, every lane with a pixel: queued as (face, x, y);
+//   pass B   lanes = queued pixels, 64 at a time, every lane busy: the 7 divisions of the barycentric weights and the
+//            perspective depth, then sink(x, y, depth).
+// Rounds 1-4 walked every face's BOX (16-pixel groups; 8x8 patches of one face at a time for boxes above 256 pixels)
+// with a span test per box pixel: three box pixels in four lie outside the spans, and the large boxes -- one face in
+// six of the hand mesh, six tenths of its box pixels -- took 380 of the kernel's 630 us for 256 crops.
+template <typename Sink>
+__device__ __forceinline__ void raster_batch(const FaceSetup &s, bool have, int lane, unsigned char *scratch, int height,
+                                             Sink &&sink) {
+  float (*s_face)[kFaceRow] = reinterpret_cast<float (*)[kFaceRow]>(scratch);
+  uint2 *s_queue = reinterpret_cast<uint2 *>(scratch + kScratchFaceBytes);
+  const int bw = s.xi_max - s.xi_min + 1, bh = s.r_hi - s.r_lo + 1;
+  const bool alive = have && s.live && bh > 0 && bw > 0;
+  const int ncol = alive ? bw : 0;                     // (<= 65535 columns each, 32 faces: 32 bits)
+  const int fincl = wave_scan_incl(ncol, lane);        // lanes = faces: the face's columns end here
+  const int ncols = __builtin_amdgcn_readlane(fincl, 63);
+  if (lane < kFacesPerWave) {
+    float *r = s_face[lane];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { r[2 * a] = s.p[a][0]; r[2 * a + 1] = s.p[a][1]; r[8 + a] = s.p[a][2]; }
+#pragma unroll
+    for (int k = 0; k < 9; k++) r[11 + k] = s.fi[k];
+    r[6] = s.s01; r[7] = s.s12;
+    r[20] = __int_as_float(s.xi_min - (fincl - ncol));   // column item k of the face is pixel column k + this
+    r[21] = __int_as_float(s.r_lo); r[22] = __int_as_float(s.r_hi); r[23] = s.s02;
+    r[24] = __int_as_float(s.sflags);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's LDS writes (rows and queue are private to the wave)
+  __builtin_amdgcn_wave_barrier();
+
+  int qn = 0;   // queued pixels (wave-uniform)
+  auto drain = [&](int take) {   // pass B on the last `take` queued pixels
+    if (lane < take) {
+      const uint2 e = s_queue[qn - take + lane];
+      const float4 *r4 = reinterpret_cast<const float4 *>(s_face[e.x]);
+      const float4 b2 = r4[2], b3 = r4[3], b4 = r4[4];
+      const float pz[3] = {b2.x, b2.y, b2.z};
+      const float fi[9] = {b2.w, b3.x, b3.y, b3.z, b3.w, b4.x, b4.y, b4.z, b4.w};
+      const int xi = (int)(e.y & 0xffffu), yi = (int)(e.y >> 16);
+      const float zp = span_depth(pz, fi, xi, yi);
+      if (zp == zp) sink(xi, yi, zp);  // fminf(NaN, old) = old
+    }
+    qn -= take;
+  };
+  for (int k0 = 0; k0 < ncols; k0 += 64) {
+    const int k = k0 + lane;
+    const bool colv = k < ncols;
+    const int face = min(run_of(fincl, lane < kFacesPerWave, k0, k), kFacesPerWave - 1);   // (faces without a column count as runs too)
+    const float4 *r4 = reinterpret_cast<const float4 *>(s_face[face]);
+    const float4 a0 = r4[0], a1 = r4[1], i0 = r4[5];
+    const int fl = __float_as_int(s_face[face][24]);
+    const int xi = k + __float_as_int(i0.x);
+    int ylo, yhi;
+    span_rows(a0.x, a0.y, a0.z, a0.w, a1.z, a1.w, i0.w, fl, xi, height, ylo, yhi);
+    ylo = max(ylo, __float_as_int(i0.y));
+    yhi = min(yhi, __float_as_int(i0.z));
+    const int cnt = (colv && yhi >= ylo) ? yhi - ylo + 1 : 0;   // (a span holds at most 65535 rows, a chunk 64 columns)
+    const int cincl = wave_scan_incl(cnt, lane);
+    const int ctotal = __builtin_amdgcn_readlane(cincl, 63), cexcl = cincl - cnt;
+    const int packed = face | (xi << 8);                          // (face < 32, xi < 65536)
+    for (int p0 = 0; p0 < ctotal; p0 += 64) {
+      const int p = p0 + lane;
+      const int col = min(run_of(cincl, colv, p0, p), 63);       // (empty columns among the runs count too)
+      const int cy = __shfl(ylo, col), ce = __shfl(cexcl, col), fx = __shfl(packed, col);
+      const bool inside = p < ctotal;
+      const unsigned long long m = __ballot(inside);
+      if (inside) {
+        const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        s_queue[pos] = make_uint2((unsigned)(fx & 0xff), (unsigned)(fx >> 8) | ((unsigned)(cy + (p - ce)) << 16));
+      }
+      qn += __popcll(m);
+      if (qn >= 64) drain(64);
+    }
+  }
+  if (qn > 0) drain(qn);
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // the queue's and the rows' last reads: the next batch rewrites them
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <bool INDEXED>
+__device__ __forceinline__ void load_face(const float *__restrict__ src, const int *__restrict__ faces, int b, int F, int NV,
+                                          int fidx, float f[9]) {
+  if (INDEXED) {  // vertices [B,NV,4] + faces [F,3]: the gather of mesh/render.py:308-309 fused
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float4 v = reinterpret_cast<const float4 *>(src)[(size_t)b * NV + faces[fidx * 3 + k]];
+      f[3 * k] = v.x; f[3 * k + 1] = v.y; f[3 * k + 2] = v.z;
+    }
+  } else {
+    const float *fp = src + ((size_t)b * F + fidx) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; k++) f[k] = fp[k];
+  }
+}
+
+// ---- the global-atomic kernel (any size) --------------------------------------------------------------------------
+// A wave takes 32 faces and offers every covered pixel to the image with a native integer atomic on the fp32 bits
+// (zmin), after one fill pass: 256 hand crops @640x640 (a 419-MB image) 630 us in rounds 1-4, 440-480 us since
+// raster_batch walks column spans instead of boxes.
 template <bool INDEXED>
 __global__ void __launch_bounds__(256)
 tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, int B, int F, int NV, int width,
@@ -168,133 +301,180 @@ tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, 
   const int b = wave_global / groups;
   if (b >= B) return;
   const int fidx = (wave_global - b * groups) * kFacesPerWave + lane;
-
   float f[9];
-  bool have = lane < kFacesPerWave && fidx < F;
+  const bool have = lane < kFacesPerWave && fidx < F;
   if (have) {
-    if (INDEXED) {  // vertices [B,NV,4] + faces [F,3]: the gather of mesh/render.py:308-309 fused
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const float4 v = reinterpret_cast<const float4 *>(src)[(size_t)b * NV + faces[fidx * 3 + k]];
-        f[3 * k] = v.x; f[3 * k + 1] = v.y; f[3 * k + 2] = v.z;
-      }
-    } else {
-      const float *fp = src + ((size_t)b * F + fidx) * 9;
-#pragma unroll
-      for (int k = 0; k < 9; k++) f[k] = fp[k];
-    }
+    load_face<INDEXED>(src, faces, b, F, NV, fidx, f);
   } else {
 #pragma unroll
     for (int k = 0; k < 9; k++) f[k] = 0.f;
   }
-  FaceSetup s = face_setup(f, width, height);
+  const FaceSetup s = face_setup(f, width, height);
   float *zimg = zbuf + (size_t)b * width * height;
-  __shared__ __attribute__((aligned(16))) float s_face[4][kFacesPerWave][kFaceRow];
-  __shared__ uint8_t s_gface[4][kFacesPerWave * kGroupsPerFace];
-  __shared__ uint2 s_queue[4][128];
-  const int wv = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) unsigned char s_scratch[4][kWaveScratchBytes];
+  raster_batch(s, have, lane, s_scratch[threadIdx.x >> 6], height,
+               [&](int xi, int yi, float zp) { zmin(zimg + (size_t)yi * width + xi, zp); });
+}
 
-  const int bw = s.xi_max - s.xi_min + 1, bh = s.r_hi - s.r_lo + 1;
-  const bool alive = have && s.live && bh > 0 && bw > 0;
-  const long long area_ll = (long long)bw * bh;
-  const bool big = alive && area_ll > 16 * kGroupsPerFace;
-  const int area = alive && !big ? (int)area_ll : 0;
-  const int ng = (area + 15) >> 4;
-  // inclusive scan of the group counts over the wave
-  int incl = ng;
-  incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
-  incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
-  incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
-  incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
-  {
-    const int r0s = __builtin_amdgcn_readlane(incl, 15), r1s = __builtin_amdgcn_readlane(incl, 31);
-    const int r2s = __builtin_amdgcn_readlane(incl, 47);
-    const int row = lane >> 4;
-    incl += (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
-  }
-  const int first = incl - ng, total = __builtin_amdgcn_readlane(incl, 63);
-  if (lane < kFacesPerWave) {
-    float *r = s_face[wv][lane];
-#pragma unroll
-    for (int a = 0; a < 3; a++) { r[2 * a] = s.p[a][0]; r[2 * a + 1] = s.p[a][1]; r[8 + a] = s.p[a][2]; }
-#pragma unroll
-    for (int k = 0; k < 9; k++) r[11 + k] = s.fi[k];
-    r[20] = __int_as_float(s.xi_min); r[21] = __int_as_float(s.r_lo); r[22] = __int_as_float(bw);
-    r[23] = __int_as_float(area); r[24] = __int_as_float(first);
-    r[25] = __int_as_float(bw > 0 ? (int)(((1u << 20) + (unsigned)bw - 1u) / (unsigned)bw) : 0);
-    r[6] = s.s01; r[7] = s.s12; r[26] = s.s02; r[27] = __int_as_float(s.sflags);
-  }
-  {
-    const int ngmax = (int)wave_minmax_all<false>((float)ng);
-    for (int k = 0; k < ngmax; k++)
-      if (k < ng) s_gface[wv][first + k] = (uint8_t)lane;
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's LDS writes (rows, tables and queue are private to the wave)
-  __builtin_amdgcn_wave_barrier();
+// ---- the band kernel (round 5) ----------------------------------------------------------------------------------
+// The image is produced in BANDS of R rows held in LDS: every covered pixel is an LDS integer minimum, every image
+// pixel is written to HBM exactly once with full-line stores -- no fill pass, no L2 atomics, and the float image is
+// the reference's bit for bit (a minimum does not depend on the order it is taken in).
+//   grid = (B, segments), block = 16 waves, dynamic LDS = row ranges [F] u32 | band's faces [F] u16 | band [R x W] f32 |
+//   16 wave scratches.
+//   phase 1  lanes = faces, once per workgroup: the reference's culls (.cu:33, :54, :68-69) and the conservative row
+//            range of the face's spans -> s_range[f] = r_lo | r_hi << 16 (0xFFFF: culled), and the number of faces that
+//            reach each band;
+//   phase 2  per band of the segment: a band no face reaches is 1000.0 straight from registers; otherwise the band is
+//            initialised in LDS, every wave walks its share of the ranges (one LDS word per face), collects the faces
+//            that reach the band and rasterizes them 32 at a time (raster_batch, rows clipped to the band) with an LDS
+//            minimum per covered pixel, and the band is streamed out.
+constexpr int kBandWaves = 16;
+constexpr int kBandMaxBands = 512;        // per-band face counters in LDS
+constexpr uint32_t kFillBits = 0x447A0000u;   // 1000.0f, .cu:122
 
-  int qn = 0;   // queued pixels (wave-uniform)
-  auto drain = [&](int take) {   // pass B on the last `take` queued pixels
-    if (lane < take) {
-      const uint2 e = s_queue[wv][qn - take + lane];
-      const float4 *r4 = reinterpret_cast<const float4 *>(s_face[wv][e.x]);
-      const float4 b2 = r4[2], b3 = r4[3], b4 = r4[4];
-      const float pz[3] = {b2.x, b2.y, b2.z};
-      const float fi[9] = {b2.w, b3.x, b3.y, b3.z, b3.w, b4.x, b4.y, b4.z, b4.w};
-      span_pixel(pz, fi, (int)(e.y & 0xffffu), (int)(e.y >> 16), width, zimg);
+// the culls and the row range of face_setup without its twelve divisions (same comparisons, same values)
+__device__ __forceinline__ uint32_t face_row_range(const float f[9], int width, int height) {
+  bool live = !((f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]));   // :33 back face
+  int p0, p2;
+  if (f[0] < f[3]) {
+    p0 = (f[6] < f[0]) ? 2 : 0;
+    p2 = (f[3] < f[6]) ? 2 : 1;
+  } else {
+    p0 = (f[6] < f[3]) ? 2 : 1;
+    p2 = (f[0] < f[6]) ? 2 : 0;
+  }
+  const float x0 = p0 == 0 ? f[0] : (p0 == 1 ? f[3] : f[6]), x2 = p2 == 0 ? f[0] : (p2 == 1 ? f[3] : f[6]);
+  if (x0 == x2) live = false;                                                       // :54
+  const int xi_min = cvt_rz_sat(fmaxf(ceilf(x0), 0.f));
+  const int xi_max = cvt_rz_sat(fminf(x2, (float)width - 1.f));
+  if (xi_min > xi_max) live = false;
+  const float ylo = fminf(fminf(f[1], f[4]), f[7]), yhi = fmaxf(fmaxf(f[1], f[4]), f[7]);
+  const bool wild = !(fabsf(ylo) < 1e9f) || !(fabsf(yhi) < 1e9f) || x2 < 0.f;
+  const float yeps = 1e-5f * (fabsf(ylo) + fabsf(yhi)) + 1e-4f;
+  const int r_lo = wild ? 0 : max(0, (int)ceilf(ylo - yeps));
+  const int r_hi = wild ? height - 1 : min(height - 1, max(0, (int)floorf(yhi + yeps)));
+  if (r_hi < r_lo) live = false;
+  return live ? ((uint32_t)r_lo | ((uint32_t)r_hi << 16)) : 0xFFFFu;
+}
+
+template <bool INDEXED>
+__global__ void __launch_bounds__(kBandWaves * 64)
+tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, int B, int F, int NV, int width, int height,
+                float *__restrict__ zbuf, int R, int nbands, int bands_per_seg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int Fpad = (F + 7) & ~7;
+  uint32_t *s_range = reinterpret_cast<uint32_t *>(smem);
+  uint16_t *s_pend = reinterpret_cast<uint16_t *>(smem + (size_t)Fpad * 4);          // the faces that reach the current band
+  float *s_band = reinterpret_cast<float *>(smem + (size_t)Fpad * 6);
+  unsigned char *s_scr = smem + (size_t)Fpad * 6 + (size_t)R * width * 4;
+  __shared__ int s_bandcnt[kBandMaxBands];
+  __shared__ int s_npend;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int band0 = blockIdx.y * bands_per_seg, band1 = min(nbands, band0 + bands_per_seg);
+  float *zimg = zbuf + (size_t)b * width * height;
+  const bool counted = nbands <= kBandMaxBands;
+  for (int i = tid; i < min(nbands, kBandMaxBands); i += kBandWaves * 64) s_bandcnt[i] = 0;
+  __syncthreads();
+  // ---- phase 1: row ranges -------------------------------------------------------------------------------------
+  const float rinv = 1.0f / (float)R;
+  for (int fidx = tid; fidx < F; fidx += kBandWaves * 64) {
+    float f[9];
+    load_face<INDEXED>(src, faces, b, F, NV, fidx, f);
+    const uint32_t rw = face_row_range(f, width, height);
+    s_range[fidx] = rw;
+    if (counted && rw != 0xFFFFu) {
+      // (band numbers through a float quotient: a band too many on either side only costs that band its shortcut)
+      const int ba = max(band0, (int)((float)(rw & 0xffffu) * rinv) - 1), bb = min(band1 - 1, (int)((float)(rw >> 16) * rinv) + 1);
+      for (int k = ba; k <= bb; k++)
+        if ((int)(rw & 0xffffu) <= min(height, (k + 1) * R) - 1 && (int)(rw >> 16) >= k * R) atomicAdd(&s_bandcnt[k], 1);
     }
-    qn -= take;
-  };
-  auto push = [&](bool inside, int face, int xi, int yi) {
-    const unsigned long long m = __ballot(inside);
-    if (m == 0ull) return;
-    if (inside) {
-      const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-      s_queue[wv][pos] = make_uint2((unsigned)face, (unsigned)xi | ((unsigned)yi << 16));
+  }
+  __syncthreads();
+  // ---- phase 2: the bands ----------------------------------------------------------------------------------------
+  const bool vec4 = (width & 3) == 0;
+  unsigned char *scratch = s_scr + (size_t)wave * kWaveScratchBytes;
+  const int nchunks = (F + 63) >> 6;
+  for (int band = band0; band < band1; band++) {
+    const int lo = band * R, hi = min(height, lo + R) - 1, rows = hi - lo + 1;
+    const int npix = rows * width;
+    float *gout = zimg + (size_t)lo * width;
+    if (counted && s_bandcnt[band] == 0) {          // no face reaches the band (workgroup-uniform)
+      if (vec4) {
+        const v4u_t t = {kFillBits, kFillBits, kFillBits, kFillBits};
+        for (int i = tid; i < (npix >> 2); i += kBandWaves * 64)
+          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(reinterpret_cast<float4 *>(gout) + i), "v"(t) : "memory");
+      } else {
+        for (int i = tid; i < npix; i += kBandWaves * 64) gout[i] = __uint_as_float(kFillBits);
+      }
+      continue;
     }
-    qn += __popcll(m);
-    if (qn >= 64) drain(64);
-  };
-
-  for (int g0 = 0; g0 < total; g0 += 4) {
-    const int g = g0 + (lane >> 4);
-    bool inside = false;
-    int face = 0, xi = 0, yi = 0;
-    if (g < total) {
-      face = s_gface[wv][g];
-      const float4 *r4 = reinterpret_cast<const float4 *>(s_face[wv][face]);
-      const float4 a0 = r4[0], a1 = r4[1], i0 = r4[5], i1 = r4[6];
-      const int x0 = __float_as_int(i0.x), y0 = __float_as_int(i0.y), fbw = __float_as_int(i0.z);
-      const int farea = __float_as_int(i0.w), ffirst = __float_as_int(i1.x);
-      const unsigned inv = (unsigned)__float_as_int(i1.y);
-      const int t = ((g - ffirst) << 4) + (lane & 15);
-      if (t < farea) {
-        const int ly = (int)(((unsigned)t * inv) >> 20);   // t / bw: exact for t <= 1024, bw <= 1024
-        xi = x0 + (t - ly * fbw);
-        yi = y0 + ly;
-        inside = span_inside(a0.x, a0.y, a0.z, a0.w, a1.z, a1.w, i1.z, __float_as_int(i1.w), xi, yi, height);
+    // the faces that reach the band, collected by ALL waves into one list (face numbers cluster: a wave's own chunks
+    // hold all of a band's faces or none), then dealt out in equal shares
+    if (tid == 0) s_npend = 0;
+    if (vec4) {
+      const float4 fv = make_float4(__uint_as_float(kFillBits), __uint_as_float(kFillBits), __uint_as_float(kFillBits),
+                                    __uint_as_float(kFillBits));
+      for (int i = tid; i < (npix >> 2); i += kBandWaves * 64) reinterpret_cast<float4 *>(s_band)[i] = fv;
+    } else {
+      for (int i = tid; i < npix; i += kBandWaves * 64) s_band[i] = __uint_as_float(kFillBits);
+    }
+    __syncthreads();
+    for (int c = wave; c < nchunks; c += kBandWaves) {
+      const int fidx = (c << 6) + lane;
+      const uint32_t rw = fidx < F ? s_range[fidx] : 0xFFFFu;
+      const bool reach = (int)(rw & 0xffffu) <= hi && (int)(rw >> 16) >= lo;
+      const unsigned long long m = __ballot(reach);
+      if (m == 0ull) continue;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_npend, __popcll(m));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (reach)
+        s_pend[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint16_t)fidx;
+    }
+    __syncthreads();
+    float *cells = s_band - (size_t)lo * width;      // cell of pixel (yi, xi) = cells[yi * width + xi]
+    auto sink = [&](int xi, int yi, float zp) {
+      float *cell = cells + yi * width + xi;
+      const uint32_t bits = __float_as_uint(zp);
+      if (bits >> 31) atomicMax(reinterpret_cast<unsigned int *>(cell), bits);   // (zmin's rule on an LDS cell)
+      else atomicMin(reinterpret_cast<int *>(cell), (int)bits);
+    };
+    {
+      // equal shares of the list, 32 faces at a time.  (Drawing batches of 16 from a counter instead -- a face costs what
+      // its box holds -- measured 1022 us against 634 for 256 crops: a batch costs its LATENCY, the gather of its
+      // vertices and the set-up's chain of divisions, whatever it holds; fewer, fuller batches win.)
+      const int n = s_npend;
+      const int from = (int)(((long long)wave * n) / kBandWaves), to = (int)(((long long)(wave + 1) * n) / kBandWaves);
+      for (int at = from; at < to; at += kFacesPerWave) {
+        const int count = min(kFacesPerWave, to - at);
+        float f[9];
+        const bool have = lane < count;
+        if (have) {
+          load_face<INDEXED>(src, faces, b, F, NV, (int)s_pend[at + lane], f);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 9; k++) f[k] = 0.f;
+        }
+        FaceSetup fs = face_setup(f, width, height);
+        fs.r_lo = max(fs.r_lo, lo);
+        fs.r_hi = min(fs.r_hi, hi);
+        raster_batch(fs, have, lane, scratch, height, sink);
       }
     }
-    push(inside, face, xi, yi);
-  }
-
-  // the faces with a large box: the whole wave on 8x8 patches of one face, values through SGPRs
-  unsigned long long live = __ballot(big);
-  while (live) {
-    const int src_lane = __builtin_amdgcn_readfirstlane(__builtin_ctzll(live));
-    live &= live - 1;
-    const float fx0 = readlane_f(s.p[0][0], src_lane), fy0 = readlane_f(s.p[0][1], src_lane);
-    const float fx1 = readlane_f(s.p[1][0], src_lane), fy1 = readlane_f(s.p[1][1], src_lane);
-    const float f01 = readlane_f(s.s01, src_lane), f12 = readlane_f(s.s12, src_lane), f02 = readlane_f(s.s02, src_lane);
-    const int ffl = __builtin_amdgcn_readlane(s.sflags, src_lane);
-    const int x0 = __builtin_amdgcn_readlane(s.xi_min, src_lane), x1 = __builtin_amdgcn_readlane(s.xi_max, src_lane);
-    const int r0 = __builtin_amdgcn_readlane(s.r_lo, src_lane), r1 = __builtin_amdgcn_readlane(s.r_hi, src_lane);
-    for (int oy = 0; oy <= r1 - r0; oy += 8)
-      for (int ox = 0; ox <= x1 - x0; ox += 8) {
-        const int xi = x0 + ox + (lane & 7), yi = r0 + oy + (lane >> 3);
-        push(xi <= x1 && yi <= r1 && span_inside(fx0, fy0, fx1, fy1, f01, f12, f02, ffl, xi, yi, height), src_lane, xi, yi);
+    __syncthreads();
+    // stream the band out
+    if (vec4) {
+      for (int i = tid; i < (npix >> 2); i += kBandWaves * 64) {
+        const uint4 v = reinterpret_cast<const uint4 *>(s_band)[i];
+        const v4u_t t = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(reinterpret_cast<float4 *>(gout) + i), "v"(t) : "memory");
       }
+    } else {
+      for (int i = tid; i < npix; i += kBandWaves * 64) gout[i] = s_band[i];
+    }
+    __syncthreads();                                  // the band's cells are re-initialised next
   }
-  if (qn > 0) drain(qn);
 }
 
 __global__ void zbuf_fill_kernel(uint4 *__restrict__ z, size_t n4, uint32_t key, uint32_t *__restrict__ tail,
@@ -358,7 +538,6 @@ lbs_project_kernel(const float *__restrict__ T, int B, int NB, int NV, const int
       o = make_float4(a0 * rf * fx + cx, acc[c][1] * rf * fy + cy, acc[c][2], 1.0f);
     }
     // (written through: the vertices are read next by the rasterizer, left dirty they are flushed at the kernel's end)
-    typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
     const v4u_t t = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(out + (size_t)b * NV + v), "v"(t) : "memory");
   }
@@ -368,8 +547,50 @@ lbs_project_kernel(const float *__restrict__ T, int B, int NB, int NV, const int
 
 using namespace shr;
 
+static int g_tri_band = -1;   // SHR_TUNE_TRI_BAND: -1 = by batch size (below), 0 = never (the global-atomic kernel), n > 0 = always, bands of <= n rows
+int shr::tri_set_band(int v) { g_tri_band = v; return SHR_OK; }
+
 static int tri_raster_common(bool indexed, const float *src, const int *faces, int B, int F, int NV, int W, int H,
                              float *depth, hipStream_t s) {
+  // The band kernel: the row ranges of all faces (4 F bytes) + sixteen wave scratches + a band of at least 8 rows
+  // in one CU's LDS, 16-bit face numbers and row numbers.
+  constexpr int kLds = 160 * 1024;
+  const long long fixed = (long long)((F + 7) & ~7) * 6 + (long long)kBandWaves * kWaveScratchBytes + 4096;   // (+ the static arrays: band counters, pending faces)
+  long long R = (kLds - fixed) / (4LL * W);
+  if (R > H) R = H;
+  // Which kernel: the band kernel has ONE 16-wave workgroup per CU (its LDS) against eight waves per SIMD for the
+  // atomic kernel, and the work is chains of IEEE divisions -- latency that only more waves hide.  Measured on the hand
+  // mesh @640x640 (tools/exp_tri_band.py): 1 crop 54 us against 78, 48 crops 274 against 170, 256 crops 515 against
+  // 480.  So: bands for a handful of crops (where a fill pass over the image and the L2 round trips of its atomics
+  // are most of the time), the atomic kernel otherwise; SHR_TUNE_TRI_BAND forces either.
+  const bool want_band = g_tri_band > 0 || (g_tri_band < 0 && B <= 4);
+  if (want_band && F > 0 && F <= 65535 && R >= 8 && H <= 65535 && W <= 65535) {
+    if (g_tri_band > 0 && g_tri_band < R) R = g_tri_band;          // tests: that many rows per band
+    const int nbands = (int)((H + R - 1) / R);
+    // segments of bands: one workgroup per crop when there is a crop per CU, more when there are few crops
+    static int cus = 0;
+    if (cus == 0) {
+      int d = 0, v = 0;
+      cus = (hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && v > 0) ? v : 256;
+    }
+    int segs = B >= cus ? 1 : (cus + B - 1) / B;
+    if (segs > nbands) segs = nbands;
+    const int per = (nbands + segs - 1) / segs;
+    segs = (nbands + per - 1) / per;
+    const size_t lds = (size_t)((F + 7) & ~7) * 6 + (size_t)R * W * 4 + (size_t)kBandWaves * kWaveScratchBytes;
+    static bool attr_done[2] = {false, false};
+    auto launch = [&](auto kernel, int which) -> int {
+      if (!attr_done[which]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds - 4096);   // (the static arrays take the rest)
+        if (e != hipSuccess) return (int)e;
+        attr_done[which] = true;
+      }
+      hipLaunchKernelGGL(kernel, dim3((unsigned)B, (unsigned)segs), dim3(kBandWaves * 64), lds, s, src, faces, B, F, NV, W, H,
+                         depth, (int)R, nbands, per);
+      return (int)hipGetLastError();
+    };
+    if (B <= 65535 * 32767) return indexed ? launch(tri_band_kernel<true>, 0) : launch(tri_band_kernel<false>, 1);
+  }
   const size_t n = (size_t)B * W * H;
   uint32_t *z = reinterpret_cast<uint32_t *>(depth);
   const size_t n4 = n / 4;

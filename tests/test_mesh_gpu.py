@@ -86,6 +86,50 @@ def test_random_large_faces_vs_oracle(oracle):
     assert np.array_equal(bits(d), bits(oracle.tri_raster_fwd(fv, W, H)))
 
 
+@pytest.mark.parametrize("band", [-1, 0, 8, 13, 4096])
+def test_tri_raster_band_kernel_and_atomic_kernel_agree_with_the_oracle(oracle, band):
+    """shr_tri_raster_fwd's two kernels -- bands of rows held in LDS (the default for up to 4 crops; `band` rows at
+    most when a test says so: faces then straddle many bands, the last band is ragged; 4096 = as many as fit) and the
+    global-atomic kernel (band = 0; the default for more crops) --
+    against the oracle, bit for bit: random soups with small and large faces and depths of both signs, widths that are
+    not a multiple of 4 (scalar stream-out), a single crop (the bands are dealt to several workgroups), a single face,
+    the quirk faces, the indexed entry, and the hand mesh at 640x640."""
+    import depth_rasterization
+    from spherehand_amd import ops
+    ops.set_tuning(ops.TUNE_TRI_BAND, band)
+    try:
+        rs = np.random.RandomState(21)
+        for B, F, W, H in ((2, 333, 200, 160), (1, 900, 96, 72), (3, 64, 37, 53), (1, 1, 64, 64), (5, 33, 130, 9)):
+            c = rs.uniform(-20, [W + 20, H + 20], (B, F, 1, 2))
+            spread = rs.choice([3.0, 12.0, 40.0], (B, F, 1, 1))
+            fv = np.concatenate([c + rs.normal(0, 1, (B, F, 3, 2)) * spread, rs.uniform(-50, 50, (B, F, 3, 1))], -1).astype(np.float32)
+            d = depth_rasterization.forward(W, H, dev(fv)).cpu().numpy()
+            assert np.array_equal(bits(d), bits(oracle.tri_raster_fwd(fv, W, H))), (B, F, W, H)
+            # the indexed entry (vertices + faces) on the same triangles
+            verts = np.concatenate([fv.reshape(B, F * 3, 3), np.ones((B, F * 3, 1), np.float32)], -1)
+            faces = np.arange(F * 3, dtype=np.int32).reshape(F, 3)
+            di = ops.tri_raster_indexed_fwd(W, H, dev(verts), dev(faces)).cpu().numpy()
+            assert np.array_equal(bits(di), bits(d)), (B, F, W, H)
+        tri = np.array([
+            [[-0.5, -0.7, 5], [-0.2, 3.0, 5], [-0.1, -0.6, 5]], [[2, 2, 0], [2, 9, 4], [9, 2, 4]], [[5, 5, 3], [5, 9, 3], [5, 7, 3]],
+            [[1, 1, 3], [4, 4, 3], [7, 7, 3]], [[np.nan, 1, 3], [4, 2, 3], [7, 9, 3]], [[3, 12, 2], [12, 3, 2], [3, 3, -2]],
+            [[-40, -30, 7], [60, -20, 7], [10, 70, 7]], [[-0.7, 7.1, 5], [-3.2, 14.3, 7], [-9.4, 7.6, 6]],
+            [[1e9, 3, 2], [2, 1e9, 2], [3, 3, 2]], [[2, -1e9, 2], [9, 1e9, 2], [4, 3, 2]],
+        ], np.float32)[None]
+        for fv in (tri, tri[:, ::-1], tri[:, :, [1, 0, 2], :]):
+            for (W, H) in ((16, 16), (17, 9), (5, 33), (8, 40)):
+                d = depth_rasterization.forward(W, H, dev(fv)).cpu().numpy()
+                assert np.array_equal(bits(d), bits(oracle.tri_raster_fwd(fv, W, H))), (W, H)
+        e = depth_rasterization.forward(8, 8, torch.empty(2, 0, 3, 3, device="cuda"))
+        assert e.shape == (2, 8, 8) and torch.all(e == 1000.0)
+        g = golden("g2_mesh.npz")
+        d = depth_rasterization.forward(640, 640, dev(g["face_vertices"][:2])).cpu().numpy()
+        assert np.array_equal(bits(d[0]), bits(g["raw640_first"]))
+        assert np.array_equal(bits(d), bits(oracle.tri_raster_fwd(g["face_vertices"][:2], 640, 640)))
+    finally:
+        ops.set_tuning(ops.TUNE_TRI_BAND, -1)
+
+
 def test_lbs_project(oracle):
     from spherehand_amd import hand_model, ops
     g = golden("g2_mesh.npz")
