@@ -48,6 +48,27 @@
 namespace shr {
 
 constexpr int kZWaves = 16;   // 1024 threads
+// In-kernel timeline (tools/headline_timeline.py builds the library with -DSHR_TIMELINE and reads shr_tl back): every
+// wave of the first 256 workgroups of a launch stamps s_memtime at its phase boundaries -- kernel k (0 forward, 1
+// backward), slot 0 = entry, 1 .. 5 = the kernel's own marks.  Nothing of it exists in the product build.
+#ifdef SHR_TIMELINE
+__device__ unsigned long long shr_tl[2][256 * kZWaves * 8];
+// (s_memtime counters are not synchronised between CUs: only differences inside a workgroup mean anything.  Entry and
+// end are stamped with s_memrealtime as well, the device-wide 100-MHz counter, for the launch's ramp and tail.)
+__device__ unsigned long long shr_tl_rt[2][256 * kZWaves * 2];
+#define SHR_TL(k, slot)                                                                              \
+  do {                                                                                               \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && blockIdx.y == 0) {                            \
+      shr_tl[k][(blockIdx.x * kZWaves + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+      if ((slot) == 0 || (slot) == 5)                                                                \
+        shr_tl_rt[k][(blockIdx.x * kZWaves + (threadIdx.x >> 6)) * 2 + ((slot) == 5)] = __builtin_amdgcn_s_memrealtime(); \
+    }                                                                                                \
+  } while (0)
+#define SHR_TL_ENTRY(k) SHR_TL(k, 0)
+#else
+#define SHR_TL(k, slot) do {} while (0)
+#define SHR_TL_ENTRY(k) do {} while (0)
+#endif
 #ifndef SHR_ROW_PAD
 #define SHR_ROW_PAD 8
 #endif
@@ -729,6 +750,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     asm volatile("" : "+v"(tid));
   }
   const int lane = tid & 63, wave = tid >> 6;
+  SHR_TL_ENTRY(0);
   // (the workgroup size rides in the same launch argument: blockDim.x is a hidden kernel argument that is NOT among
   // the preloaded ones -- reading it put an s_load round trip in front of the records' request)
   const int nwaves = (w4_shift_flags >> 16) & 0xff, nthr = nwaves << 6;
@@ -805,9 +827,11 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     const unsigned long long bad = __ballot(valid && !(sphere_is_tame(sph) && fabsf(sph.z) < 1e30f));
     const unsigned long long low = __ballot(valid && sph.z <= kBackground);
     const unsigned long long behind = __ballot(valid && sph.z > kBackground);
+    SHR_TL(0, 6);   // (list wave) the crop's records have arrived
     bool too_big;   // excluded by the launcher (W <= kMaxFastWidth, H <= 32768)
     const int total = build_work_list<kSphereCostFwd>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big,
                                                       TABLE ? s_run : nullptr);
+    SHR_TL(0, 7);   // (list wave) the work list stands
     if (lane == 0) {
       s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
       s_flag[1] = total;
@@ -911,7 +935,9 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     s_flag[10] = over ? split : r1;
     s_flag[11] = over ? min(r1, (r0 + (out_hi + row_len - 1) / row_len + kTileH - 1) & ~(kTileH - 1)) : r1;
   }
+  SHR_TL(0, 1);   // this wave's work in front of the first barrier is done (list / table / background rows / init)
   __syncthreads();
+  SHR_TL(0, 2);   // past the first barrier: the scan starts
   if (!(list_wave || bg_wave || tab_wave)) sph = s_sph[lane];
   const bool has_next = PERSIST && n + crop_step < N;   // (the launcher keeps a prefetch wave whenever gridDim.x < N)
   float4 sph_next = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -972,7 +998,9 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
           [](int) {}, RunTab{s_tab, s_run});
     }
     if (pf_wave && has_next) s_next[lane] = sph_next;   // (arrived long ago: the wave's own scan slice lies in between)
+    SHR_TL(0, 3);   // this wave's scan slice is done
     __syncthreads();
+    SHR_TL(0, 4);   // past the second barrier: the stream-out starts
 
     // ---- stream the touched rows out: [out_lo, out_hi) of the region's chunks / pixels -------
     const Key *zrow = zbuf - (p0 - r0) * pitch - cu0;   // cell of region pixel (v, x) = zrow[v * pitch + x]
@@ -1033,6 +1061,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     tile_forward<VEC4, OWNER>(sph, J, H, W, out, aout, tiles_x, t0 + wave, t1, nwaves, lane);
   }
   if (general && pf_wave && has_next) s_next[lane] = sph_next;
+  SHR_TL(0, 5);   // end: the touched rows are streamed out
   if (PERSIST && n + crop_step < N) __syncthreads();   // the z-buffer is re-initialised next: every wave's stream-out reads are done
   }  // crops
 }
@@ -1082,6 +1111,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     asm volatile("" : "+v"(tid));
   }
   const int lane = tid & 63, wave = tid >> 6;
+  SHR_TL_ENTRY(1);
   const int LW = W + kRowPad;
   float *gbuf = reinterpret_cast<float *>(smem + kHdrBytes + kPartBytes);
   uint8_t *obuf = smem + kHdrBytes + kPartBytes + (size_t)(rows + kPadRows) * LW * 4;
@@ -1154,6 +1184,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
       if (lane < J) sph = t;
     }
     touched_rows(sph, lane < J, ay, ky, 0, H, lead_v0, lead_v1);
+    SHR_TL(1, 6);   // (lead waves) the records have arrived, the touched rows are known
     if (wave_s == 0) {
       s_sph[lane] = sph;
       if (!WHOLE && lane == 0) { s_flag[2] = lead_v0; s_flag[3] = lead_v1; }
@@ -1178,6 +1209,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
       bool too_big;   // excluded by the launcher (W <= kMaxFastWidth)
       const int total = build_work_list<kSphereCostBwd>(sph, lane < J, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
       if (lane == 0) s_flag[1] = total;
+      SHR_TL(1, 7);   // (wave 0) the work list stands
     }
   };
   auto stage = [&](int r0, int r1, int t_lo, int t_hi, auto first_tag) {   // rows [t_lo, t_hi) of [r0, r1) are wanted
@@ -1296,7 +1328,9 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
                  : "v106", "v107", "v108", "v109", "memory");
   for (int r0 = cv0; r0 <= cv1;) {
     const int r1 = min(r0 + rows, cv1 + 1), rh = r1 - r0;
+    SHR_TL(1, 1);   // this wave's staging (and, wave 0, the list) is done
     __syncthreads();
+    SHR_TL(1, 2);   // past the staging barrier: the walk starts
 
     // Static schedule: wave w walks the w-th contiguous slice of the list (which wave sums which pixels must
     // not depend on timing); at the end of a run on a sphere its register partials are reduced with one
@@ -1347,7 +1381,9 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
                  : "=v"(t.x), "=v"(t.y), "=v"(t.z), "=v"(t.w) : : "memory");
     s_next[lane] = t;
   }
+  SHR_TL(1, 3);   // this wave's walk is done
   __syncthreads();
+  SHR_TL(1, 4);   // past the closing barrier
   // combine the waves' partials in wave order; d/dr = r * sum(-g/sqrt(q))
   if (tid < J) {
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1359,6 +1395,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     const v4u_t tt = {__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w)};
     asm_store16<SHR_BWD_STORE_MODE>(grad_spheres + (size_t)n * J + tid, tt);
   }
+  SHR_TL(1, 5);   // end: gradients stored
   if (has_next) __syncthreads();   // the partials are zeroed and the staging buffers refilled next
   }  // crops
 }

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-4 profile collection on the GPU box (run through gpurun from the repo root):  bash tools/collect_profiles_r04.sh
+# Round-5 profile collection on the GPU box (run through gpurun from the repo root):  bash tools/collect_profiles_r05.sh
 # PMC passes carry --kernel-trace only (no --stats, no other trace domain), one counter set per pass.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r04; rm -rf "$O"; mkdir -p "$O"
+O=gpurun_out/r05; rm -rf "$O"; mkdir -p "$O"
 # (a) the headline kernels over >= 2000 steps: stats summary + per-launch trace (medians)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_headline" -o bench -- python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-secondary > "$O/stats_headline.log" 2>&1
 # (b) the same tracing over the full bench (secondary set)
@@ -34,6 +34,16 @@ timeout 300 rocprofv3 --kernel-trace --pmc $SQB --output-format csv -d "$O/sq_b_
 # unchanged observations; and the A/B of the two orders in one process
 { timeout 120 python tools/prof_mvloss.py; OVERLAP=1 timeout 120 python tools/prof_mvloss.py; OVERLAP=1 CACHE=1 timeout 120 python tools/prof_mvloss.py;
   timeout 200 python tools/ab_mvloss_overlap.py; } > "$O/mvloss_wall.log" 2>&1
+# (b2c) the same-view mode (is_mv = False) of the same loss: per-kernel timeline of one step in both modes
+bash tools/timeline_mvloss.sh > "$O/mvloss_timeline.log" 2>&1
+# (b2d) the rasterizer kernels at config 5's own size, 1000 launches each under the tracer
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_c5size" -o c5 -- python tools/prof_config5_size.py > "$O/stats_c5size.log" 2>&1
+# (b2e) pose <-> sphere records kernels and the pose -> depth -> pose chain; the triangle path; the in-kernel timeline
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_fk" -o fk -- python tools/bench_fk.py 256 > "$O/stats_fk.log" 2>&1
+timeout 200 python tools/bench_tri.py > "$O/tri.log" 2>&1
+timeout 200 python tools/bench_mesh.py >> "$O/tri.log" 2>&1
+timeout 200 python tools/headline_timeline.py > "$O/headline_timeline.log" 2>&1
+timeout 200 python tools/bench_mvloss_graph.py > "$O/mvloss_graph.log" 2>&1
 # (b3) the headline launches from a C loop (tools/cloop.c), unprofiled and under the tracer: the durations `frac_rocprof` uses
 timeout 200 python tools/prof_cloop.py > "$O/cloop_plain.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/cloop" -o cloop -- python tools/prof_cloop.py > "$O/cloop_traced.log" 2>&1
@@ -43,7 +53,7 @@ timeout 300 python bench.py --steps 20 --warmup 5 > "$O/bench_line_steps20.json"
 timeout 300 python bench.py --launch graph --no-secondary --no-cpu-baseline > "$O/bench_line_graph.json" 2>> "$O/bench_line.err"
 # (d) the fuzzer on these kernels: FUZZ_SECONDS per family (default 45)
 timeout 1200 python tools/fuzz.py ${FUZZ_SECONDS:-45} 3 > "$O/fuzz.log" 2>&1
-python tools/summarize_r04.py gpurun_out/r04_profiles > "$O/summarize.log" 2>&1
+python tools/summarize_r05.py gpurun_out/r05_profiles > "$O/summarize.log" 2>&1
 find "$O" -name "*counter_collection.csv" -delete; find "$O" -name "*kernel_trace.csv" -delete
 tail -3 "$O/summarize.log"; tail -2 "$O/fuzz.log"; tail -1 "$O/bench_line_steps20.json" | cut -c1-160
 du -sh "$O"

@@ -1,7 +1,7 @@
-"""gpurun_out/r04 (tools/collect_profiles_r04.sh) -> profiles/r04_*: python tools/summarize_r04.py"""
+"""gpurun_out/r05 (tools/collect_profiles_r05.sh) -> profiles/r05_*: python tools/summarize_r05.py"""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-O = os.path.join(ROOT, "gpurun_out", "r04")
+O = os.path.join(ROOT, "gpurun_out", "r05")
 P = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 
@@ -15,10 +15,10 @@ def shr_rows(src, dst, keep=lambda name: True):
                 w.writerow([r[0].split("(")[0][:120]] + r[1:])
 
 ours = lambda n: "shr::" in n or "group_norm" in n or "d2m_" in n
-shr_rows(os.path.join(O, "stats_headline", "bench_kernel_stats.csv"), os.path.join(P, "r04_bench_kernel_stats.csv"))
-shr_rows(os.path.join(O, "stats", "bench_kernel_stats.csv"), os.path.join(P, "r04_secondary_kernel_stats.csv"), ours)
+shr_rows(os.path.join(O, "stats_headline", "bench_kernel_stats.csv"), os.path.join(P, "r05_bench_kernel_stats.csv"))
+shr_rows(os.path.join(O, "stats", "bench_kernel_stats.csv"), os.path.join(P, "r05_secondary_kernel_stats.csv"), ours)
 for n in ("bench_line.json", "bench_line_graph.json", "bench_line_steps20.json"):
-    shutil.copy(os.path.join(O, n), os.path.join(P, "r04_" + n))
+    shutil.copy(os.path.join(O, n), os.path.join(P, "r05_" + n))
 # per-launch durations of the headline kernels from the trace: mean, median, quartiles (>= 2000 launches each)
 import statistics
 dur = collections.defaultdict(list)
@@ -34,38 +34,49 @@ for k, v in dur.items():
               "p25_us": round(v[len(v) // 4], 3), "p75_us": round(v[3 * len(v) // 4], 3), "min_us": round(v[0], 3)}
 med["_note"] = ("rocprofv3 --kernel-trace --stats -- python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-secondary: "
                 "End - Start of every launch of the two headline kernels (the traced process's own HIP-event means are in "
-                "its JSON line, gpurun_out/r04/stats_headline.log)")
+                "its JSON line, gpurun_out/r05/stats_headline.log)")
 try:
     line = [l for l in open(os.path.join(O, "stats_headline.log")) if l.startswith("{")][-1]
     med["traced_process_hip_event_us"] = json.loads(line)["roofline"]["launch_us"]
 except Exception as e:      # noqa
     med["traced_process_hip_event_us"] = None
-json.dump(med, open(os.path.join(P, "r04_headline_launch_durations.json"), "w"), indent=1)
+json.dump(med, open(os.path.join(P, "r05_headline_launch_durations.json"), "w"), indent=1)
 if os.path.exists(os.path.join(O, "fuzz.log")):
-    shutil.copy(os.path.join(O, "fuzz.log"), os.path.join(P, "r04_fuzz_summary.txt"))
+    shutil.copy(os.path.join(O, "fuzz.log"), os.path.join(P, "r05_fuzz_summary.txt"))
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), os.path.join(O, "pmc_fetch"),
-                       os.path.join(O, "pmc_write"), os.path.join(P, "r04_pmc_traffic.json"), "sphere_zbuf_fwd_kernel",
+                       os.path.join(O, "pmc_write"), os.path.join(P, "r05_pmc_traffic.json"), "sphere_zbuf_fwd_kernel",
                        "sphere_zbuf_bwd_kernel"], stdout=subprocess.DEVNULL)
 # config 5's loss: HBM traffic per launch of its kernels (tools/prof_mvloss.py under the same two PMC passes)
 if os.path.isdir(os.path.join(O, "pmc_fetch_mvloss")):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), os.path.join(O, "pmc_fetch_mvloss"),
-                           os.path.join(O, "pmc_write_mvloss"), os.path.join(P, "r04_pmc_traffic_config5_loss.json"),
+                           os.path.join(O, "pmc_write_mvloss"), os.path.join(P, "r05_pmc_traffic_config5_loss.json"),
                            "sphere_zbuf_mse_box_kernel", "d2m_compact_kernel", "d2m_points_kernel", "mv_loss_combine_kernel",
                            "mutual_project_fwd_kernel"], stdout=subprocess.DEVNULL)
-    d = json.load(open(os.path.join(P, "r04_pmc_traffic_config5_loss.json")))
+    d = json.load(open(os.path.join(P, "r05_pmc_traffic_config5_loss.json")))
     d["_note"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/prof_mvloss.py: "
                   "MutualProjectionLoss forward + backward, 1152 crops @256x256 (384 observed images of 256 KB = 100.7 MB), fresh "
                   "observations every call.  bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 half-count correction).")
-    json.dump(d, open(os.path.join(P, "r04_pmc_traffic_config5_loss.json"), "w"), indent=1)
+    json.dump(d, open(os.path.join(P, "r05_pmc_traffic_config5_loss.json"), "w"), indent=1)
 if os.path.exists(os.path.join(O, "mvloss_wall.log")):
-    with open(os.path.join(O, "mvloss_wall.log")) as f, open(os.path.join(P, "r04_config5_loss_wall.txt"), "w") as g:
+    with open(os.path.join(O, "mvloss_wall.log")) as f, open(os.path.join(P, "r05_config5_loss_wall.txt"), "w") as g:
         g.write("# tools/prof_mvloss.py (20 steps each) and tools/ab_mvloss_overlap.py (200 steps each), untraced\n")
         g.writelines(l for l in f if l.startswith(("MutualProjectionLoss", "one stream", "render-and-compare")))
 if os.path.isdir(os.path.join(O, "stats_mvloss")):
-    shr_rows(os.path.join(O, "stats_mvloss", "mv_kernel_stats.csv"), os.path.join(P, "r04_config5_loss_kernel_stats.csv"), ours)
+    shr_rows(os.path.join(O, "stats_mvloss", "mv_kernel_stats.csv"), os.path.join(P, "r05_config5_loss_kernel_stats.csv"), ours)
+if os.path.isdir(os.path.join(O, "stats_c5size")):
+    shr_rows(os.path.join(O, "stats_c5size", "c5_kernel_stats.csv"), os.path.join(P, "r05_config5_size_kernel_stats.csv"), ours)
+if os.path.isdir(os.path.join(O, "stats_fk")):
+    shr_rows(os.path.join(O, "stats_fk", "fk_kernel_stats.csv"), os.path.join(P, "r05_pose_kernels_stats.csv"), ours)
+for src, dst in (("mvloss_timeline.log", "r05_config5_loss_timeline.txt"), ("tri.log", "r05_triangle_path.txt"),
+                 ("mvloss_graph.log", "r05_config5_loss_eager_vs_graph.txt")):
+    if os.path.exists(os.path.join(O, src)):
+        with open(os.path.join(O, src)) as f, open(os.path.join(P, dst), "w") as g:
+            g.writelines(l for l in f if not l.startswith(("W2026", "/opt/amdgpu", "[rocprofv3]", "E2026")) and "amdgpu.ids" not in l)
+if os.path.exists(os.path.join(ROOT, "gpurun_out", "r05_headline_timeline.json")):
+    shutil.copy(os.path.join(ROOT, "gpurun_out", "r05_headline_timeline.json"), os.path.join(P, "r05_headline_timeline.json"))
 if os.path.isdir(os.path.join(O, "cloop")):
-    shr_rows(os.path.join(O, "cloop", "cloop_kernel_stats.csv"), os.path.join(P, "r04_cloop_kernel_stats.csv"))
-    with open(os.path.join(P, "r04_cloop_lines.txt"), "w") as f:
+    shr_rows(os.path.join(O, "cloop", "cloop_kernel_stats.csv"), os.path.join(P, "r05_cloop_kernel_stats.csv"))
+    with open(os.path.join(P, "r05_cloop_lines.txt"), "w") as f:
         f.write("unprofiled:\n" + open(os.path.join(O, "cloop_plain.log")).read() + "\nunder rocprofv3 --kernel-trace --stats:\n" +
                 open(os.path.join(O, "cloop_traced.log")).read())
 # SQ counters: per kernel, mean per launch over every launch of every pass that saw it
@@ -103,9 +114,9 @@ for k, cs in sorted(sq.items()):
     if "FETCH_SIZE" in m:
         d["hbm_read_bytes_per_launch (2 x FETCH_SIZE KB, gfx950 half-count)"] = int(2 * m["FETCH_SIZE"] * 1024)
     out[k] = d
-out["_note"] = ("rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes, sets A and B of tools/collect_profiles_r04.sh) on "
+out["_note"] = ("rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes, sets A and B of tools/collect_profiles_r05.sh) on "
                 "bench.py (--no-secondary: the headline kernels at batch 256; with the secondary set: every other kernel) and on "
                 "tools/prof_d2m.py (1152 crops, S = 128 / 256).  SQ_*_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles "
                 "summed over all waves; a kernel seen at several problem sizes is split by grid size.")
-json.dump(out, open(os.path.join(P, "r04_sq_counters.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(P, "r05_sq_counters.json"), "w"), indent=1)
 print(json.dumps({k: v.get("share_of_wave_cycles") for k, v in out.items() if isinstance(v, dict)}, indent=1))
