@@ -80,9 +80,6 @@ int shr_device_info(char *name_host, int name_len, int *num_cu_host);
 #define SHR_TUNE_TRI_BAND 16         /* shr_tri_raster_fwd: -1 = by batch size (default: the LDS band kernel for up to 4
                                     * crops, the global-atomic kernel above), 0 = always the atomic kernel, n > 0 = always
                                     * the band kernel, bands of at most n rows */
-#define SHR_TUNE_D2M_BALANCED 17     /* shr_data_to_model_balanced_bytes / _from_points_balanced: -1 = offered when the crops
-                                    * exceed the workgroups resident at once (default), 0 = never, n > 0 = always, with n
-                                    * workgroups (tests) */
 int shr_set_tuning(int key, int value);
 /* Self-test: adds to *mismatches (device, caller-zeroed u64) the number of fp32
  * bit patterns in [lo_bits, hi_bits) where the rasterizer's internal square root
@@ -190,17 +187,6 @@ int shr_data_to_model_from_points_indexed(const void *workspace, int M, const in
                                           const int32_t *centre_index, const float *centres, int centre_stride,
                                           const float *radii, int N, int J, int H, int W, int parts,
                                           float *loss_parts, float *grad_parts, void *stream);
-/* The same search as ONE launch of exactly as many workgroups as the device holds at once, for batches with more crops
- * than that: the crops are cut into halves (point groups of one parity), every workgroup takes an equal run of
- * half-crops, the halves' fixed-point INTEGER sums go to `scratch` (shr_data_to_model_balanced_bytes(N, J) bytes,
- * caller-allocated, 8-byte aligned; 0 = the batch fits one round: use the entry above) and a second small launch adds
- * them: loss_sum[N], grad_centres[N,J,3] (may be NULL) -- the same bits as one workgroup per crop (1152 crops @256x256
- * on 768 slots: 75 -> see DESIGN 4.3). */
-long long shr_data_to_model_balanced_bytes(int N, int J);
-int shr_data_to_model_from_points_balanced(const void *workspace, int M, const int32_t *depth_index,
-                                           const int32_t *centre_index, const float *centres, int centre_stride,
-                                           const float *radii, int N, int J, int H, int W, void *scratch,
-                                           float *loss_sum, float *grad_centres, void *stream);
 
 /* Fused render-and-compare: the model->data term of mesh/multiview_utility.py:98-101 and
  * :107-113 (MSELoss(BallRender(...).min(), observed)) with its whole backward, one

@@ -184,7 +184,6 @@ int d2m_set_waves(int waves);        // data_to_model.hip: launch-shape hooks be
 int d2m_set_band_units(int units);  // SHR_TUNE_D2M_BAND_UNITS
 int d2m_set_tiled(int on);          // SHR_TUNE_D2M_TILED
 int tri_set_band(int rows);         // tri_raster.hip: SHR_TUNE_TRI_BAND
-int d2m_set_balanced(int v);        // data_to_model.hip: SHR_TUNE_D2M_BALANCED
 // data_to_model.hip: the two halves of shr_data_to_model_compact (mutual_project.hip: shr_mv_project_compact)
 int d2m_compact_check(const float *depth, int M, int H, int W, void *workspace, int **counts);
 int d2m_compact_launch(const float *depth, int M, int H, int W, void *workspace, hipStream_t s);

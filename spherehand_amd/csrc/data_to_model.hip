@@ -413,21 +413,20 @@ d2m_compact_kernel(const float *__restrict__ depth, int H, int W, int geom, uint
   }
 }
 
-// One (crop, part) unit of the point search: the groups g = part (mod parts) of the image's list against crop n's
-// records.  FX = false: float results into slot `slot` (round 4's layout); FX = true: the raw fixed-point integers
-// (loss, then J x 3 gradient components; LLONG_MIN in the loss word = NaN) -- sums of several units of one crop are
-// then added as INTEGERS by whoever reads them: independent of how the crop was cut.
-template <bool WANT_GRAD, int WAVES, bool FX>
-__device__ __forceinline__ void d2m_points_unit(const uint2 *__restrict__ points, const int *__restrict__ counts, int P,
-                                                const int *__restrict__ depth_index, const float *__restrict__ centres,
-                                                int centre_stride, const float *__restrict__ radii, int J, int H, int W,
-                                                const int *__restrict__ centre_index, int n, int part, int parts,
-                                                size_t slot, float *__restrict__ loss_sum, float *__restrict__ grad_centres,
-                                                long long *__restrict__ loss_fx, long long *__restrict__ grad_fx,
-                                                float4 *s_c, int *s_odd, int *s_nan, unsigned long long *s_loss,
-                                                unsigned long long *s_acc, int tid) {
+template <bool WANT_GRAD, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+d2m_points_kernel(const uint2 *__restrict__ points, const int *__restrict__ counts, int P,
+                  const int *__restrict__ depth_index, const float *__restrict__ centres, int centre_stride,
+                  const float *__restrict__ radii, int J, int H, int W, int parts, float *__restrict__ loss_sum,
+                  float *__restrict__ grad_centres, const int *__restrict__ centre_index) {
   constexpr int K = 4, GS = 64 * K;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __shared__ float4 s_c[SHR_MAX_SPHERES];
+  __shared__ int s_odd, s_nan;
+  __shared__ unsigned long long s_loss;
+  __shared__ unsigned long long s_acc[WANT_GRAD ? kD2mTables * kD2mTableStride : 1];
+
+  const int n = blockIdx.x / parts, part = blockIdx.x - n * parts;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = depth_index ? depth_index[n] : n;
   const int T = counts[m], G = (T + GS - 1) / GS;
   const uint2 *img = points + (size_t)m * P;
@@ -461,7 +460,7 @@ __device__ __forceinline__ void d2m_points_unit(const uint2 *__restrict__ points
     const float inf = __builtin_inff();
     const bool bad = lane < J && (!(fabsf(c.x) < inf) || !(fabsf(c.y) < inf) || !(fabsf(c.z) < inf) || !(fabsf(c.w) < inf));
     const bool any = __ballot(bad) != 0ull;
-    if (lane == 0) { *s_odd = any; *s_nan = 0; *s_loss = 0ull; }
+    if (lane == 0) { s_odd = any; s_nan = 0; s_loss = 0ull; }
   }
   if (WANT_GRAD)
     for (int i = tid; i < kD2mTables * kD2mTableStride; i += WAVES * 64) s_acc[i] = 0ull;
@@ -469,108 +468,31 @@ __device__ __forceinline__ void d2m_points_unit(const uint2 *__restrict__ points
   D2mCtx ctx;
   ctx.s_c = s_c; ctx.cj = lane < J ? s_c[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
   ctx.all = J >= 64 ? ~0ull : ((1ull << J) - 1ull);
-  ctx.table_odd = *s_odd != 0; ctx.J = J; ctx.lane = lane; ctx.ax = make_axis(W); ctx.ay = make_axis(H);
-  ctx.s_acc = s_acc; ctx.acc_stride = kD2mTableStride; ctx.s_nan = s_nan;
-  long long loss_fx_acc = 0;
+  ctx.table_odd = s_odd != 0; ctx.J = J; ctx.lane = lane; ctx.ax = make_axis(W); ctx.ay = make_axis(H);
+  ctx.s_acc = s_acc; ctx.acc_stride = kD2mTableStride; ctx.s_nan = &s_nan;
+  long long loss_fx = 0;
   while (g < G) {
     const int gn = g + stride;
     if (gn < G) load_group(gn, en);               // the next group's points travel while this one is searched
 #ifndef EXP_NO_SEARCH
-    d2m_search_points<K, WANT_GRAD>(ctx, e, min(GS, T - g * GS), loss_fx_acc);
+    d2m_search_points<K, WANT_GRAD>(ctx, e, min(GS, T - g * GS), loss_fx);
 #else
-    loss_fx_acc += (long long)e[0].x + (long long)e[3].z;
+    loss_fx += (long long)e[0].x + (long long)e[3].z;
 #endif
 #pragma unroll
     for (int i = 0; i < K; i++) e[i] = en[i];
     g = gn;
   }
-  if (loss_fx_acc) atomicAdd(s_loss, (unsigned long long)loss_fx_acc);
+  if (loss_fx) atomicAdd(&s_loss, (unsigned long long)loss_fx);
   __syncthreads();
-  if (tid == 0) {
-    if (FX) loss_fx[slot] = *s_nan ? (long long)0x8000000000000000ull : (long long)*s_loss;
-    else loss_sum[slot] = *s_nan ? __builtin_nanf("") : (float)((double)(long long)*s_loss * (1.0 / (double)kLossScale));
-  }
+  if (tid == 0)
+    loss_sum[blockIdx.x] = s_nan ? __builtin_nanf("") : (float)((double)(long long)s_loss * (1.0 / (double)kLossScale));
   if (WANT_GRAD && tid < J * 3) {
     const int j = tid / 3, c = tid - j * 3;
     long long t = 0;
 #pragma unroll
     for (int k = 0; k < kD2mTables; k++) t += (long long)s_acc[k * kD2mTableStride + j * 4 + c];
-    if (FX) grad_fx[slot * J * 3 + tid] = t;
-    else grad_centres[slot * J * 3 + tid] = (float)((double)t * (1.0 / (double)kGradScale));
-  }
-}
-
-template <bool WANT_GRAD, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
-d2m_points_kernel(const uint2 *__restrict__ points, const int *__restrict__ counts, int P,
-                  const int *__restrict__ depth_index, const float *__restrict__ centres, int centre_stride,
-                  const float *__restrict__ radii, int J, int H, int W, int parts, float *__restrict__ loss_sum,
-                  float *__restrict__ grad_centres, const int *__restrict__ centre_index) {
-  __shared__ float4 s_c[SHR_MAX_SPHERES];
-  __shared__ int s_odd, s_nan;
-  __shared__ unsigned long long s_loss;
-  __shared__ unsigned long long s_acc[WANT_GRAD ? kD2mTables * kD2mTableStride : 1];
-  const int n = blockIdx.x / parts, part = blockIdx.x - n * parts;
-  d2m_points_unit<WANT_GRAD, WAVES, false>(points, counts, P, depth_index, centres, centre_stride, radii, J, H, W,
-                                           centre_index, n, part, parts, blockIdx.x, loss_sum, grad_centres, nullptr, nullptr,
-                                           s_c, &s_odd, &s_nan, &s_loss, s_acc, (int)threadIdx.x);
-}
-
-// BALANCED launch (round 5): more crops than the device holds workgroups.  One workgroup per crop left the last round
-// half empty (1152 crops on 768 slots: 1.5 rounds, the kernel 75-80 us for 40 k groups that fill the device for 45);
-// here the launch has exactly as many workgroups as are resident, the crops are cut into HALVES (groups of one parity)
-// and every workgroup takes an equal, contiguous run of half-crops -- a whole crop where both halves are its own.  The
-// halves report their fixed-point INTEGER sums (slot [n][h]; a whole crop writes [n][0] and zeroes [n][1]);
-// d2m_fx_finish_kernel adds the two integers and converts: the same bits as one workgroup per crop, however it was cut.
-template <bool WANT_GRAD, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
-d2m_points_balanced_kernel(const uint2 *__restrict__ points, const int *__restrict__ counts, int P,
-                           const int *__restrict__ depth_index, const float *__restrict__ centres, int centre_stride,
-                           const float *__restrict__ radii, int J, int H, int W, int N, long long *__restrict__ loss_fx,
-                           long long *__restrict__ grad_fx, const int *__restrict__ centre_index) {
-  __shared__ float4 s_c[SHR_MAX_SPHERES];
-  __shared__ int s_odd, s_nan;
-  __shared__ unsigned long long s_loss;
-  __shared__ unsigned long long s_acc[WANT_GRAD ? kD2mTables * kD2mTableStride : 1];
-  const long long total = 2LL * N;
-  long long u = ((long long)blockIdx.x * total) / gridDim.x;
-  const long long u1 = ((long long)(blockIdx.x + 1) * total) / gridDim.x;
-  while (u < u1) {
-    const int n = (int)(u >> 1), h = (int)(u & 1);
-    const bool whole = h == 0 && u + 1 < u1;
-    // (every unit starts from OPAQUE copies of the thread index and of the launch constants: left alone the compiler
-    // hoists what does not change between units out of the loop and keeps it in registers -- 90 VGPRs, five waves per
-    // SIMD, against 70 for one unit per workgroup)
-    int tid = threadIdx.x, J_ = J, H_ = H, W_ = W, P_ = P, cs = centre_stride;
-    asm volatile("" : "+v"(tid));
-    asm volatile("" : "+s"(J_), "+s"(H_), "+s"(W_), "+s"(P_), "+s"(cs));
-    d2m_points_unit<WANT_GRAD, WAVES, true>(points, counts, P_, depth_index, centres, cs, radii, J_, H_, W_,
-                                            centre_index, n, whole ? 0 : h, whole ? 1 : 2, (size_t)2 * n + (whole ? 0 : h),
-                                            nullptr, nullptr, loss_fx, grad_fx, s_c, &s_odd, &s_nan, &s_loss, s_acc, tid);
-    if (whole) {
-      if (threadIdx.x == 0) loss_fx[(size_t)2 * n + 1] = 0;
-      if (WANT_GRAD && (int)threadIdx.x < J * 3) grad_fx[((size_t)2 * n + 1) * J * 3 + threadIdx.x] = 0;
-    }
-    u += whole ? 2 : 1;
-    __syncthreads();          // the tables and the records are rewritten for the next unit
-  }
-}
-
-// (loss [N], grad [N][J][3]) from the halves' integers
-__global__ void __launch_bounds__(256)
-d2m_fx_finish_kernel(const long long *__restrict__ loss_fx, const long long *__restrict__ grad_fx, int N, int J,
-                     float *__restrict__ loss_sum, float *__restrict__ grad_centres) {
-  const int per = 1 + (grad_centres ? J * 3 : 0);
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)N * per) return;
-  const int n = (int)(idx / per), k = (int)(idx - (long long)n * per);
-  if (k == 0) {
-    const long long a = loss_fx[(size_t)2 * n], b = loss_fx[(size_t)2 * n + 1];
-    const long long nanv = (long long)0x8000000000000000ull;
-    loss_sum[n] = (a == nanv || b == nanv) ? __builtin_nanf("") : (float)((double)(a + b) * (1.0 / (double)kLossScale));
-  } else {
-    const long long t = grad_fx[((size_t)2 * n) * J * 3 + (k - 1)] + grad_fx[((size_t)2 * n + 1) * J * 3 + (k - 1)];
-    grad_centres[(size_t)n * J * 3 + (k - 1)] = (float)((double)t * (1.0 / (double)kGradScale));
+    grad_centres[(size_t)blockIdx.x * J * 3 + tid] = (float)((double)t * (1.0 / (double)kGradScale));
   }
 }
 
@@ -578,7 +500,6 @@ d2m_fx_finish_kernel(const long long *__restrict__ loss_fx, const long long *__r
 
 namespace {
 int g_d2m_waves = 0;   // 0 = by batch size (SHR_TUNE_D2M_WAVES)
-int g_d2m_balanced = -1;   // SHR_TUNE_D2M_BALANCED: -1 = when the crops exceed the resident workgroups, 0 = never, n > 0 = always, n workgroups
 int g_d2m_band = 0;    // 0 = by crop size (SHR_TUNE_D2M_BAND_UNITS)
 int g_d2m_tiled = -1;  // units = 32 x 8-pixel tiles + box bounds: -1 = from 192 x 192 pixels on, 0 = never, 1 = wherever W % 4 == 0 (SHR_TUNE_D2M_TILED)
 
@@ -643,11 +564,6 @@ int launch_d2m(const float *depth, const int32_t *depth_index, const float *cent
 int shr::d2m_set_waves(int waves) {
   if (waves != 0 && waves != 4 && waves != 8 && waves != 16) return SHR_EINVAL;
   g_d2m_waves = waves;
-  return SHR_OK;
-}
-int shr::d2m_set_balanced(int v) {
-  if (v < -1) return SHR_EINVAL;
-  g_d2m_balanced = v;
   return SHR_OK;
 }
 int shr::d2m_set_tiled(int on) {
@@ -775,60 +691,3 @@ extern "C" int shr_data_to_model_from_points_indexed(const void *workspace, int 
 #undef D2P_LAUNCH
   return (int)hipGetLastError();
 }
-
-// ---- the balanced launch of the point search ---------------------------------------------------------------------
-namespace {
-// workgroups of the 8-wave point search that are resident at once on this device
-int d2m_resident_slots(bool want_grad) {
-  static int slots[2] = {0, 0};
-  int &v = slots[want_grad ? 1 : 0];
-  if (v == 0) {
-    int d = 0, cus = 0, per = 0;
-    if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || cus <= 0)
-      cus = 256;
-    const hipError_t e = want_grad ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, shr::d2m_points_balanced_kernel<true, 8>, 512, 0)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, shr::d2m_points_balanced_kernel<false, 8>, 512, 0);
-    if (e != hipSuccess || per <= 0) per = 3;
-    v = cus * per;
-  }
-  return v;
-}
-}  // namespace
-
-extern "C" long long shr_data_to_model_balanced_bytes(int N, int J) {
-  if (N <= 0 || J <= 0 || J > SHR_MAX_SPHERES) return 0;
-  if (g_d2m_balanced == 0 || (g_d2m_balanced < 0 && N <= d2m_resident_slots(true))) return 0;   // one workgroup per crop fits a round
-  return (long long)N * 2 * (1 + (long long)J * 3) * 8;
-}
-
-extern "C" int shr_data_to_model_from_points_balanced(const void *workspace, int M, const int32_t *depth_index,
-                                                      const int32_t *centre_index, const float *centres, int centre_stride,
-                                                      const float *radii, int N, int J, int H, int W, void *scratch,
-                                                      float *loss_sum, float *grad_centres, void *stream) {
-  using namespace shr;
-  if (N == 0) return SHR_OK;
-  if (!workspace || !centres || !radii || !loss_sum || !scratch || N < 0 || M <= 0 || J <= 0 || H <= 0 || W <= 0) return SHR_EINVAL;
-  if ((centre_stride != 3 && centre_stride != 4) || (!depth_index && M != N) || (((uintptr_t)scratch) & 7u) != 0) return SHR_EINVAL;
-  if (!d2m_points_ok(H, W) || J > SHR_MAX_SPHERES || (long long)N * (1 + J * 3) > 0x7fffffffLL) return SHR_ETOOLARGE;
-  const uint2 *points = static_cast<const uint2 *>(workspace);
-  const int *counts = reinterpret_cast<const int *>(static_cast<const unsigned char *>(workspace) + d2m_counts_offset(M, H, W));
-  hipStream_t s = (hipStream_t)stream;
-  long long *loss_fx = static_cast<long long *>(scratch), *grad_fx = loss_fx + (size_t)2 * N;
-  int slots = d2m_resident_slots(grad_centres != nullptr);
-  if (g_d2m_balanced > 0) slots = g_d2m_balanced;                 // tests: that many workgroups
-  const long long units = 2LL * N;
-  const unsigned grid = (unsigned)(units < slots ? units : slots);
-  if (grad_centres)
-    hipLaunchKernelGGL((d2m_points_balanced_kernel<true, 8>), dim3(grid), dim3(512), 0, s, points, counts, H * W, depth_index,
-                       centres, centre_stride, radii, J, H, W, N, loss_fx, grad_fx, centre_index);
-  else
-    hipLaunchKernelGGL((d2m_points_balanced_kernel<false, 8>), dim3(grid), dim3(512), 0, s, points, counts, H * W, depth_index,
-                       centres, centre_stride, radii, J, H, W, N, loss_fx, grad_fx, centre_index);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return (int)e;
-  const long long items = (long long)N * (1 + (grad_centres ? J * 3 : 0));
-  hipLaunchKernelGGL(d2m_fx_finish_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, loss_fx, grad_fx, N, J, loss_sum,
-                     grad_centres);
-  return (int)hipGetLastError();
-}
-

@@ -99,7 +99,7 @@ def sphere_raster_bwd(spheres, grad_depth, argmin=None):
 
 TUNE_FWD_LDS_BYTES, TUNE_FWD_OWNER_LDS_BYTES, TUNE_BWD_LDS_BYTES, TUNE_FORCE_GENERAL, TUNE_FWD_WAVES = 1, 2, 3, 4, 5
 TUNE_FWD_SHARES, TUNE_BWD_SHARES, TUNE_D2M_WAVES, TUNE_D2M_BAND_UNITS, TUNE_PERSISTENT, TUNE_FWD_ZBUF_BYTES = 6, 7, 8, 9, 10, 11
-TUNE_BWD_WAVES, TUNE_MSE_BOX, TUNE_FWD_RUN_TABLE, TUNE_D2M_TILED, TUNE_TRI_BAND, TUNE_D2M_BALANCED = 12, 13, 14, 15, 16, 17
+TUNE_BWD_WAVES, TUNE_MSE_BOX, TUNE_FWD_RUN_TABLE, TUNE_D2M_TILED, TUNE_TRI_BAND = 12, 13, 14, 15, 16
 
 
 def set_tuning(key, value):
@@ -320,16 +320,6 @@ def data_to_model_from_points(ws, M, H, W, centres, radii, depth_index=None, wan
     stride = int(centres.shape[2]) if centre_stride is None else centre_stride
     P = d2m_points_parts(N) if parts is None else parts
     lib = _lib.lib()
-    nbal = lib.shr_data_to_model_balanced_bytes(int(N), int(J)) if P == 1 else 0
-    if nbal > 0:      # more crops than resident workgroups: one balanced launch (+ the integer sums' conversion), same bits
-        with _on(centres.device):
-            scratch = torch.empty(nbal // 8, dtype=torch.int64, device=centres.device)
-            loss = torch.empty((N,), dtype=torch.float32, device=centres.device)
-            grad = torch.empty((N, J, 3), dtype=torch.float32, device=centres.device) if want_grad else None
-            _lib.check(lib.shr_data_to_model_from_points_balanced(_ptr(ws), int(M), _ptr(depth_index), None, _ptr(centres), stride,
-                                                                  _ptr(radii), N, J, int(H), int(W), _ptr(scratch), _ptr(loss),
-                                                                  _ptr(grad), _stream()), "shr_data_to_model_from_points_balanced")
-        return (loss, grad) if want_grad else loss
     with _on(centres.device):
         loss = torch.empty((N, P), dtype=torch.float32, device=centres.device)
         grad = torch.empty((N, P, J, 3), dtype=torch.float32, device=centres.device) if want_grad else None
@@ -472,16 +462,9 @@ class MutualProjectionLossFused(torch.autograd.Function):
                 Rd = d2m_points_parts(E)
                 d2m = torch.empty((E, Rd), dtype=torch.float32, device=dev)
                 gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
-                nbal = lib.shr_data_to_model_balanced_bytes(int(E), int(J)) if Rd == 1 else 0
-                if nbal > 0:   # more pairs than resident workgroups (config 5: 1152 on 768): the balanced launch, same bits
-                    scratch = torch.empty(nbal // 8, dtype=torch.int64, device=dev)
-                    _lib.check(lib.shr_data_to_model_from_points_balanced(_ptr(ws), int(observed.shape[0]), _ptr(cidx), _ptr(cen_index),
-                                                                          _ptr(spheres), 4, _ptr(radii), E, J, H, W, _ptr(scratch),
-                                                                          _ptr(d2m), _ptr(gd2m), s_d2m), "shr_data_to_model_from_points_balanced")
-                else:
-                    _lib.check(lib.shr_data_to_model_from_points_indexed(_ptr(ws), int(observed.shape[0]), _ptr(cidx), _ptr(cen_index),
-                                                                         _ptr(spheres), 4, _ptr(radii), E, J, H, W, Rd, _ptr(d2m),
-                                                                         _ptr(gd2m), s_d2m), "shr_data_to_model_from_points")
+                _lib.check(lib.shr_data_to_model_from_points_indexed(_ptr(ws), int(observed.shape[0]), _ptr(cidx), _ptr(cen_index),
+                                                                     _ptr(spheres), 4, _ptr(radii), E, J, H, W, Rd, _ptr(d2m),
+                                                                     _ptr(gd2m), s_d2m), "shr_data_to_model_from_points")
                 if overlap:
                     main.wait_stream(side)
             else:
