@@ -420,13 +420,13 @@ extern "C" int shr_sphere_raster_mse_indexed(const float *spheres, const int32_t
 #ifdef SHR_TIMELINE
 // tools/headline_timeline.py only (never in the product build): the stamps of kernel `which` to host memory
 extern "C" int shr_debug_timeline(int which, void *host, size_t bytes) {
-  if (which < 0 || which > 1 || bytes > sizeof(shr::shr_tl[0])) return SHR_EINVAL;
+  if (which < 0 || which > 2 || bytes > sizeof(shr::shr_tl[0])) return SHR_EINVAL;
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return (int)e;
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(shr::shr_tl), bytes, (size_t)which * sizeof(shr::shr_tl[0]), hipMemcpyDeviceToHost);
 }
 extern "C" int shr_debug_timeline_rt(int which, void *host, size_t bytes) {
-  if (which < 0 || which > 1 || bytes > sizeof(shr::shr_tl_rt[0])) return SHR_EINVAL;
+  if (which < 0 || which > 2 || bytes > sizeof(shr::shr_tl_rt[0])) return SHR_EINVAL;
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return (int)e;
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(shr::shr_tl_rt), bytes, (size_t)which * sizeof(shr::shr_tl_rt[0]), hipMemcpyDeviceToHost);

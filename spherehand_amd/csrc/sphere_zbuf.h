@@ -52,16 +52,21 @@ constexpr int kZWaves = 16;   // 1024 threads
 // wave of the first 256 workgroups of a launch stamps s_memtime at its phase boundaries -- kernel k (0 forward, 1
 // backward), slot 0 = entry, 1 .. 5 = the kernel's own marks.  Nothing of it exists in the product build.
 #ifdef SHR_TIMELINE
-__device__ unsigned long long shr_tl[2][256 * kZWaves * 8];
+#ifndef SHR_TL_REGION
+#define SHR_TL_REGION 1u
+#endif
+__device__ unsigned long long shr_tl[3][256 * kZWaves * 8];
 // (s_memtime counters are not synchronised between CUs: only differences inside a workgroup mean anything.  Entry and
 // end are stamped with s_memrealtime as well, the device-wide 100-MHz counter, for the launch's ramp and tail.)
-__device__ unsigned long long shr_tl_rt[2][256 * kZWaves * 2];
+__device__ unsigned long long shr_tl_rt[3][256 * kZWaves * 2];
 #define SHR_TL(k, slot)                                                                              \
   do {                                                                                               \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && blockIdx.y == 0) {                            \
-      shr_tl[k][(blockIdx.x * kZWaves + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
-      if ((slot) == 0 || (slot) == 5)                                                                \
-        shr_tl_rt[k][(blockIdx.x * kZWaves + (threadIdx.x >> 6)) * 2 + ((slot) == 5)] = __builtin_amdgcn_s_memrealtime(); \
+    /* kernel 2 (fused render-and-compare at config 5's size): steady-state workgroups of row region 1 */ \
+    const unsigned tl_bx = blockIdx.x - ((k) == 2 ? 512u : 0u);                                      \
+    if ((threadIdx.x & 63) == 0 && tl_bx < 256u && blockIdx.y == ((k) == 2 ? SHR_TL_REGION : 0u)) {  \
+      shr_tl[k][(tl_bx * kZWaves + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+      if ((slot) == 0 || (slot) == ((k) == 2 ? 7 : 5))                                               \
+        shr_tl_rt[k][(tl_bx * kZWaves + (threadIdx.x >> 6)) * 2 + ((slot) != 0)] = __builtin_amdgcn_s_memrealtime(); \
     }                                                                                                \
   } while (0)
 #define SHR_TL_ENTRY(k) SHR_TL(k, 0)
@@ -1453,6 +1458,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   }
   const int region = blockIdx.y, nregions = gridDim.y;
   const int lane = tid & 63, wave = tid >> 6;
+  SHR_TL_ENTRY(2);
   const int r0 = region * rows_per_region;
   const int r1 = min(H, r0 + rows_per_region);
   const int rh = r1 - r0;
@@ -1544,7 +1550,9 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
       s_flag[12] = behind != 0ull;   // only a sphere centred behind the background can hit at exactly 100.0 (tie_owner)
     }
   }
+  SHR_TL(2, 1);   // this wave's work in front of the first barrier is done
   __syncthreads();
+  SHR_TL(2, 2);   // past the first barrier
   if (!(wave_s == 0 || bg_wave)) sph = s_sph[lane];
   float4 sph_next = make_float4(0.f, 0.f, 0.f, 0.f);
   if (pf_wave && has_next && valid)
@@ -1589,7 +1597,13 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
         },
         [](int) {});
     if (pf_wave && has_next) s_next[lane] = sph_next;
-    __syncthreads();
+    SHR_TL(2, 3);   // this wave's scan slice is done
+    // (a region no sphere touches -- the top and the bottom quarter of a 256 x 256 hand crop cut into four 64-row
+    // regions: the list is empty, every unit of the convert pass is a background unit that never looks at the
+    // z-buffer, the walk has nothing to visit: the two barriers around the convert pass order nothing)
+    const bool untouched = ua >= ub && tile_lo >= tile_hi;
+    if (!untouched) __syncthreads();
+    SHR_TL(2, 4);   // past the second barrier: the convert pass starts
 
     // ---- convert: error, its square, gradient image in place ---------------------------------
     auto convert_unit = [&](int u, const float4 t) {
@@ -1642,7 +1656,9 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
       const int c = (u << 6) + lane;
       convert_unit(u, tgt4[min(c, nchunk - 1)]);
     }
-    __syncthreads();
+    SHR_TL(2, 5);   // this wave's convert units are done
+    if (!untouched) __syncthreads();
+    SHR_TL(2, 6);   // past the third barrier: the walk starts
 
     // ---- walk (backward): static slices, per-run DPP sums into the wave's LDS row ------------
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -1742,6 +1758,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   if (general && pf_wave && has_next) s_next[lane] = sph_next;
   // ---- reductions: waves in order --------------------------------------------------------------
   sse = wave_sum_lane63(sse);
+  SHR_TL(2, 7);   // this wave's walk (and tile code) is done
   __syncthreads();
   float *s_wsum = reinterpret_cast<float *>(s_items);   // the work list is done with
   if (lane == 63) s_wsum[wave] = sse;
