@@ -1,0 +1,66 @@
+"""A/B of the sphere rasterizer forward / backward between the product library and a variant built with extra -D flags:
+    python tools/ab_variant.py build -DEXP_FLAG ...     (anywhere: tools/libspherehand_exp.so)
+    python tools/ab_variant.py                          (GPU box: alternating timings at 256 / 1152 / 9216 crops, same-bits check)"""
+import ctypes, glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+EXP = os.path.join(ROOT, "tools", "libspherehand_exp.so")
+
+
+def build(flags):
+    from spherehand_amd import build as b
+    b.build()
+    obj = "/tmp/sphere_raster_exp.o"
+    subprocess.check_call([b.HIPCC] + [f for f in b.FLAGS if f != "-shared"] + flags +
+                          ["-c", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(b.PKG, "csrc"), "-o", obj,
+                           os.path.join(b.PKG, "csrc", "sphere_raster.hip")])
+    objs = [o for o in glob.glob(os.path.join(b.OBJ_DIR, "*.o")) if not o.endswith("sphere_raster.o")]
+    subprocess.check_call([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", EXP, obj] + objs)
+    print(EXP, flags)
+
+
+def main():
+    import torch
+    import bench
+    from spherehand_amd import _lib, hand_model
+    from spherehand_amd.joint_angle import sample_poses
+    from spherehand_amd.kinematicsTransformation import HandTransformationMat
+    from spherehand_amd.render import HandBallPrimitiveRender
+    vp, i = ctypes.c_void_p, ctypes.c_int
+    libs = {"product": _lib.lib(), "variant": ctypes.CDLL(EXP)}
+    for l in libs.values():
+        l.shr_sphere_raster_fwd_ex.argtypes = [vp, i, i, i, i, vp, vp, i, vp]
+        l.shr_sphere_raster_bwd.argtypes = [vp, vp, vp, i, i, i, i, vp, vp]
+    dev = torch.device("cuda", 0)
+    S, J = 128, 41
+    mesh = hand_model.load_mesh()
+    fk = HandTransformationMat([b["offset_matrix"].astype("float32") for b in mesh["bones"]]).to(dev)
+    hbr = HandBallPrimitiveRender(mesh["bones"], S, S).to(dev)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        for n in (256, 1152, 9216):
+            with torch.no_grad():
+                sph = hbr.spheres(fk(sample_poses(n, seed=7).to(dev))).contiguous()
+            depth = torch.empty(n, S, S, device=dev); owner = torch.empty(n, S, S, device=dev, dtype=torch.uint8)
+            grad = torch.randn(n, S, S, device=dev); gs = torch.empty(n, J, 4, device=dev)
+            p = [t.data_ptr() for t in (sph, depth, owner, grad, gs)]
+            reps = 200 if n == 256 else (40 if n == 1152 else 8)
+            ref = {}
+            for rnd in range(3):
+                for name, l in libs.items():
+                    f = lambda s: l.shr_sphere_raster_fwd_ex(p[0], n, J, S, S, p[1], p[2], 1, s)
+                    f0 = lambda s: l.shr_sphere_raster_fwd_ex(p[0], n, J, S, S, p[1], None, 0, s)
+                    b = lambda s: l.shr_sphere_raster_bwd(p[0], p[3], p[2], n, J, S, S, p[4], s)
+                    assert f(stream.cuda_stream) == 0
+                    tf = bench.mean_launch_us(f, stream, reps, 3, 3, warm_ms=30.0)
+                    tb = bench.mean_launch_us(b, stream, reps, 3, 3, warm_ms=30.0)
+                    t0 = bench.mean_launch_us(f0, stream, reps, 3, 3, warm_ms=30.0)
+                    f(stream.cuda_stream); b(stream.cuda_stream); stream.synchronize()
+                    key = (depth.clone(), gs.clone())
+                    same = "" if name == "product" else "  same bits: %s" % (torch.equal(key[0], ref["d"]) and torch.equal(key[1], ref["g"]))
+                    if name == "product": ref = {"d": key[0], "g": key[1]}
+                    print("n %5d %-8s fwd+owner %7.2f  bwd %7.2f  fwd depth-only %7.2f us%s" % (n, name, tf, tb, t0, same), flush=True)
+
+
+if __name__ == "__main__":
+    build(sys.argv[2:]) if len(sys.argv) > 1 and sys.argv[1] == "build" else main()
