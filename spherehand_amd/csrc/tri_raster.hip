@@ -481,8 +481,8 @@ __global__ void zbuf_fill_kernel(uint4 *__restrict__ z, size_t n4, uint32_t key,
                                  int ntail) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const uint4 v = make_uint4(key, key, key, key);
-  for (; i < n4; i += stride) z[i] = v;
+  const v4u_t v = {key, key, key, key};
+  for (; i < n4; i += stride) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(z + i), "v"(v) : "memory");
   if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = key;
 }
 
@@ -595,7 +595,10 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
   uint32_t *z = reinterpret_cast<uint32_t *>(depth);
   const size_t n4 = n / 4;
   const int ntail = (int)(n - n4 * 4);
-  const unsigned fill_blocks = (unsigned)((n4 + 255) / 256 > 4096 ? 4096 : ((n4 + 255) / 256 ? (n4 + 255) / 256 : 1));
+  // (16384 workgroups at most: 4096 left the fill of 256 crops at 74 us, 16384 at ~60 -- torch's fill of the same bytes
+  // takes 64; write-through / non-temporal stores change nothing, tools/exp_tri_fill.sh in round 5)
+  const size_t want_blocks = (n4 + 255) / 256;
+  const unsigned fill_blocks = (unsigned)(want_blocks > 16384 ? 16384 : (want_blocks ? want_blocks : 1));
   hipLaunchKernelGGL(zbuf_fill_kernel, dim3(fill_blocks), dim3(256), 0, s, reinterpret_cast<uint4 *>(z), n4,
                      0x447A0000u /* 1000.0f, .cu:122 */, z + n4 * 4, ntail);
   if (F > 0) {
