@@ -379,6 +379,12 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
         loss, _ = crit(cam, inv, joints, real, False)
         loss.backward()
     t_sv = torch_us(same_view_step, 50, 3, 10)
+    # the same two steps as Engine's epoch loops run them: projected depth maps not materialised
+    # (MutualProjectionLoss.return_projections = False -- the module's default returns the reference's pair)
+    crit.return_projections = False
+    t_mv_lean = torch_us(mv_step, 50, 3, 10)
+    t_sv_lean = torch_us(same_view_step, 50, 3, 10)
+    crit.return_projections = True
     crit.cache_points = False
     with torch.no_grad():
         _, pts = crit.mutual_projection(cam, inv, joints.detach())
@@ -416,6 +422,9 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
                                      "cache off: what a training step pays); _same_observations_us = the same with the cache "
                                      "on and the observed images unchanged between calls (second hourglass stack, fitting loop)",
         "mutual_projection_loss_same_view_pairs_only_fwd_bwd_us": round(t_sv, 1),
+        "without_materialised_projections_us": {"all_pairs": round(t_mv_lean, 1), "same_view_pairs_only": round(t_sv_lean, 1),
+                                                "is": "return_projections = False, as Engine's epoch loops set it: the loss "
+                                                      "returns (loss, None); the numbers above return the reference's pair"},
         "crops_per_s": round(n5 / (t_mv * 1e-6), 1),
         # two-step data->model (the path the loss takes): images read once (4 S^2 each) and their foreground written as
         # 8-byte points; the search reads every crop's image list (8 B per point) + the 41 records

@@ -340,6 +340,20 @@ class Engine:
         if self.steps_per_epoch:
             n_steps = min(n_steps, self.steps_per_epoch)
         pose_it = self._pose_iter(self.synt_batch if with_real else 128 // self.num_stacks) if with_synt else None
+        # the epoch loops drop the projected depth maps (the reference hands them to its visualiser only): the loss
+        # does not materialise them here -- half of the render-and-compare kernel's HBM bytes, and in the same-view
+        # mode a whole rasterizer launch per stack (MutualProjectionLoss.return_projections)
+        mp = getattr(self.criterion, 'mv_projection_loss', None)
+        keep_projections = None if mp is None else mp.return_projections
+        if mp is not None:
+            mp.return_projections = False
+        try:
+            return self._epoch_steps(train, epoch, n_steps, real_it, pose_it, with_synt, losses, metrics_avg, t_prev)
+        finally:
+            if mp is not None:
+                mp.return_projections = keep_projections
+
+    def _epoch_steps(self, train, epoch, n_steps, real_it, pose_it, with_synt, losses, metrics_avg, t_prev):
         for it in range(n_steps):
             real = next(real_it) if real_it is not None else None
             pose = next(pose_it) if pose_it is not None else None

@@ -71,6 +71,11 @@ class MutualProjectionLoss(nn.Module):
         # alive until the next call or invalidate(); MultiTaskLoss drops it once a step's stacks are through.
         self.cache_points = True
         self._points = None        # (observed tensor, version, workspace, stream)
+        # False: forward() returns (loss, None) -- the projected depth maps are not materialised.  They are half of the
+        # fused kernel's HBM bytes (302 MB per call at config 5's size) and the only reader in the reference is its
+        # visualiser; Engine's epoch loops (which drop them) switch this off, everything else gets the reference's
+        # return value.
+        self.return_projections = True
 
     def invalidate(self):
         """Forget the cached point lists (and release the observed tensor and the workspace they pin)."""
@@ -90,10 +95,11 @@ class MutualProjectionLoss(nn.Module):
                 index, diag, diag_target = self._indices(B, V, joints.device)
                 ws, fresh, keep = self._point_lists(observed) if ops.d2m_two_step_pays(observed) else (None, False, None)
                 loss, projected = ops.MutualProjectionLossFused.apply(camera_poses, inv_camera_poses, joints, observed, radii,
-                                                                      index, diag, bool(is_mv), 500.0, ws, fresh, diag_target)
+                                                                      index, diag, bool(is_mv), 500.0, ws, fresh, diag_target,
+                                                                      bool(self.return_projections))
                 if keep is not None:        # (kept only once the call that fills them has been issued)
                     self._points = keep
-                return loss, projected.view(B, V, V, H, W)
+                return loss, (projected.view(B, V, V, H, W) if self.return_projections else None)
         projected_dms, projected_joints = mp(camera_poses, inv_camera_poses, joints)
         J = projected_joints.shape[3]
         pts = projected_joints.squeeze(-1)                                     # [B,V,V,J,3]

@@ -372,7 +372,7 @@ class MutualProjectionLossFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cam, inv_cam, joints, observed, radii, index, diag_index, is_mv, d2m_weight, points_ws=None,
-                points_fresh=False, diag_target=None):
+                points_fresh=False, diag_target=None, want_depth=True):
         cam, inv_cam, joints = (t.detach().contiguous().float() for t in (cam, inv_cam, joints))
         observed, radii = observed.contiguous().float(), radii.contiguous().float()
         for t, name in ((cam, "camera_poses"), (inv_cam, "inv_camera_poses"), (joints, "joints"), (observed, "depth_maps"),
@@ -403,7 +403,11 @@ class MutualProjectionLossFused(torch.autograd.Function):
             points_ws, points_fresh = d2m_points_workspace(observed), True
         with _on(dev):
             spheres = torch.empty((N, J, 4), dtype=torch.float32, device=dev)
-            depth = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+            # want_depth = False (MutualProjectionLoss.return_projections off: a training loop that never looks at the
+            # projections): the fused kernel writes no depth map -- half of its HBM bytes -- and the same-view mode
+            # launches no plain forward at all; an empty tensor stands in for the projections.
+            depth = torch.empty((N, H, W) if want_depth else (0, H, W), dtype=torch.float32, device=dev)
+            dptr = _ptr(depth) if want_depth else None
             # Two streams where the stack is large enough for the two-step path (MV_OVERLAP; same bits either way):
             #   caller's stream   view projection -> render-and-compare (the LONG kernel: nothing it waits for crosses
             #                     a queue) [-> the plain forward of all pairs in the same-view split]
@@ -444,7 +448,7 @@ class MutualProjectionLossFused(torch.autograd.Function):
                 E, cidx, cen_index = B * V, diag_target, diag_index
             # On a large stack the compare runs on those pairs alone (no depth output) and the plain forward kernel
             # renders all N projections behind it (SAME_VIEW_SPLIT).
-            split = overlap and not is_mv and SAME_VIEW_SPLIT
+            split = (overlap or not want_depth) and not is_mv and SAME_VIEW_SPLIT
             Em = E if split else N
             sse = torch.empty((Em, Rm), dtype=torch.float32, device=dev)
             gsp = torch.empty((Em, Rm, J, 4), dtype=torch.float32, device=dev)
@@ -452,10 +456,11 @@ class MutualProjectionLossFused(torch.autograd.Function):
                 _lib.check(lib.shr_sphere_raster_mse_indexed(_ptr(spheres), _ptr(diag_index), E, J, H, W, _ptr(observed),
                                                              _ptr(index), None, _ptr(sse), _ptr(gsp), s_main),
                            "shr_sphere_raster_mse_indexed")
-                _lib.check(lib.shr_sphere_raster_fwd_ex(_ptr(spheres), N, J, H, W, _ptr(depth), None, 0, s_main),
-                           "shr_sphere_raster_fwd_ex")
+                if want_depth:
+                    _lib.check(lib.shr_sphere_raster_fwd_ex(_ptr(spheres), N, J, H, W, dptr, None, 0, s_main),
+                               "shr_sphere_raster_fwd_ex")
             else:
-                _lib.check(lib.shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), _ptr(depth),
+                _lib.check(lib.shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), dptr,
                                                      _ptr(sse), _ptr(gsp), s_main), "shr_sphere_raster_mse")
             if two_step:
                 ws = points_ws
@@ -489,9 +494,9 @@ class MutualProjectionLossFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_depth):
         if g_loss is None:
-            return (None,) * 12
+            return (None,) * 13
         (gj,) = ctx.saved_tensors
-        return (None, None, gj * g_loss) + (None,) * 9
+        return (None, None, gj * g_loss) + (None,) * 10
 
 
 class MutualProject(torch.autograd.Function):

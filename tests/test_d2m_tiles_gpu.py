@@ -497,3 +497,33 @@ def test_loss_module_captured_in_a_hipgraph_replays_on_new_inputs(is_mv, cache):
         assert torch.equal(l2, ref(cam, inv, static_j.detach(), static_dms.clone(), is_mv)[0])
     finally:
         ops.D2M_TWO_STEP_MIN_PIXELS = keep
+
+
+@pytest.mark.parametrize("S,B", [(64, 5), (128, 12), (256, 43)])
+@pytest.mark.parametrize("is_mv", [True, False])
+def test_loss_without_materialised_projections_is_the_same_loss(S, B, is_mv):
+    """MutualProjectionLoss.return_projections = False (what Engine's epoch loops set: nobody reads the projected depth
+    maps there): the fused kernel writes no depth output, the same-view mode launches no plain forward -- loss and
+    d loss / d joints bit-identical to the default, which returns the reference's (loss, projected_dms); sizes below
+    and above the two-step / two-stream threshold."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.datasets import SyntheticMultiviewDataset
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    mesh = hand_model.load_mesh()
+    ds = SyntheticMultiviewDataset(mesh, B, S, seed=9, device="cuda")
+    full, lean = MutualProjectionLoss(S, mesh).cuda(), MutualProjectionLoss(S, mesh).cuda()
+    lean.return_projections = False
+    cam, inv, dms = ds.cam.cuda(), ds.inv_cam.cuda(), ds.dms.cuda()
+    for k in range(2):
+        j1 = (ds.joints.cuda() + 0.4 * (k + 1)).requires_grad_(True)
+        j2 = j1.detach().clone().requires_grad_(True)
+        l1, p1 = full(cam, inv, j1, dms, is_mv)
+        l2, p2 = lean(cam, inv, j2, dms, is_mv)
+        assert p2 is None and p1.shape == (B, 3, 3, S, S)
+        l1.backward()
+        l2.backward()
+        if is_mv:
+            assert torch.equal(l1, l2)
+        else:      # (the default may take the one-launch wiring on a small stack: same per-pair values, another summation order)
+            assert abs(l1.item() - l2.item()) <= 1e-6 * abs(l1.item())
+        assert torch.equal(j1.grad, j2.grad)
