@@ -194,6 +194,7 @@ pose_fwd_kernel(const float *__restrict__ params, const float *__restrict__ offs
       v = wv[j];
       rad = radii[j];
     }
+    kb = min(max(kb, 0), kBones - 1);            // (a bone number outside the hand's 17 reads a row of the table, not beyond it)
     const float4 r0 = rows[3 * kb], r1 = rows[3 * kb + 1], r2 = rows[3 * kb + 2];
     const float x = ((r0.x * v.x + r0.y * v.y) + r0.z * v.z) + r0.w * v.w;
     const float y = ((r1.x * v.x + r1.y * v.y) + r1.z * v.z) + r1.w * v.w;
