@@ -450,39 +450,40 @@ class MutualProjectionLossFused(torch.autograd.Function):
             # renders all N projections behind it (SAME_VIEW_SPLIT).
             split = (overlap or not want_depth) and not is_mv and SAME_VIEW_SPLIT
             Em = E if split else N
-            sse = torch.empty((Em, Rm), dtype=torch.float32, device=dev)
-            gsp = torch.empty((Em, Rm, J, 4), dtype=torch.float32, device=dev)
+            # the partial results of the two terms: ONE allocation, addressed by offsets (four torch.empty calls and
+            # their tensors were ~10 us of host time per step)
+            Rd = d2m_points_parts(E) if two_step else lib.shr_data_to_model_parts(E, int(H), int(W))
+            n_gsp, n_gd2m, n_sse, n_d2m = Em * Rm * J * 4, E * Rd * J * 3, Em * Rm, E * Rd
+            scratch = torch.empty(n_gsp + n_gd2m + n_sse + n_d2m, dtype=torch.float32, device=dev)
+            loss = torch.empty(1, dtype=torch.float32, device=dev)    # (its own: the result must not pin the scratch)
+            p_gsp = scratch.data_ptr()                          # (16-byte aligned: the allocation's start)
+            p_gd2m = p_gsp + 4 * n_gsp
+            p_sse = p_gd2m + 4 * n_gd2m
+            p_d2m = p_sse + 4 * n_sse
             if split:
                 _lib.check(lib.shr_sphere_raster_mse_indexed(_ptr(spheres), _ptr(diag_index), E, J, H, W, _ptr(observed),
-                                                             _ptr(index), None, _ptr(sse), _ptr(gsp), s_main),
+                                                             _ptr(index), None, p_sse, p_gsp, s_main),
                            "shr_sphere_raster_mse_indexed")
                 if want_depth:
                     _lib.check(lib.shr_sphere_raster_fwd_ex(_ptr(spheres), N, J, H, W, dptr, None, 0, s_main),
                                "shr_sphere_raster_fwd_ex")
             else:
                 _lib.check(lib.shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), dptr,
-                                                     _ptr(sse), _ptr(gsp), s_main), "shr_sphere_raster_mse")
+                                                     p_sse, p_gsp, s_main), "shr_sphere_raster_mse")
             if two_step:
                 ws = points_ws
-                Rd = d2m_points_parts(E)
-                d2m = torch.empty((E, Rd), dtype=torch.float32, device=dev)
-                gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
                 _lib.check(lib.shr_data_to_model_from_points_indexed(_ptr(ws), int(observed.shape[0]), _ptr(cidx), _ptr(cen_index),
-                                                                     _ptr(spheres), 4, _ptr(radii), E, J, H, W, Rd, _ptr(d2m),
-                                                                     _ptr(gd2m), s_d2m), "shr_data_to_model_from_points")
+                                                                     _ptr(spheres), 4, _ptr(radii), E, J, H, W, Rd, p_d2m,
+                                                                     p_gd2m, s_d2m), "shr_data_to_model_from_points")
                 if overlap:
                     main.wait_stream(side)
             else:
                 cen = spheres if is_mv else spheres.index_select(0, diag_index.long())
-                Rd = lib.shr_data_to_model_parts(E, int(H), int(W))
-                d2m = torch.empty((E, Rd), dtype=torch.float32, device=dev)
-                gd2m = torch.empty((E, Rd, J, 3), dtype=torch.float32, device=dev)
                 _lib.check(lib.shr_data_to_model_partial(_ptr(observed), _ptr(cidx), _ptr(cen), 4, _ptr(radii), E, J, H, W, Rd,
-                                                         _ptr(d2m), _ptr(gd2m), s_main), "shr_data_to_model_partial")
-            loss = torch.empty(1, dtype=torch.float32, device=dev)
+                                                         p_d2m, p_gd2m, s_main), "shr_data_to_model_partial")
             want = ctx.needs_input_grad[2]
             gj = torch.empty((B, V, J, 3), dtype=torch.float32, device=dev) if want else None
-            _lib.check(lib.shr_mv_loss_combine(_ptr(cam), _ptr(inv_cam), _ptr(sse), _ptr(gsp), Rm, _ptr(d2m), _ptr(gd2m), Rd,
+            _lib.check(lib.shr_mv_loss_combine(_ptr(cam), _ptr(inv_cam), p_sse, p_gsp, Rm, p_d2m, p_gd2m, Rd,
                                                B, V, J, H, W, 1 if is_mv else (2 if split else 0), float(d2m_weight), _ptr(loss), _ptr(gj),
                                                _stream()), "shr_mv_loss_combine")
         if want:
