@@ -177,9 +177,18 @@ __device__ __forceinline__ Item sphere_item(const float4 s, const Axis &ax, cons
     // integer or at least 1/64 below the next one, so + 0.01 then truncation is exact; ceil(h / ph) =
     // floor((h + ph - 1 + 0.5) / ph) -- at least 1/128 from an integer, the error stays below that
     // for h < 16384 (taller boxes take the IEEE division).
-    it.pw = min(w, kWave);
+    // A box 33 .. 64 pixels wide packed one row per chunk leaves up to half of a chunk's lanes without a pixel (35
+    // columns: 29 idle lanes; at 256 x 256 fourteen of the hand's 41 spheres are that wide: 822 chunks per crop where
+    // the boxes hold 569 x 64 pixels).  Such a box is walked as TWO column segments of ceil(w / 2) columns, each packed
+    // like a narrow box (35 columns -> 2 x 18, three rows per chunk: 24 chunks instead of 35); chunk c = (row group
+    // c / 2, segment c % 2).  (SHR_SEG2 = 0: round 4's packing.)
+#ifndef SHR_SEG2
+#define SHR_SEG2 1
+#endif
+    const bool seg2 = SHR_SEG2 && w > 32 && w <= kWave;
+    it.pw = seg2 ? (w + 1) >> 1 : min(w, kWave);
     it.ph = (int)(64.0f * __builtin_amdgcn_rcpf((float)it.pw) + 0.01f);
-    it.ncx = w > kWave ? (w + kWave - 1) >> 6 : 1;
+    it.ncx = w > kWave ? (w + kWave - 1) >> 6 : (seg2 ? 2 : 1);
     const float hh = (float)(h + it.ph - 1) + 0.5f;
     const int ngr = h < 16384 ? (int)(hh * __builtin_amdgcn_rcpf((float)it.ph)) : (int)(hh / (float)it.ph);
     it.nchunks = ngr * it.ncx;
@@ -391,9 +400,11 @@ __device__ __forceinline__ void walk_slice_packed(const WaveList &w, int J, int 
   const int ce = min((wend - base) >> kChunkShift, (hi - base + kChunkCost - 1) >> kChunkShift);
   const int v1l = w.item.y & 0xffff, inv15l = (int)((unsigned)w.item.y >> 16), phl = (inv15l << 6) >> 15;
   const bool active = lane < J && wend > wstart && cb < ce;
-  const bool narrow = ((w.item.z >> 8) & 0xff) == 1;
-  // (cb, ce < 4096: the caller sends taller regions through walk_slice; pw <= 64)
-  const int pk = cb | (ce << 12) | ((w.item.z & 0x7f) << 24) | ((ROWFREE && v1l < r1 - 1) ? (int)0x80000000u : 0);
+  const int ncxl = (w.item.z >> 8) & 0xff;
+  const bool seg2l = ncxl == 2 && (w.item.z & 0x7f) <= 32;       // two column segments (sphere_item), walked here as two runs
+  const bool narrow = ncxl == 1 || seg2l;
+  // (cb, ce < 4096: the caller sends taller regions through walk_slice; pw <= 64; a two-segment box: pw + 64 <= 96)
+  const int pk = cb | (ce << 12) | (((w.item.z & 0x7f) + (seg2l ? 64 : 0)) << 24) | ((ROWFREE && v1l < r1 - 1) ? (int)0x80000000u : 0);
   // what a run needs of its sphere beyond the record, formed ONCE here with lanes = spheres -- a run broadcasts the
   // result instead of repeating the arithmetic on a uniform value: r * r, the chunk's height in millimetres, the
   // row limit of a box that reaches the region's last row
@@ -408,31 +419,47 @@ __device__ __forceinline__ void walk_slice_packed(const WaveList &w, int J, int 
     const int pkj = rl(pk, j), geom = rl(w.item.x, j), rows = rl(w.item.y, j);
     const float4 s = make_float4(readlane_f(w.sph.x, j), readlane_f(w.sph.y, j), readlane_f(w.sph.z, j), 0.f);
     const float rr = readlane_f(rrl, j);
-    int c = pkj & 0xfff;
-    const int c_end = (pkj >> 12) & 0xfff, pw = (pkj >> 24) & 0x7f;
+    const int cb_j = pkj & 0xfff, ce_j = (pkj >> 12) & 0xfff, pwf = (pkj >> 24) & 0x7f;
+    const bool seg2 = pwf > 64;
+    const int pw = seg2 ? pwf - 64 : pwf;
     const int u0 = geom & 0xffff, v0 = (int)((unsigned)geom >> 16);
     const int inv15 = (int)((unsigned)rows >> 16), ph = (inv15 << 6) >> 15;
     const int ly = __mul24(lane, inv15) >> 15;
     const int lx = lane - __mul24(ly, pw);
     const bool packed = ly < ph;
-    const int u = u0 + lx;
-    const float dx = axis_coord_t<true>(ax, u) - s.x;
-    const float ca = rr - dx * dx;
-    const int v = v0 + c * ph + ly;
-    int cell = __mul24(v - r0, LW) + u;
-    const int dcell = ph * LW;
-    const float cav = packed ? ca : -1.f;
-    float yg = axis_coord_t<true>(ay, v);
     const float dyg = readlane_f(dygl, j);
-    if (ROWFREE && pkj < 0) {
-      for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell)
-        body(j, s, cell, cell + dcell, dx, cav, yg, yg + dyg, packed, packed, c + 1 < c_end, std::false_type());
-    } else {
-      const float ylim = packed ? readlane_f(yliml, j) : -3.0e38f;
-      for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell) {
-        const float ygb = yg + dyg;
-        body(j, s, cell, cell + dcell, dx, cav, yg, ygb, yg <= ylim, ygb <= ylim, c + 1 < c_end, std::true_type());
+    const int dcell = ph * LW;
+    const float ylim = packed ? readlane_f(yliml, j) : -3.0e38f;
+    // one run: the row groups [c, c_end) of the columns u0s .. (the whole box, or one of its two segments; a segment's
+    // lanes right of the box -- the second one of an odd width -- never hit)
+    auto run = [&](int u0s, int u1s, int c, int c_end) {
+      const int u = u0s + lx;
+      const float dx = axis_coord_t<true>(ax, u) - s.x;
+      const float ca = rr - dx * dx;
+      const int v = v0 + c * ph + ly;
+      int cell = __mul24(v - r0, LW) + u;
+      const float cav = (packed && u <= u1s) ? ca : -1.f;
+      float yg = axis_coord_t<true>(ay, v);
+      if (ROWFREE && pkj < 0) {
+        for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell)
+          body(j, s, cell, cell + dcell, dx, cav, yg, yg + dyg, packed, packed, c + 1 < c_end, std::false_type());
+      } else {
+        for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell) {
+          const float ygb = yg + dyg;
+          body(j, s, cell, cell + dcell, dx, cav, yg, ygb, yg <= ylim, ygb <= ylim, c + 1 < c_end, std::true_type());
+        }
       }
+    };
+    if (!seg2) {
+      run(u0, 0x7fffffff, cb_j, ce_j);
+    } else {
+      // chunks [cb, ce) of the list interleave the segments (c = 2 g + segment): each segment's row groups are a
+      // contiguous range, walked as a run of its own (pairs along the rows, as in a narrow box)
+      const int u1 = (int)((unsigned)rl(w.item.z, j) >> 16);
+      const int a0 = (cb_j + 1) >> 1, a1 = (ce_j + 1) >> 1;          // segment 0: even c
+      const int b0 = cb_j >> 1, b1 = ce_j >> 1;                      // segment 1: odd c
+      if (a0 < a1) run(u0, u1, a0, a1);
+      if (b0 < b1) run(u0 + pw, u1, b0, b1);
     }
     end_sphere(j);
   }
@@ -513,14 +540,16 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
             body(j, s, cell, cell + dcell, dx, cav, axis_coord_t<POW2>(ay, v), axis_coord_t<POW2>(ay, v + ph),
                  packed && v <= v1c, packed && v + ph <= v1c, c + 1 < c_end, std::true_type());
         }
-      } else {   // a box wider than a wave: pw = 64, ph = 1, chunk = (row c / ncx, segment c % ncx)
-        const int c_end_w = min(c_end, (v1c - v0 + 1) * ncx);
+      } else {   // column segments: chunk = (row group c / ncx, segment c % ncx) -- boxes wider than a wave (pw = 64,
+                 // ph = 1) and, where the packed walk does not take them, the two-segment boxes of 33 .. 64 columns
+        const int ngr_c = (v1c - v0 + ph) / ph;
+        const int c_end_w = min(c_end, ngr_c * ncx);
         for (; c < c_end_w; ++c) {
           const int g = rfl((int)(((float)c + 0.5f) / (float)ncx));
-          const int u = u0 + ((c - g * ncx) << 6) + lane, v = v0 + g;
+          const int u = u0 + __mul24(c - g * ncx, pw) + lx, v = v0 + __mul24(g, ph) + ly;
           const float dx = axis_coord_t<POW2>(ax, u) - s.x;
-          body(j, s, (v - r0) * LW + u, 0, dx, rr - dx * dx, axis_coord_t<POW2>(ay, v), 0.f, u <= u1, false, false,
-               std::true_type());
+          body(j, s, (v - r0) * LW + u, 0, dx, packed ? rr - dx * dx : -1.f, axis_coord_t<POW2>(ay, v), 0.f,
+               packed && u <= u1 && v <= v1c, false, false, std::true_type());
         }
       }
       end_sphere(j);

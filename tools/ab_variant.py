@@ -32,13 +32,13 @@ def main():
         l.shr_sphere_raster_fwd_ex.argtypes = [vp, i, i, i, i, vp, vp, i, vp]
         l.shr_sphere_raster_bwd.argtypes = [vp, vp, vp, i, i, i, i, vp, vp]
     dev = torch.device("cuda", 0)
-    S, J = 128, 41
+    S, J = int(os.environ.get("S", 128)), 41
     mesh = hand_model.load_mesh()
     fk = HandTransformationMat([b["offset_matrix"].astype("float32") for b in mesh["bones"]]).to(dev)
     hbr = HandBallPrimitiveRender(mesh["bones"], S, S).to(dev)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        for n in (256, 1152, 9216):
+        for n in [int(v) for v in os.environ.get("NS", "256,1152,9216").split(",")]:
             with torch.no_grad():
                 sph = hbr.spheres(fk(sample_poses(n, seed=7).to(dev))).contiguous()
             depth = torch.empty(n, S, S, device=dev); owner = torch.empty(n, S, S, device=dev, dtype=torch.uint8)
