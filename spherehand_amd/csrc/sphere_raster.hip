@@ -102,11 +102,11 @@ int persistent_grid(int N, int regions, size_t lds, int nwaves) {
   return N >= 4 * cap ? (int)cap : N;
 }
 
-template <bool OWNER, bool VEC4, bool POW2, bool PERSIST, bool BOX, bool TABLE = false>
+template <bool OWNER, bool VEC4, bool POW2, bool PERSIST, bool BOX, bool TABLE = false, bool SEG2 = false>
 int launch_zbuf_fwd_p(const float4 *sp, int N, int J, int H, int W, float *depth, uint8_t *argmin, int rows, size_t lds,
                       int zcells, dim3 grid, int flags, hipStream_t s) {
   static AttrDone attr_done;
-  auto k = sphere_zbuf_fwd_kernel<OWNER, VEC4, POW2, PERSIST, BOX, TABLE>;
+  auto k = sphere_zbuf_fwd_kernel<OWNER, VEC4, POW2, PERSIST, BOX, TABLE, SEG2>;
   const hipError_t e = allow_big_lds(k, &attr_done);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k, grid, dim3(64 * g_tune.fwd_waves), lds, s, sp, N, J, H, W, depth, argmin, rows,
@@ -138,10 +138,15 @@ int launch_zbuf_fwd_t(const float4 *sp, int N, int J, int H, int W, float *depth
   if (!box) lds = kHdrBytes + (size_t)rows * (W + kRowPad) * key;
   const int zcells = (int)((lds - kHdrBytes) / key);
   dim3 grid((unsigned)persistent_grid(N, regions, lds, g_tune.fwd_waves), (unsigned)regions);
-  if (box)
+  if (box) {
+    // images from 192 pixels on: the instantiation that packs boxes 33 .. 64 columns wide as two segments (sphere_zbuf.h SEG2)
+    if constexpr (VEC4 && POW2)
+      if ((H >= 192 || W >= 192) && (int)grid.x >= N)
+        return launch_zbuf_fwd_p<OWNER, true, true, false, true, false, true>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, flags, s);
     return (int)grid.x < N
                ? launch_zbuf_fwd_p<OWNER, VEC4, POW2, true, true>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, flags, s)
                : launch_zbuf_fwd_p<OWNER, VEC4, POW2, false, true>(sp, N, J, H, W, depth, argmin, rows, lds, zcells, grid, flags, s);
+  }
   // Whole-region z-buffer: when the run table (J x 64 entries of 8 bytes, sphere_zbuf.h build_run_table) fits behind it
   // and the workgroup has a wave to spare for it, the runs start from LDS
   if constexpr (VEC4 && POW2) {
@@ -169,11 +174,11 @@ int launch_zbuf_fwd(const float4 *sp, int N, int J, int H, int W, float *depth, 
              : launch_zbuf_fwd_t<OWNER, VEC4, false>(sp, N, J, H, W, depth, argmin, rows, flags, s);
 }
 
-template <bool VEC4, bool POW2, bool PERSIST, int NW, bool WHOLE>
+template <bool VEC4, bool POW2, bool PERSIST, int NW, bool WHOLE, bool SEG2 = false>
 int launch_zbuf_bwd_p(const float4 *sp, const float *grad, const uint8_t *argmin, int N, int J, int H, int W, float4 *gs,
                       int rows, size_t lds, int gridx, hipStream_t s) {
   static AttrDone attr_done;
-  auto k = sphere_zbuf_bwd_kernel<VEC4, POW2, PERSIST, NW, WHOLE>;
+  auto k = sphere_zbuf_bwd_kernel<VEC4, POW2, PERSIST, NW, WHOLE, SEG2>;
   const hipError_t e = allow_big_lds(k, &attr_done);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k, dim3((unsigned)gridx), dim3(64 * NW), lds, s, sp, grad, argmin, N, J, H, W, gs, rows,
@@ -197,9 +202,13 @@ int launch_zbuf_bwd_t(const float4 *sp, const float *grad, const uint8_t *argmin
     lds = fixed + (size_t)rows * row_bytes;
   }
   const int gridx = persistent_grid(N, 1, lds, kZWaves);   // (any backward workgroup has a prefetch wave to spare)
-  if (waves == 8)
+  if (waves == 8) {
+    if constexpr (VEC4 && POW2)
+      if ((H >= 192 || W >= 192) && gridx >= N)   // (two-segment boxes: see the forward)
+        return launch_zbuf_bwd_p<true, true, false, 8, false, true>(sp, grad, argmin, N, J, H, W, gs, rows, lds, gridx, s);
     return gridx < N ? launch_zbuf_bwd_p<VEC4, POW2, true, 8, false>(sp, grad, argmin, N, J, H, W, gs, rows, lds, gridx, s)
                      : launch_zbuf_bwd_p<VEC4, POW2, false, 8, false>(sp, grad, argmin, N, J, H, W, gs, rows, lds, gridx, s);
+  }
   if (rows >= H)   // the buffers hold the whole crop: rows at their own index, no exchange of the touched rows
     return gridx < N ? launch_zbuf_bwd_p<VEC4, POW2, true, 16, true>(sp, grad, argmin, N, J, H, W, gs, rows, lds, gridx, s)
                      : launch_zbuf_bwd_p<VEC4, POW2, false, 16, true>(sp, grad, argmin, N, J, H, W, gs, rows, lds, gridx, s);
@@ -393,8 +402,10 @@ extern "C" int shr_sphere_raster_mse_indexed(const float *spheres, const int32_t
     if (blds < least) blds = least;
     if (blds > (size_t)kMaxLds) blds = kMaxLds;
     const int zcells = (int)((blds - kHdrBytes - part) / 8);
-    auto k = sphere_zbuf_mse_box_kernel<true>;
-    const hipError_t e = allow_big_lds(k, &attr_c);
+    static AttrDone attr_d;
+    const bool seg2 = H >= 192 || W >= 192;        // (two-segment boxes: see the forward)
+    auto k = seg2 ? sphere_zbuf_mse_box_kernel<true, true> : sphere_zbuf_mse_box_kernel<true, false>;
+    const hipError_t e = allow_big_lds(k, seg2 ? &attr_d : &attr_c);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(1024), blds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
                        target_index, rows, log2_if_pow2(W / 4), zcells, g_tune.fwd_shares, g_tune.bwd_shares, depth,

@@ -159,6 +159,15 @@ __device__ __forceinline__ void axis_box(float c, float ar, float k, float half,
 }
 
 // (kx, ky = size / 300 per axis: wave-uniform, computed by the caller before the records arrive)
+// SEG2 (kernels for images from 192 pixels on, where a hand's spheres get there): a box 33 .. 64 pixels wide packed
+// one row per chunk leaves up to half of a chunk's lanes without a pixel (35 columns: 29 idle lanes; at 256 x 256
+// fourteen of the hand's 41 spheres are that wide: 822 chunks per crop where the boxes hold 569 x 64 pixels).  Such a
+// box is walked as TWO column segments of ceil(w / 2) columns, each packed like a narrow box (35 columns -> 2 x 18,
+// three rows per chunk: 24 chunks instead of 35); chunk c = (row group c / 2, segment c % 2).  The tag rides in the
+// walkers' kSphereCost parameter (kSeg2Tag): kernels without it are round 4's code, instruction for instruction --
+// the two-segment code in every kernel cost the 128 x 128 launches 2.6-4 % (EXPERIMENTS R2e).
+constexpr int kSeg2Tag = 0x100;
+template <bool SEG2>
 __device__ __forceinline__ Item sphere_item(const float4 s, const Axis &ax, const Axis &ay, float kx, float ky, int W,
                                             int r0, int r1) {
   int u0 = 0, u1 = W - 1, v0 = r0, v1 = r1 - 1;
@@ -177,15 +186,7 @@ __device__ __forceinline__ Item sphere_item(const float4 s, const Axis &ax, cons
     // integer or at least 1/64 below the next one, so + 0.01 then truncation is exact; ceil(h / ph) =
     // floor((h + ph - 1 + 0.5) / ph) -- at least 1/128 from an integer, the error stays below that
     // for h < 16384 (taller boxes take the IEEE division).
-    // A box 33 .. 64 pixels wide packed one row per chunk leaves up to half of a chunk's lanes without a pixel (35
-    // columns: 29 idle lanes; at 256 x 256 fourteen of the hand's 41 spheres are that wide: 822 chunks per crop where
-    // the boxes hold 569 x 64 pixels).  Such a box is walked as TWO column segments of ceil(w / 2) columns, each packed
-    // like a narrow box (35 columns -> 2 x 18, three rows per chunk: 24 chunks instead of 35); chunk c = (row group
-    // c / 2, segment c % 2).  (SHR_SEG2 = 0: round 4's packing.)
-#ifndef SHR_SEG2
-#define SHR_SEG2 1
-#endif
-    const bool seg2 = SHR_SEG2 && w > 32 && w <= kWave;
+    const bool seg2 = SEG2 && w > 32 && w <= kWave;
     it.pw = seg2 ? (w + 1) >> 1 : min(w, kWave);
     it.ph = (int)(64.0f * __builtin_amdgcn_rcpf((float)it.pw) + 0.01f);
     it.ncx = w > kWave ? (w + kWave - 1) >> 6 : (seg2 ? 2 : 1);
@@ -224,9 +225,9 @@ template <int kSphereCost>
 __device__ __forceinline__ int build_work_list(const float4 s, bool valid, const Axis &ax, const Axis &ay,
                                                float kx, float ky, int W, int r0, int r1, int4 *s_items,
                                                int *s_ends, int lane, bool *too_big, float4 *s_run = nullptr) {
-  const Item it = sphere_item(s, ax, ay, kx, ky, W, r0, r1);
+  const Item it = sphere_item<(kSphereCost & kSeg2Tag) != 0>(s, ax, ay, kx, ky, W, r0, r1);
   const int nchunks = valid ? it.nchunks : 0;
-  const int cost = nchunks > 0 ? kSphereCost + nchunks * kChunkCost : 0;
+  const int cost = nchunks > 0 ? (kSphereCost & 0xff) + nchunks * kChunkCost : 0;
   // inclusive scan over the 64 lanes: 4 DPP steps inside each row of 16, then the
   // three row totals are added with SGPR broadcasts
   int incl = cost;
@@ -336,7 +337,7 @@ __device__ __forceinline__ void walk_slice_table(const WaveList &w, int J, int l
                                                  const Axis &ay, int r0, int r1, int LW, const RunTab rt, Body &&body,
                                                  EndSphere &&end_sphere) {
   // lanes = spheres: this slice's chunk range of every sphere, packed for one v_readlane per run
-  const int wstart = w.item.w, wend = w.end, base = wstart + kSphereCost;
+  const int wstart = w.item.w, wend = w.end, base = wstart + (kSphereCost & 0xff);
   const int cb = lo <= base ? 0 : (lo - base + kChunkCost - 1) >> kChunkShift;
   const int ce = min((wend - base) >> kChunkShift, (hi - base + kChunkCost - 1) >> kChunkShift);
   const int v1 = w.item.y & 0xffff, inv15 = (int)((unsigned)w.item.y >> 16), ph = (inv15 << 6) >> 15;
@@ -395,7 +396,66 @@ template <int kSphereCost, bool ROWFREE, typename Body, typename EndSphere>
 __device__ __forceinline__ void walk_slice_packed(const WaveList &w, int J, int lo, int hi, int lane, const Axis &ax,
                                                   const Axis &ay, int r0, int r1, int LW, Body &&body,
                                                   EndSphere &&end_sphere) {
-  const int wstart = w.item.w, wend = w.end, base = wstart + kSphereCost;
+  const int wstart = w.item.w, wend = w.end, base = wstart + (kSphereCost & 0xff);
+  const int cb = lo <= base ? 0 : (lo - base + kChunkCost - 1) >> kChunkShift;
+  const int ce = min((wend - base) >> kChunkShift, (hi - base + kChunkCost - 1) >> kChunkShift);
+  const int v1l = w.item.y & 0xffff, inv15l = (int)((unsigned)w.item.y >> 16), phl = (inv15l << 6) >> 15;
+  const bool active = lane < J && wend > wstart && cb < ce;
+  const bool narrow = ((w.item.z >> 8) & 0xff) == 1;
+  // (cb, ce < 4096: the caller sends taller regions through walk_slice; pw <= 64)
+  const int pk = cb | (ce << 12) | ((w.item.z & 0x7f) << 24) | ((ROWFREE && v1l < r1 - 1) ? (int)0x80000000u : 0);
+  // what a run needs of its sphere beyond the record, formed ONCE here with lanes = spheres -- a run broadcasts the
+  // result instead of repeating the arithmetic on a uniform value: r * r, the chunk's height in millimetres, the
+  // row limit of a box that reaches the region's last row
+  const float rrl = w.sph.w * w.sph.w;
+  const float dygl = (float)phl * ay.mul;
+  const float yliml = axis_coord_t<true>(ay, min(v1l, r1 - 1)) + 0.5f * ay.mul;
+  unsigned long long m = __ballot(active && narrow);
+  const unsigned long long wide = __ballot(active && !narrow);
+  while (m) {
+    const int j = __builtin_ctzll(m);
+    m &= m - 1;
+    const int pkj = rl(pk, j), geom = rl(w.item.x, j), rows = rl(w.item.y, j);
+    const float4 s = make_float4(readlane_f(w.sph.x, j), readlane_f(w.sph.y, j), readlane_f(w.sph.z, j), 0.f);
+    const float rr = readlane_f(rrl, j);
+    int c = pkj & 0xfff;
+    const int c_end = (pkj >> 12) & 0xfff, pw = (pkj >> 24) & 0x7f;
+    const int u0 = geom & 0xffff, v0 = (int)((unsigned)geom >> 16);
+    const int inv15 = (int)((unsigned)rows >> 16), ph = (inv15 << 6) >> 15;
+    const int ly = __mul24(lane, inv15) >> 15;
+    const int lx = lane - __mul24(ly, pw);
+    const bool packed = ly < ph;
+    const int u = u0 + lx;
+    const float dx = axis_coord_t<true>(ax, u) - s.x;
+    const float ca = rr - dx * dx;
+    const int v = v0 + c * ph + ly;
+    int cell = __mul24(v - r0, LW) + u;
+    const int dcell = ph * LW;
+    const float cav = packed ? ca : -1.f;
+    float yg = axis_coord_t<true>(ay, v);
+    const float dyg = readlane_f(dygl, j);
+    if (ROWFREE && pkj < 0) {
+      for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell)
+        body(j, s, cell, cell + dcell, dx, cav, yg, yg + dyg, packed, packed, c + 1 < c_end, std::false_type());
+    } else {
+      const float ylim = packed ? readlane_f(yliml, j) : -3.0e38f;
+      for (; c < c_end; c += 2, yg += 2.f * dyg, cell += 2 * dcell) {
+        const float ygb = yg + dyg;
+        body(j, s, cell, cell + dcell, dx, cav, yg, ygb, yg <= ylim, ygb <= ylim, c + 1 < c_end, std::true_type());
+      }
+    }
+    end_sphere(j);
+  }
+  if (wide) walk_slice<true, kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere, wide);
+}
+
+// walk_slice_packed for the kernels whose lists hold two-segment boxes (sphere_item<SEG2 = true>): a box of 33 .. 64
+// columns is two runs, one per column segment.
+template <int kSphereCost, bool ROWFREE, typename Body, typename EndSphere>
+__device__ __forceinline__ void walk_slice_packed_seg2(const WaveList &w, int J, int lo, int hi, int lane, const Axis &ax,
+                                                  const Axis &ay, int r0, int r1, int LW, Body &&body,
+                                                  EndSphere &&end_sphere) {
+  const int wstart = w.item.w, wend = w.end, base = wstart + (kSphereCost & 0xff);
   const int cb = lo <= base ? 0 : (lo - base + kChunkCost - 1) >> kChunkShift;
   const int ce = min((wend - base) >> kChunkShift, (hi - base + kChunkCost - 1) >> kChunkShift);
   const int v1l = w.item.y & 0xffff, inv15l = (int)((unsigned)w.item.y >> 16), phl = (inv15l << 6) >> 15;
@@ -489,7 +549,7 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
     if (wstart >= hi) break;
     if (!((only >> j) & 1ull)) { ++j; continue; }
     const int wend = rl(w.end, j);
-    const int base = wstart + kSphereCost;
+    const int base = wstart + (kSphereCost & 0xff);
     // chunk c sits at base + c * kChunkCost and belongs to the slice that holds that position
     int c = lo <= base ? 0 : (lo - base + kChunkCost - 1) >> kChunkShift;
     const int c_end = min((wend - base) >> kChunkShift, (hi - base + kChunkCost - 1) >> kChunkShift);
@@ -540,8 +600,9 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
             body(j, s, cell, cell + dcell, dx, cav, axis_coord_t<POW2>(ay, v), axis_coord_t<POW2>(ay, v + ph),
                  packed && v <= v1c, packed && v + ph <= v1c, c + 1 < c_end, std::true_type());
         }
-      } else {   // column segments: chunk = (row group c / ncx, segment c % ncx) -- boxes wider than a wave (pw = 64,
-                 // ph = 1) and, where the packed walk does not take them, the two-segment boxes of 33 .. 64 columns
+      } else if constexpr ((kSphereCost & kSeg2Tag) != 0) {
+        // column segments of any packing: chunk = (row group c / ncx, segment c % ncx) -- boxes wider than a wave (pw =
+        // 64, ph = 1) and the two-segment boxes of 33 .. 64 columns where the packed walk does not take them
         const int ngr_c = (v1c - v0 + ph) / ph;
         const int c_end_w = min(c_end, ngr_c * ncx);
         for (; c < c_end_w; ++c) {
@@ -550,6 +611,15 @@ __device__ __forceinline__ void walk_slice(const WaveList &w, int J, int lo, int
           const float dx = axis_coord_t<POW2>(ax, u) - s.x;
           body(j, s, (v - r0) * LW + u, 0, dx, packed ? rr - dx * dx : -1.f, axis_coord_t<POW2>(ay, v), 0.f,
                packed && u <= u1 && v <= v1c, false, false, std::true_type());
+        }
+      } else {   // a box wider than a wave: pw = 64, ph = 1, chunk = (row c / ncx, segment c % ncx)
+        const int c_end_w = min(c_end, (v1c - v0 + 1) * ncx);
+        for (; c < c_end_w; ++c) {
+          const int g = rfl((int)(((float)c + 0.5f) / (float)ncx));
+          const int u = u0 + ((c - g * ncx) << 6) + lane, v = v0 + g;
+          const float dx = axis_coord_t<POW2>(ax, u) - s.x;
+          body(j, s, (v - r0) * LW + u, 0, dx, rr - dx * dx, axis_coord_t<POW2>(ay, v), 0.f, u <= u1, false, false,
+               std::true_type());
         }
       }
       end_sphere(j);
@@ -588,7 +658,10 @@ __device__ __forceinline__ void walk_my_slice(const WaveList &w, int J, int tota
     static_assert(POW2, "the run table carries exact power-of-two coordinates");
     walk_slice_table<kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, rt, body, end_sphere);
   } else if constexpr (POW2) {
-    if (r1 - r0 < 4096) walk_slice_packed<kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere);
+    if (r1 - r0 < 4096) {
+      if constexpr ((kSphereCost & kSeg2Tag) != 0) walk_slice_packed_seg2<kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere);
+      else walk_slice_packed<kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere);
+    }
     else walk_slice<POW2, kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere);
   } else {
     walk_slice<POW2, kSphereCost, ROWFREE>(w, J, lo, hi, lane, ax, ay, r0, r1, LW, body, end_sphere);
@@ -745,7 +818,7 @@ __host__ __device__ __forceinline__ int max_box_pitch(int W) { return ((W + 3) &
 // other waves fill that time with the z-buffer initialisation and then with the
 // BACKGROUND ROWS: rows no sphere's box touches (half of a hand crop) are stored straight
 // from registers before the first barrier and never pass through LDS or the decode.
-template <bool OWNER, bool VEC4, bool POW2, bool PERSIST, bool BOX, bool TABLE = false>
+template <bool OWNER, bool VEC4, bool POW2, bool PERSIST, bool BOX, bool TABLE = false, bool SEG2 = false>
 __global__ void __launch_bounds__(1024)
 sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_,
                        float *__restrict__ depth, uint8_t *__restrict__ argmin, int rows_per_region_,
@@ -760,7 +833,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   Key *zbuf = reinterpret_cast<Key *>(smem + kHdrBytes);
   // TABLE (whole-region z-buffer, one workgroup per CU, not persistent): the run table follows the z-buffer, the
   // spheres' run records take the place of the next crop's records (build_run_table)
-  static_assert(!TABLE || (POW2 && VEC4 && !BOX && !PERSIST), "run table: whole-crop workgroups on power-of-two images");
+  static_assert(!TABLE || (POW2 && VEC4 && !BOX && !PERSIST && !SEG2), "run table: whole-crop workgroups on power-of-two images");
   uint2 *s_tab = reinterpret_cast<uint2 *>(smem + kHdrBytes + (size_t)zcells_ * sizeof(Key));
   float4 *s_run = s_next;
 
@@ -863,7 +936,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     const unsigned long long behind = __ballot(valid && sph.z > kBackground);
     SHR_TL(0, 6);   // (list wave) the crop's records have arrived
     bool too_big;   // excluded by the launcher (W <= kMaxFastWidth, H <= 32768)
-    const int total = build_work_list<kSphereCostFwd>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big,
+    const int total = build_work_list<kSphereCostFwd | (SEG2 ? kSeg2Tag : 0)>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big,
                                                       TABLE ? s_run : nullptr);
     SHR_TL(0, 7);   // (list wave) the work list stands
     if (lane == 0) {
@@ -1001,7 +1074,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
       wl.item = s_items[lane];
       wl.end = s_ends[lane];
       Key *zb = zbuf - (p0 * pitch + cu0);   // cell of pixel (v, u) = zb[v * pitch + u]
-      walk_my_slice<POW2, kSphereCostFwd, true, TABLE>(
+      walk_my_slice<POW2, kSphereCostFwd | (SEG2 ? kSeg2Tag : 0), true, TABLE>(
           wl, J, s_flag[1], wave, nwaves, shares, lane, ax, ay, 0, clip, pitch,
           [&](int j, const float4 s, int cell_a, int cell_b, float, float ca, float yga, float ygb, bool ok_a,
               bool ok_b, bool has_b, auto row_test) {
@@ -1118,7 +1191,7 @@ constexpr int kSpecUnits = 2;    // ... and units per wave requested before the 
 // copy such registers -- before the data was there -- as soon as the path from the request to its wait branched.
 constexpr int kBwdVgprs = 96;
 
-template <bool VEC4, bool POW2, bool PERSIST, int NW, bool WHOLE>
+template <bool VEC4, bool POW2, bool PERSIST, int NW, bool WHOLE, bool SEG2 = false>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_num_vgpr(kBwdVgprs)))
 sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restrict__ grad_depth,
                        const uint8_t *__restrict__ argmin, int N, int J_, int H_, int W_,
@@ -1241,7 +1314,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
   auto build_list = [&](int r0, int r1) {
     if (wave_s == 0) {
       bool too_big;   // excluded by the launcher (W <= kMaxFastWidth)
-      const int total = build_work_list<kSphereCostBwd>(sph, lane < J, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
+      const int total = build_work_list<kSphereCostBwd | (SEG2 ? kSeg2Tag : 0)>(sph, lane < J, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
       if (lane == 0) s_flag[1] = total;
       SHR_TL(1, 7);   // (wave 0) the work list stands
     }
@@ -1372,7 +1445,7 @@ sphere_zbuf_bwd_kernel(const float4 *__restrict__ spheres, const float *__restri
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const int cell_max = rh * LW - 1;
     const WaveList wl = load_wave_list(s_sph, s_items, s_ends, lane);
-    walk_my_slice<POW2, kSphereCostBwd, false>(
+    walk_my_slice<POW2, kSphereCostBwd | (SEG2 ? kSeg2Tag : 0), false>(
         wl, J, s_flag[1], wave, NW, shares, lane, ax, ay, r0, r1, LW,
         [&](int j, const float4 s, int cell_a, int cell_b, float dx, float ca, float yga, float ygb, bool ok_a,
             bool ok_b, bool has_b, auto) {
@@ -1455,7 +1528,7 @@ constexpr int kSphereCostMse = 28;
 // (BOX: the z-buffer covers the touched box only, `zcells` cells, as in the forward -- half of a CU's LDS and, with
 // 64 VGPRs, two workgroups per CU; the rows a box has beyond it go through the tile code of the general path, which
 // adds to the same partial sums.  Needs a power-of-two image at least 32 wide: tile rows are then whole units.)
-template <bool POW2, bool PERSIST, bool BOX>
+template <bool POW2, bool PERSIST, bool BOX, bool SEG2 = false>
 __device__ __forceinline__ void
 sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, int W_, const float *__restrict__ target,
                      const int *__restrict__ target_index, float *__restrict__ depth,
@@ -1572,7 +1645,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
     const unsigned long long low = __ballot(valid && sph.z <= kBackground);
     const unsigned long long behind = __ballot(valid && sph.z > kBackground);
     bool too_big;
-    const int total = build_work_list<kSphereCostMse>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
+    const int total = build_work_list<kSphereCostMse | (SEG2 ? kSeg2Tag : 0)>(sph, valid, ax, ay, kx, ky, W, r0, r1, s_items, s_ends, lane, &too_big);
     if (lane == 0) {
       s_flag[0] = (bad != 0ull) || (low == 0ull) || too_big;
       s_flag[1] = total;
@@ -1605,7 +1678,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
     wl.sph = sph;
     wl.item = s_items[lane];
     wl.end = s_ends[lane];
-    walk_my_slice<POW2, kSphereCostMse, true>(
+    walk_my_slice<POW2, kSphereCostMse | (SEG2 ? kSeg2Tag : 0), true>(
         wl, J, s_flag[1], wave, kZWaves, shares_fwd, lane, ax, ay, 0, clip, pitch,
         [&](int j, const float4 s, int cell_a, int cell_b, float, float ca, float yga, float ygb, bool ok_a,
             bool ok_b, bool has_b, auto row_test) {
@@ -1692,7 +1765,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
     // ---- walk (backward): static slices, per-run DPP sums into the wave's LDS row ------------
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const int cell_max = (p0 * pitch + cu0) + (pe - p0) * pitch - 1;   // the z-buffer's last cell, as the walk counts cells
-    walk_my_slice<POW2, kSphereCostMse, true>(
+    walk_my_slice<POW2, kSphereCostMse | (SEG2 ? kSeg2Tag : 0), true>(
         wl, J, s_flag[1], wave, kZWaves, shares_bwd, lane, ax, ay, 0, clip, pitch,
         [&](int j, const float4 s, int cell_a, int cell_b, float dx, float ca, float yga, float ygb, bool ok_a,
             bool ok_b, bool has_b, auto) {
@@ -1827,14 +1900,14 @@ sphere_zbuf_mse_kernel(const float4 *__restrict__ spheres, int N, int J, int H, 
 // two of these per CU: eight waves per SIMD, i.e. at most 64 VGPRs -- and few enough SGPRs: left alone the kernel takes
 // 93 (descriptor count) and the second workgroup does not become resident (242 us against 172 with the cap's 78 and 15
 // scalar spills, 1152 crops @256x256)
-template <bool POW2>
+template <bool POW2, bool SEG2 = false>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sphere_zbuf_mse_box_kernel(const float4 *__restrict__ spheres, int N, int J, int H, int W, const float *__restrict__ target,
                            const int *__restrict__ target_index, int rows_per_region, int w4_shift, int zcells,
                            int shares_fwd, int shares_bwd, float *__restrict__ depth, float *__restrict__ sse_out,
                            float4 *__restrict__ grad_out, AxisK axk, const int *__restrict__ crop_index) {
   static_assert(POW2, "box variant: power-of-two images");
-  sphere_zbuf_mse_body<POW2, false, true>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
+  sphere_zbuf_mse_body<POW2, false, true, SEG2>(spheres, N, J, H, W, target, target_index, depth, sse_out, grad_out,
                                           rows_per_region, w4_shift, shares_fwd, shares_bwd, zcells, axk, crop_index);
 }
 
