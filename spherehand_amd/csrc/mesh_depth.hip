@@ -24,6 +24,27 @@
 
 namespace shr {
 
+// In-kernel timeline (tools/exp_mesh_phases.py builds this file alone with -DMESH_TL): s_memtime of every wave of the
+// first 256 workgroups at the phase boundaries, read back through shr_mesh_debug_timeline.  Not in the product build.
+#ifdef MESH_TL
+__device__ unsigned long long mesh_tl[256 * 16 * 16];
+#define MESH_STAMP(slot)                                                                                      \
+  do {                                                                                                        \
+    asm volatile("" ::: "memory");   /* (what precedes the stamp in the source is issued in front of it) */      \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y < 256)                                       \
+      mesh_tl[(blockIdx.y * 16 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_amdgcn_s_memtime();            \
+    asm volatile("" ::: "memory");                                                                            \
+  } while (0)
+#define MESH_NOTE(slot, value)                                                                                \
+  do {                                                                                                        \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y < 256)                                       \
+      mesh_tl[(blockIdx.y * 16 + (threadIdx.x >> 6)) * 16 + (slot)] = (unsigned long long)(value);            \
+  } while (0)
+#else
+#define MESH_STAMP(slot) do {} while (0)
+#define MESH_NOTE(slot, value) do {} while (0)
+#endif
+
 __device__ __forceinline__ uint32_t mkey(float d) {
   const uint32_t b = __float_as_uint(d);
   return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
@@ -177,6 +198,7 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float scale = (float)src / (float)S;
   const float4 *verts = vertices + (size_t)b * NV;
+  MESH_STAMP(0);
 
   for (int i = tid; i < SL * TO * (SL * TO + 1); i += blockDim.x) (&s_z[0][0])[i] = 0x447A0000u ^ 0x80000000u;  // 1000.0f
 
@@ -265,6 +287,7 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
       return incl + (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
     };
     const int incl = wave_scan(n), incl_rows = wave_scan(nrow);
+    MESH_STAMP(1);   // this wave's culls and counts are done
     __syncthreads();   // the previous round's queue is consumed, s_wave_cnt is free
     if (lane == 63) { s_wave_cnt[wave] = incl; s_wave_rows[wave] = incl_rows; }
     __syncthreads();
@@ -290,8 +313,12 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
       row++;
     }
     __syncthreads();
+    MESH_STAMP(2);   // the scans are through, the survivors' rows are assigned
     for (int r = tid; r < min(kMeshRows, total_rows); r += blockDim.x)
       s_rows[r] = face_row(face_setup_sorted(verts, faces, s_rows[r].pad[0], src));
+    MESH_STAMP(3);   // this wave's face rows stand
+    MESH_NOTE(8, total);
+    MESH_NOTE(9, total_rows);
     for (int w0 = 0; w0 < total; w0 += kMeshQueue) {
       if (w0 > 0) __syncthreads();
       {
@@ -316,7 +343,9 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
         }
       }
       if (tid == 0) s_next_item = 0;
+      if (w0 == 0) MESH_STAMP(4);   // this wave's queue entries are written (first round)
       __syncthreads();
+      if (w0 == 0) MESH_STAMP(5);   // phase B starts (first round)
       // ---- B. rasterize the queued items (order is irrelevant: integer minima) ---------------
       // (64 items at a time from a counter: consecutive items are one face's columns and neighbouring faces -- with a
       // static stride the wave that holds the crop's large faces finished at 33 k cycles against a mean of 26 k)
@@ -383,6 +412,7 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
       }
     }
   }
+  MESH_STAMP(6);     // this wave found the queue empty
   __syncthreads();
 
   // ---- clamp + bilinear (mesh/render.py:286, :311; ATen upsample_bilinear2d) ---------------
@@ -418,9 +448,16 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
       out[(size_t)y * S + x] = ly.l0 * (lx.l0 * v[0][0] + lx.l1 * v[0][1]) + ly.l1 * (lx.l0 * v[1][0] + lx.l1 * v[1][1]);
     }
   }
+  MESH_STAMP(7);
 }
 
 }  // namespace shr
+
+#ifdef MESH_TL
+extern "C" int shr_mesh_debug_timeline(unsigned long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(shr::mesh_tl), sizeof(shr::mesh_tl));
+}
+#endif
 
 extern "C" int shr_mesh_depth_fwd(const float *vertices, const int32_t *faces, int B, int NV, int F, int src_size,
                                   int S, float clamp_max, float *depth, void *stream) {
