@@ -31,6 +31,8 @@ def main():
     for l in libs.values():
         l.shr_sphere_raster_fwd_ex.argtypes = [vp, i, i, i, i, vp, vp, i, vp]
         l.shr_sphere_raster_bwd.argtypes = [vp, vp, vp, i, i, i, i, vp, vp]
+        l.shr_sphere_raster_mse.argtypes = [vp, i, i, i, i, vp, vp, vp, vp, vp, vp]
+        l.shr_sphere_raster_mse_regions.argtypes = [i, i]
     dev = torch.device("cuda", 0)
     S, J = int(os.environ.get("S", 128)), 41
     mesh = hand_model.load_mesh()
@@ -59,6 +61,13 @@ def main():
                     key = (depth.clone(), gs.clone())
                     same = "" if name == "product" else "  same bits: %s" % (torch.equal(key[0], ref["d"]) and torch.equal(key[1], ref["g"]))
                     if name == "product": ref = {"d": key[0], "g": key[1]}
+                    if os.environ.get("MSE"):   # the fused render-and-compare kernel on the same crops (target: the depth map + noise)
+                        R = l.shr_sphere_raster_mse_regions(S, S)
+                        tgt = (ref.get("d", depth) + 3.0 * torch.randn_like(depth)).contiguous()
+                        sse = torch.empty(n * R, device=dev); gsp = torch.empty(n * R * J * 4, device=dev)
+                        m = lambda s: l.shr_sphere_raster_mse(p[0], n, J, S, S, tgt.data_ptr(), None, p[1], sse.data_ptr(), gsp.data_ptr(), s)
+                        assert m(stream.cuda_stream) == 0
+                        print("n %5d %-8s render-and-compare %7.2f us" % (n, name, bench.mean_launch_us(m, stream, reps, 3, 3, warm_ms=30.0)), flush=True)
                     print("n %5d %-8s fwd+owner %7.2f  bwd %7.2f  fwd depth-only %7.2f us%s" % (n, name, tf, tb, t0, same), flush=True)
 
 
