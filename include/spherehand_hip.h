@@ -77,9 +77,9 @@ int shr_device_info(char *name_host, int name_len, int *num_cu_host);
                                     * points' own box (needs W % 4 == 0 and 16-byte aligned images), 0 = 256 consecutive
                                     * pixels per unit and strip bounds (round 2's kernel), -1 = tiles from 192 x 192 pixels
                                     * on (default) */
-#define SHR_TUNE_TRI_BAND 16         /* shr_tri_raster_fwd: -1 = by batch size (default: the LDS band kernel for up to 4
-                                    * crops, the global-atomic kernel above), 0 = always the atomic kernel, n > 0 = always
-                                    * the band kernel, bands of at most n rows */
+#define SHR_TUNE_TRI_BAND 16         /* shr_tri_raster_fwd: -1 = the LDS band kernel wherever it fits (default: band height
+                                    * and workgroups per crop planned per launch), 0 = always the global-atomic kernel,
+                                    * n > 0 = the band kernel with bands of at most n rows */
 int shr_set_tuning(int key, int value);
 /* Self-test: adds to *mismatches (device, caller-zeroed u64) the number of fp32
  * bit patterns in [lo_bits, hi_bits) where the rasterizer's internal square root

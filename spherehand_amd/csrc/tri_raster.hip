@@ -156,9 +156,9 @@ __device__ __forceinline__ float span_depth(const float pz[3], const float fi[9]
 constexpr int kFaceRow = 28;          // x0 y0 x1 y1 x2 y2 s01 s12 | z0 z1 z2 fi[9] | x of column item 0, r_lo, r_hi, s02 | slope flags
 constexpr int kFacesPerWave = 32;     // 4.5 KB of LDS per wave (rows, queue): eight waves per SIMD fit
 // a wave's private scratch: face rows | pixel queue
-constexpr int kScratchFaceBytes = kFacesPerWave * kFaceRow * 4;                    // 3584
 constexpr int kScratchQueueBytes = 128 * 8;                                        // 1024
-constexpr int kWaveScratchBytes = kScratchFaceBytes + kScratchQueueBytes;
+constexpr int wave_scratch_bytes(int nf) { return nf * kFaceRow * 4 + kScratchQueueBytes; }
+constexpr int kWaveScratchBytes = wave_scratch_bytes(kFacesPerWave);               // 3584 + 1024
 
 // One batch: lane l < 32 brings face set-up `s` (`have`: the lane holds a face; rows [s.r_lo, s.r_hi] already clipped
 // to what the caller wants rasterized); every pixel inside its column's span goes to sink(xi, yi, depth) once.
@@ -198,17 +198,24 @@ __device__ __forceinline__ int run_of(int incl, bool mine, int k0, int k) {
 // Rounds 1-4 walked every face's BOX (16-pixel groups; 8x8 patches of one face at a time for boxes above 256 pixels)
 // with a span test per box pixel: three box pixels in four lie outside the spans, and the large boxes -- one face in
 // six of the hand mesh, six tenths of its box pixels -- took 380 of the kernel's 630 us for 256 crops.
-template <typename Sink>
+// NF = faces per batch (lanes 0 .. NF - 1 bring one each; `scratch` = wave_scratch_bytes(NF)).
+// LEVELS: the pixels of a chunk of columns are queued LEVEL by level -- level t = row ylo + t of every column whose span
+// is longer than t, compacted with a ballot -- instead of column after column: a level costs a ballot and a store where
+// the pixel-order walk pays a run search and three shuffles per 64 pixels, and a drain's neighbouring lanes are then
+// neighbouring columns at one height.  For an LDS sink (band kernel): 1 crop 54 -> 37 us.  NOT for the global atomics:
+// 64 lanes in a few cache lines resolve slower in the L2 than 64 lanes in 64 lines (256 crops 461 -> 544 us;
+// tools/exp_tri_level.py, EXPERIMENTS R3c).
+template <int NF, bool LEVELS, typename Sink>
 __device__ __forceinline__ void raster_batch(const FaceSetup &s, bool have, int lane, unsigned char *scratch, int height,
                                              Sink &&sink) {
   float (*s_face)[kFaceRow] = reinterpret_cast<float (*)[kFaceRow]>(scratch);
-  uint2 *s_queue = reinterpret_cast<uint2 *>(scratch + kScratchFaceBytes);
+  uint2 *s_queue = reinterpret_cast<uint2 *>(scratch + NF * kFaceRow * 4);
   const int bw = s.xi_max - s.xi_min + 1, bh = s.r_hi - s.r_lo + 1;
   const bool alive = have && s.live && bh > 0 && bw > 0;
   const int ncol = alive ? bw : 0;                     // (<= 65535 columns each, 32 faces: 32 bits)
   const int fincl = wave_scan_incl(ncol, lane);        // lanes = faces: the face's columns end here
   const int ncols = __builtin_amdgcn_readlane(fincl, 63);
-  if (lane < kFacesPerWave) {
+  if (lane < NF) {
     float *r = s_face[lane];
 #pragma unroll
     for (int a = 0; a < 3; a++) { r[2 * a] = s.p[a][0]; r[2 * a + 1] = s.p[a][1]; r[8 + a] = s.p[a][2]; }
@@ -239,7 +246,7 @@ __device__ __forceinline__ void raster_batch(const FaceSetup &s, bool have, int 
   for (int k0 = 0; k0 < ncols; k0 += 64) {
     const int k = k0 + lane;
     const bool colv = k < ncols;
-    const int face = min(run_of(fincl, lane < kFacesPerWave, k0, k), kFacesPerWave - 1);   // (faces without a column count as runs too)
+    const int face = min(run_of(fincl, lane < NF, k0, k), NF - 1);   // (faces without a column count as runs too)
     const float4 *r4 = reinterpret_cast<const float4 *>(s_face[face]);
     const float4 a0 = r4[0], a1 = r4[1], i0 = r4[5];
     const int fl = __float_as_int(s_face[face][24]);
@@ -249,21 +256,36 @@ __device__ __forceinline__ void raster_batch(const FaceSetup &s, bool have, int 
     ylo = max(ylo, __float_as_int(i0.y));
     yhi = min(yhi, __float_as_int(i0.z));
     const int cnt = (colv && yhi >= ylo) ? yhi - ylo + 1 : 0;   // (a span holds at most 65535 rows, a chunk 64 columns)
-    const int cincl = wave_scan_incl(cnt, lane);
-    const int ctotal = __builtin_amdgcn_readlane(cincl, 63), cexcl = cincl - cnt;
-    const int packed = face | (xi << 8);                          // (face < 32, xi < 65536)
-    for (int p0 = 0; p0 < ctotal; p0 += 64) {
-      const int p = p0 + lane;
-      const int col = min(run_of(cincl, colv, p0, p), 63);       // (empty columns among the runs count too)
-      const int cy = __shfl(ylo, col), ce = __shfl(cexcl, col), fx = __shfl(packed, col);
-      const bool inside = p < ctotal;
-      const unsigned long long m = __ballot(inside);
-      if (inside) {
-        const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        s_queue[pos] = make_uint2((unsigned)(fx & 0xff), (unsigned)(fx >> 8) | ((unsigned)(cy + (p - ce)) << 16));
+    if (LEVELS) {
+      const unsigned packed = (unsigned)xi | ((unsigned)ylo << 16);   // (xi, yi < 65536)
+      for (int t = 0;; t++) {
+        const bool on = cnt > t;
+        const unsigned long long m = __ballot(on);
+        if (m == 0ull) break;
+        if (on) {
+          const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          s_queue[pos] = make_uint2((unsigned)face, packed + ((unsigned)t << 16));
+        }
+        qn += __popcll(m);
+        if (qn >= 64) drain(64);
       }
-      qn += __popcll(m);
-      if (qn >= 64) drain(64);
+    } else {
+      const int cincl = wave_scan_incl(cnt, lane);
+      const int ctotal = __builtin_amdgcn_readlane(cincl, 63), cexcl = cincl - cnt;
+      const int packed = face | (xi << 8);                          // (face < 32, xi < 65536)
+      for (int p0 = 0; p0 < ctotal; p0 += 64) {
+        const int p = p0 + lane;
+        const int col = min(run_of(cincl, colv, p0, p), 63);       // (empty columns among the runs count too)
+        const int cy = __shfl(ylo, col), ce = __shfl(cexcl, col), fx = __shfl(packed, col);
+        const bool inside = p < ctotal;
+        const unsigned long long m = __ballot(inside);
+        if (inside) {
+          const int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          s_queue[pos] = make_uint2((unsigned)(fx & 0xff), (unsigned)(fx >> 8) | ((unsigned)(cy + (p - ce)) << 16));
+        }
+        qn += __popcll(m);
+        if (qn >= 64) drain(64);
+      }
     }
   }
   if (qn > 0) drain(qn);
@@ -312,7 +334,7 @@ tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, 
   const FaceSetup s = face_setup(f, width, height);
   float *zimg = zbuf + (size_t)b * width * height;
   __shared__ __attribute__((aligned(16))) unsigned char s_scratch[4][kWaveScratchBytes];
-  raster_batch(s, have, lane, s_scratch[threadIdx.x >> 6], height,
+  raster_batch<kFacesPerWave, false>(s, have, lane, s_scratch[threadIdx.x >> 6], height,
                [&](int xi, int yi, float zp) { zmin(zimg + (size_t)yi * width + xi, zp); });
 }
 
@@ -330,6 +352,9 @@ tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, 
 //            that reach the band and rasterizes them 32 at a time (raster_batch, rows clipped to the band) with an LDS
 //            minimum per covered pixel, and the band is streamed out.
 constexpr int kBandWaves = 16;
+constexpr int kBandFaces = 16;            // faces per batch: a wave's share of a band's faces is about that, and sixteen rows of
+                                          // scratch less per wave are eleven more rows of band (2.8 instead of 4.5 KB per wave)
+constexpr int kBandScratchBytes = wave_scratch_bytes(kBandFaces);
 constexpr int kBandMaxBands = 512;        // per-band face counters in LDS
 constexpr uint32_t kFillBits = 0x447A0000u;   // 1000.0f, .cu:122
 
@@ -361,7 +386,7 @@ __device__ __forceinline__ uint32_t face_row_range(const float f[9], int width, 
 template <bool INDEXED>
 __global__ void __launch_bounds__(kBandWaves * 64)
 tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, int B, int F, int NV, int width, int height,
-                float *__restrict__ zbuf, int R, int nbands, int bands_per_seg) {
+                float *__restrict__ zbuf, int R, int nbands) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int Fpad = (F + 7) & ~7;
   uint32_t *s_range = reinterpret_cast<uint32_t *>(smem);
@@ -371,7 +396,9 @@ tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, in
   __shared__ int s_bandcnt[kBandMaxBands];
   __shared__ int s_npend;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int band0 = blockIdx.y * bands_per_seg, band1 = min(nbands, band0 + bands_per_seg);
+  // workgroup y of a crop takes bands y, y + gridDim.y, ...: interleaved, so that every workgroup of a crop gets its
+  // share of the hand's rows and of the empty ones (consecutive bands: the top and bottom segments were nearly free)
+  const int band_first = blockIdx.y, band_step = gridDim.y;
   float *zimg = zbuf + (size_t)b * width * height;
   const bool counted = nbands <= kBandMaxBands;
   for (int i = tid; i < min(nbands, kBandMaxBands); i += kBandWaves * 64) s_bandcnt[i] = 0;
@@ -385,7 +412,7 @@ tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, in
     s_range[fidx] = rw;
     if (counted && rw != 0xFFFFu) {
       // (band numbers through a float quotient: a band too many on either side only costs that band its shortcut)
-      const int ba = max(band0, (int)((float)(rw & 0xffffu) * rinv) - 1), bb = min(band1 - 1, (int)((float)(rw >> 16) * rinv) + 1);
+      const int ba = max(0, (int)((float)(rw & 0xffffu) * rinv) - 1), bb = min(nbands - 1, (int)((float)(rw >> 16) * rinv) + 1);
       for (int k = ba; k <= bb; k++)
         if ((int)(rw & 0xffffu) <= min(height, (k + 1) * R) - 1 && (int)(rw >> 16) >= k * R) atomicAdd(&s_bandcnt[k], 1);
     }
@@ -393,9 +420,9 @@ tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, in
   __syncthreads();
   // ---- phase 2: the bands ----------------------------------------------------------------------------------------
   const bool vec4 = (width & 3) == 0;
-  unsigned char *scratch = s_scr + (size_t)wave * kWaveScratchBytes;
+  unsigned char *scratch = s_scr + (size_t)wave * kBandScratchBytes;
   const int nchunks = (F + 63) >> 6;
-  for (int band = band0; band < band1; band++) {
+  for (int band = band_first; band < nbands; band += band_step) {
     const int lo = band * R, hi = min(height, lo + R) - 1, rows = hi - lo + 1;
     const int npix = rows * width;
     float *gout = zimg + (size_t)lo * width;
@@ -441,13 +468,13 @@ tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, in
       else atomicMin(reinterpret_cast<int *>(cell), (int)bits);
     };
     {
-      // equal shares of the list, 32 faces at a time.  (Drawing batches of 16 from a counter instead -- a face costs what
+      // equal shares of the list, 16 faces at a time.  (Drawing batches of 16 from a counter instead -- a face costs what
       // its box holds -- measured 1022 us against 634 for 256 crops: a batch costs its LATENCY, the gather of its
       // vertices and the set-up's chain of divisions, whatever it holds; fewer, fuller batches win.)
       const int n = s_npend;
       const int from = (int)(((long long)wave * n) / kBandWaves), to = (int)(((long long)(wave + 1) * n) / kBandWaves);
-      for (int at = from; at < to; at += kFacesPerWave) {
-        const int count = min(kFacesPerWave, to - at);
+      for (int at = from; at < to; at += kBandFaces) {
+        const int count = min(kBandFaces, to - at);
         float f[9];
         const bool have = lane < count;
         if (have) {
@@ -459,7 +486,7 @@ tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, in
         FaceSetup fs = face_setup(f, width, height);
         fs.r_lo = max(fs.r_lo, lo);
         fs.r_hi = min(fs.r_hi, hi);
-        raster_batch(fs, have, lane, scratch, height, sink);
+        raster_batch<kBandFaces, true>(fs, have, lane, scratch, height, sink);
       }
     }
     __syncthreads();
@@ -555,29 +582,46 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
   // The band kernel: the row ranges of all faces (4 F bytes) + sixteen wave scratches + a band of at least 8 rows
   // in one CU's LDS, 16-bit face numbers and row numbers.
   constexpr int kLds = 160 * 1024;
-  const long long fixed = (long long)((F + 7) & ~7) * 6 + (long long)kBandWaves * kWaveScratchBytes + 4096;   // (+ the static arrays: band counters, pending faces)
-  long long R = (kLds - fixed) / (4LL * W);
-  if (R > H) R = H;
-  // Which kernel: the band kernel has ONE 16-wave workgroup per CU (its LDS) against eight waves per SIMD for the
-  // atomic kernel, and the work is chains of IEEE divisions -- latency that only more waves hide.  Measured on the hand
-  // mesh @640x640 (tools/exp_tri_band.py): 1 crop 54 us against 78, 48 crops 274 against 170, 256 crops 515 against
-  // 480.  So: bands for a handful of crops (where a fill pass over the image and the L2 round trips of its atomics
-  // are most of the time), the atomic kernel otherwise; SHR_TUNE_TRI_BAND forces either.
-  const bool want_band = g_tri_band > 0 || (g_tri_band < 0 && B <= 4);
-  if (want_band && F > 0 && F <= 65535 && R >= 8 && H <= 65535 && W <= 65535) {
-    if (g_tri_band > 0 && g_tri_band < R) R = g_tri_band;          // tests: that many rows per band
-    const int nbands = (int)((H + R - 1) / R);
-    // segments of bands: one workgroup per crop when there is a crop per CU, more when there are few crops
+  const long long fixed = (long long)((F + 7) & ~7) * 6 + (long long)kBandWaves * kBandScratchBytes + 4096;   // (+ the static arrays: band counters, pending faces)
+  long long Rmax = (kLds - fixed) / (4LL * W);
+  if (Rmax > H) Rmax = H;
+  // Which kernel: the band kernel wherever it fits (round 5, after raster_batch's level walk: hand mesh @640x640,
+  // tools/exp_tri_band.py -- 1 crop 20.8 us against 78 for the atomic kernel, 48 crops 142 against 173, 256 crops 348
+  // against 461); the atomic kernel for what does not (more than 65535 faces, rows too wide for 8 of them in LDS).
+  // SHR_TUNE_TRI_BAND: 0 forces the atomic kernel, n > 0 bands of at most n rows.
+  if (g_tri_band != 0 && F > 0 && F <= 65535 && Rmax >= 8 && H <= 65535 && W <= 65535) {
     static int cus = 0;
     if (cus == 0) {
       int d = 0, v = 0;
       cus = (hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && v > 0) ? v : 256;
     }
-    int segs = B >= cus ? 1 : (cus + B - 1) / B;
+    // Rows per band and workgroups per crop.  A band costs a fixed part -- one batch's latency: the gather of its faces,
+    // the set-up's chain of divisions, three barriers -- worth ~24 rows of raster and stream-out (256 crops: 8.8 us per
+    // band of 8 rows, 13.4 per band of 25), so: as few bands per WORKGROUP as possible, with one workgroup per CU at most
+    // (a workgroup has the CU's LDS: a second one per CU waits for the first).  Many crops: the tallest band, one
+    // workgroup per crop.  Few crops: cus / B workgroups per crop and the band height that leaves each the fewest rows.
+    int R = (int)Rmax, segs = 1;
+    if (g_tri_band > 0) {
+      if (g_tri_band < R) R = g_tri_band;
+      const int nb = (H + R - 1) / R;
+      segs = B >= cus ? 1 : (cus + B - 1) / B;
+      if (segs > nb) segs = nb;
+    } else {
+      long long best = -1;
+      const int lo = (int)(Rmax < 8 ? Rmax : 8);
+      for (int r = (int)Rmax; r >= lo; r--) {
+        const int nb = (H + r - 1) / r;
+        int sg = B >= cus ? 1 : cus / B;
+        if (sg > nb) sg = nb;
+        const int per = (nb + sg - 1) / sg;
+        const long long cost = (long long)per * (24 + r);
+        if (best < 0 || cost < best) { best = cost; R = r; segs = sg; }
+      }
+    }
+    const int nbands = (H + R - 1) / R;
     if (segs > nbands) segs = nbands;
-    const int per = (nbands + segs - 1) / segs;
-    segs = (nbands + per - 1) / per;
-    const size_t lds = (size_t)((F + 7) & ~7) * 6 + (size_t)R * W * 4 + (size_t)kBandWaves * kWaveScratchBytes;
+    if (segs > 65535) segs = 65535;
+    const size_t lds = (size_t)((F + 7) & ~7) * 6 + (size_t)R * W * 4 + (size_t)kBandWaves * kBandScratchBytes;
     static bool attr_done[2] = {false, false};
     auto launch = [&](auto kernel, int which) -> int {
       if (!attr_done[which]) {
@@ -586,10 +630,10 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
         attr_done[which] = true;
       }
       hipLaunchKernelGGL(kernel, dim3((unsigned)B, (unsigned)segs), dim3(kBandWaves * 64), lds, s, src, faces, B, F, NV, W, H,
-                         depth, (int)R, nbands, per);
+                         depth, R, nbands);
       return (int)hipGetLastError();
     };
-    if (B <= 65535 * 32767) return indexed ? launch(tri_band_kernel<true>, 0) : launch(tri_band_kernel<false>, 1);
+    return indexed ? launch(tri_band_kernel<true>, 0) : launch(tri_band_kernel<false>, 1);
   }
   const size_t n = (size_t)B * W * H;
   uint32_t *z = reinterpret_cast<uint32_t *>(depth);

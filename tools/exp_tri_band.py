@@ -13,12 +13,12 @@ fk = HandTransformationMat([b["offset_matrix"].astype("float32") for b in mesh["
 dr = DepthRender(mesh, 128).to(dev)
 stream = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(stream):
-    for B in (256, 48, 1):
+    for B in [int(v) for v in os.environ.get("BS", "256,48,1").split(",")]:
         with torch.no_grad():
             verts = dr.lbs(fk(sample_poses(B, seed=1).to(dev)), dr.camera, None)
             fv = verts[:, dr.rasterizer.faces, 0:3].reshape(B, -1, 3, 3).contiguous()
         outs = []
-        for band in (0, -1, 32, 16):
+        for band in [int(v) for v in os.environ.get("BANDS", "0,-1,32,16").split(",")]:
             ops.set_tuning(ops.TUNE_TRI_BAND, band)
             outs.append(depth_rasterization.forward(640, 640, fv))
             t = bench.mean_launch_us(lambda _s: depth_rasterization.forward(640, 640, fv), stream, 10, 3, 3)
