@@ -597,9 +597,13 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
     }
     // Rows per band and workgroups per crop.  A band costs a fixed part -- one batch's latency: the gather of its faces,
     // the set-up's chain of divisions, three barriers -- worth ~24 rows of raster and stream-out (256 crops: 8.8 us per
-    // band of 8 rows, 13.4 per band of 25), so: as few bands per WORKGROUP as possible, with one workgroup per CU at most
-    // (a workgroup has the CU's LDS: a second one per CU waits for the first).  Many crops: the tallest band, one
-    // workgroup per crop.  Few crops: cus / B workgroups per crop and the band height that leaves each the fewest rows.
+    // band of 8 rows, 13.4 per band of 25), a workgroup its pass over all faces' row ranges (~10 rows' worth), and a
+    // workgroup has the CU's LDS: what does not fit the CUs at once waits for a CU.  The plan minimises
+    //     rounds x (10 + bands per workgroup x (24 + R)),   rounds = 1 if B x segs <= cus, else B x segs / cus + 1/2
+    // over R and the workgroups per crop (their bands interleaved): a crop per CU -> the tallest band, one workgroup
+    // per crop; few crops -> cus / B workgroups per crop at the height that leaves each the fewest rows; somewhat more
+    // crops than CUs -> several workgroups per crop again, so that the second round is not a whole crop long (288
+    // crops: 517 -> see EXPERIMENTS R3c).
     int R = (int)Rmax, segs = 1;
     if (g_tri_band > 0) {
       if (g_tri_band < R) R = g_tri_band;
@@ -607,15 +611,23 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
       segs = B >= cus ? 1 : (cus + B - 1) / B;
       if (segs > nb) segs = nb;
     } else {
-      long long best = -1;
+      float best = -1.f;
       const int lo = (int)(Rmax < 8 ? Rmax : 8);
       for (int r = (int)Rmax; r >= lo; r--) {
         const int nb = (H + r - 1) / r;
-        int sg = B >= cus ? 1 : cus / B;
-        if (sg > nb) sg = nb;
-        const int per = (nb + sg - 1) / sg;
-        const long long cost = (long long)per * (24 + r);
-        if (best < 0 || cost < best) { best = cost; R = r; segs = sg; }
+        // far fewer crops than CUs: cus / B workgroups per crop, all resident at once; from half a crop per CU on: up to
+        // 8 per crop (200 crops as 200 workgroups leave 56 CUs idle for a whole crop's time)
+        int sg_lo = B >= cus ? 1 : cus / B, sg_hi = 2 * B > cus ? 8 : cus / B;
+        if (sg_lo > nb) sg_lo = nb;
+        if (sg_hi > nb) sg_hi = nb;
+        for (int sg = sg_lo; sg <= sg_hi; sg++) {
+          const int per = (nb + sg - 1) / sg;
+          if (sg > sg_lo && (nb + sg - 2) / (sg - 1) == per) continue;      // (one workgroup fewer does the same)
+          const float load = (float)B * (float)sg / (float)cus;
+          const float rounds = load <= 1.f ? 1.f : load + 0.5f;
+          const float cost = rounds * (10.f + (float)per * (float)(24 + r));
+          if (best < 0.f || cost < best) { best = cost; R = r; segs = sg; }
+        }
       }
     }
     const int nbands = (H + R - 1) / R;
