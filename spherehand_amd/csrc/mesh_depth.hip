@@ -20,6 +20,8 @@
 // Zero-weight slots are not rasterized (0 * finite = 0 contributes nothing); the only
 // input on which this differs from the reference chain is a raster value of -inf next to a
 // sampled pixel (an exactly zero 1/z denominator), where the reference's 0 * -inf is NaN.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace shr {
@@ -31,14 +33,14 @@ __device__ unsigned long long mesh_tl[256 * 16 * 16];
 #define MESH_STAMP(slot)                                                                                      \
   do {                                                                                                        \
     asm volatile("" ::: "memory");   /* (what precedes the stamp in the source is issued in front of it) */      \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y < 256)                                       \
-      mesh_tl[(blockIdx.y * 16 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_amdgcn_s_memtime();            \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x * gridDim.y + blockIdx.y < 256 && (gridDim.y == 1 || blockIdx.x == 0)) \
+      mesh_tl[((blockIdx.x * gridDim.y + blockIdx.y) * 16 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
     asm volatile("" ::: "memory");                                                                            \
   } while (0)
 #define MESH_NOTE(slot, value)                                                                                \
   do {                                                                                                        \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y < 256)                                       \
-      mesh_tl[(blockIdx.y * 16 + (threadIdx.x >> 6)) * 16 + (slot)] = (unsigned long long)(value);            \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x * gridDim.y + blockIdx.y < 256 && (gridDim.y == 1 || blockIdx.x == 0)) \
+      mesh_tl[((blockIdx.x * gridDim.y + blockIdx.y) * 16 + (threadIdx.x >> 6)) * 16 + (slot)] = (unsigned long long)(value); \
   } while (0)
 #else
 #define MESH_STAMP(slot) do {} while (0)
@@ -83,16 +85,9 @@ struct FaceSetup {
   bool live;
 };
 
-__device__ __forceinline__ FaceSetup face_setup_sorted(const float4 *__restrict__ verts, const int *__restrict__ faces,
-                                                       int f, int src) {
+__device__ __forceinline__ FaceSetup face_setup_from(const float (&fv)[9], int src) {
   FaceSetup s;
   s.live = false;
-  float fv[9];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const float4 v = verts[faces[f * 3 + k]];
-    fv[3 * k] = v.x; fv[3 * k + 1] = v.y; fv[3 * k + 2] = v.z;
-  }
   if ((fv[7] - fv[1]) * (fv[3] - fv[0]) < (fv[4] - fv[1]) * (fv[6] - fv[0])) return s;
   int p0, p2;
   if (fv[0] < fv[3]) { p0 = (fv[6] < fv[0]) ? 2 : 0; p2 = (fv[3] < fv[6]) ? 2 : 1; }
@@ -124,6 +119,17 @@ __device__ __forceinline__ FaceSetup face_setup_sorted(const float4 *__restrict_
   s.r_hi = wild ? src - 1 : min(src - 1, max(0, (int)floorf(yhi + yeps)));
   s.live = true;
   return s;
+}
+
+__device__ __forceinline__ FaceSetup face_setup_sorted(const float4 *__restrict__ verts, const int *__restrict__ faces,
+                                                       int f, int src) {
+  float fv[9];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float4 v = verts[faces[f * 3 + k]];
+    fv[3 * k] = v.x; fv[3 * k + 1] = v.y; fv[3 * k + 2] = v.z;
+  }
+  return face_setup_from(fv, src);
 }
 
 constexpr int kMeshQueue = 3584;   // work items per round (14 KB next to the 66-KB slot array)
@@ -451,6 +457,254 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
   MESH_STAMP(7);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The LATTICE kernel (round 5): integer resize ratios whose sampled source pixels form a lattice of at most 128 x 128
+// (S = 128 from 640: every fifth row and column; S = 64: the pairs 10 d + 4, 10 d + 5), one workgroup per crop with the
+// whole lattice as integer keys in LDS.  It is the triangle band kernel's structure (tri_raster.hip) on the lattice:
+//   1  lanes = faces (all of them, four per thread): gather, the reference's culls, "does the box hold a lattice column
+//      and a lattice row" -> the numbers of the surviving faces, compacted into one list (half of a hand's 3 382);
+//   2  equal shares of the list for the 16 waves, 32 faces at a time: lanes = faces for the set-up (sort, inverse
+//      barycentric matrix, slopes: face_row) parked in the wave's own LDS rows; lanes = the batch's lattice COLUMNS for
+//      the span of rows (.cu:72-90) and the lattice rows inside it; those pixels queued level by level (level t = t-th
+//      lattice row of every column that has one, compacted with a ballot); lanes = queued pixels, 64 at a time, every
+//      lane busy, for the seven IEEE divisions of .cu:97-110 and the LDS minimum;
+//   3  the tile kernel's epilogue: clamp, ATen's bilinear formula, 16-byte stores.
+// mesh_depth_kernel (below this size: its tiles; any non-integer ratio) walks (face, column) items with a row loop per
+// lane -- 68 batches x 3-4 iterations of ~140 instructions for a crop's ~4 800 sampled pixels, three lanes in ten busy
+// (EXPERIMENTS R4) -- and rebuilds the faces its 768-row table cannot hold; here every face is set up once and the
+// division chains run on full waves.  Same pixels, same arithmetic per pixel, integer minima: bit-identical images.
+constexpr int kLatWaves = 16;
+constexpr int kLatFaces = 32;                                   // faces per batch (5 bits in a queue entry)
+constexpr int kLatQueue = 128;                                  // queued pixels per wave (4-byte entries)
+constexpr int kLatScratchBytes = kLatFaces * (int)sizeof(FaceRow) + kLatQueue * 4 + 64;   // rows | queue | start marks: 3648
+constexpr int kLatMax = 128;                                    // lattice rows / columns (7 bits each in a queue entry)
+
+__host__ __device__ inline size_t lattice_lds_bytes(int L, int F) {
+  return (size_t)L * (L + 1) * 4 + (size_t)((F + 7) & ~7) * 2 + (size_t)kLatWaves * kLatScratchBytes;
+}
+
+template <int SL>
+__global__ void __launch_bounds__(kLatWaves * 64)
+mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__ faces, int NV, int F, int src, int S,
+                    float clamp_max, float *__restrict__ depth) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lat_smem[];
+  const int L = SL * S, LP = L + 1;
+  uint32_t *s_z = reinterpret_cast<uint32_t *>(lat_smem);                                   // [L][L + 1] keys
+  uint16_t *s_surv = reinterpret_cast<uint16_t *>(lat_smem + (size_t)L * LP * 4);        // the surviving faces' numbers
+  unsigned char *s_scr = lat_smem + (size_t)L * LP * 4 + (size_t)((F + 7) & ~7) * 2;
+  __shared__ int s_nsurv;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float4 *verts = vertices + (size_t)b * NV;
+  MESH_STAMP(0);
+  if (tid == 0) s_nsurv = 0;
+  for (int i = tid; i < L * LP; i += kLatWaves * 64) s_z[i] = 0x447A0000u ^ 0x80000000u;  // 1000.0f
+
+  // lattice index <-> source index.  SL = 1 (odd ratio R): c -> R c + (R - 1) / 2.  SL = 2 (even R): c = 2 d + s ->
+  // R d + R / 2 - 1 + s.  first_lat(lo) = the first lattice index whose source index is >= lo, last_lat(hi) = the last
+  // one whose source index is <= hi (-1: none); floor(x / R) through a float product as in mesh_depth_kernel.
+  const int ratio = src / S, base = SL == 1 ? (ratio - 1) >> 1 : (ratio >> 1) - 1;
+  const float rcp_r = 1.0f / (float)ratio;
+  auto fdiv = [&](int x) { return (int)floorf(((float)x + 0.5f) * rcp_r); };   // floor(x / R), |x| < 2^15
+  auto src_of = [&](int c) { return SL == 1 ? ratio * c + base : ratio * (c >> 1) + base + (c & 1); };
+  auto first_lat = [&](int lo) {
+    const int a = lo - base;
+    if (a <= 0) return 0;
+    const int d = fdiv(a), rem = a - d * ratio;
+    if (SL == 1) return rem == 0 ? d : d + 1;
+    return rem == 0 ? 2 * d : (rem == 1 ? 2 * d + 1 : 2 * d + 2);
+  };
+  auto last_lat = [&](int hi) {
+    const int a = hi - base;
+    if (a < 0) return -1;
+    const int d = fdiv(a), rem = a - d * ratio;
+    const int c = SL == 1 ? d : (rem >= 1 ? 2 * d + 1 : 2 * d);
+    return min(c, L - 1);
+  };
+  __syncthreads();
+
+  // ---- 1. culls; the survivors' numbers ---------------------------------------------------------------------------
+  for (int f0 = 0; f0 < F; f0 += kLatWaves * 64 * kMeshFaces) {
+    bool keep[kMeshFaces];
+#pragma unroll
+    for (int k = 0; k < kMeshFaces; k++) {
+      const int f = f0 + k * kLatWaves * 64 + tid;
+      keep[k] = false;
+      if (f < F) {
+        const FaceSetup fs = face_setup_sorted(verts, faces, f, src);
+        keep[k] = fs.live && first_lat(fs.xi_min) <= last_lat(fs.xi_max) && first_lat(fs.r_lo) <= last_lat(fs.r_hi);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kMeshFaces; k++) {
+      const unsigned long long m = __ballot(keep[k]);
+      if (m == 0ull) continue;
+      int at = 0;
+      if (lane == 0) at = atomicAdd(&s_nsurv, __popcll(m));
+      at = __builtin_amdgcn_readfirstlane(at);
+      if (keep[k])
+        s_surv[at + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+            (uint16_t)(f0 + k * kLatWaves * 64 + tid);
+    }
+  }
+  MESH_STAMP(1);
+  __syncthreads();
+  MESH_STAMP(2);
+
+  // ---- 2. the survivors, 32 at a time per wave ------------------------------------------------------------------------
+  {
+    FaceRow *s_face = reinterpret_cast<FaceRow *>(s_scr + (size_t)wave * kLatScratchBytes);
+    uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_scr + (size_t)wave * kLatScratchBytes + kLatFaces * sizeof(FaceRow));
+    unsigned char *s_mark = s_scr + (size_t)wave * kLatScratchBytes + kLatFaces * sizeof(FaceRow) + kLatQueue * 4;
+    const int n = s_nsurv;
+    MESH_NOTE(9, n);
+    // batches of 32 survivors dealt round robin (face numbers cluster: a wave's own contiguous share was all palm or all
+    // finger tips, and the waves finished between 21 and 30 us).  Measured on top and not kept: batches drawn from a
+    // counter with the next batch's vertices requested a batch ahead (corner numbers in the list instead of face
+    // numbers: one round trip) -- 29.9 -> 31.6 us: the kernel is VALU-bound (82 % busy), not waiting for its gathers.
+    const int from = wave * kLatFaces;
+    for (int at = from; at < n; at += kLatWaves * kLatFaces) {
+      if (at == from + kLatWaves * kLatFaces) MESH_STAMP(5);   // this wave's second batch starts
+      const int count = min(kLatFaces, n - at);
+      int ncol = 0, c_lo = 0;
+      FaceRow row;
+      if (lane < count) {
+        const FaceSetup fs = face_setup_sorted(verts, faces, (int)s_surv[at + lane], src);
+        row = face_row(fs);
+        c_lo = first_lat(fs.xi_min);
+        ncol = max(0, last_lat(fs.xi_max) - c_lo + 1);
+      }
+      const int fincl = wave_scan_incl(ncol, lane);            // lanes = faces: the face's lattice columns end here
+      const int ncols = __builtin_amdgcn_readlane(fincl, 63);
+      if (lane < count) {
+        row.pad[0] = c_lo - (fincl - ncol);                    // column item k of the face is lattice column k + this
+        s_face[lane] = row;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);                      // this wave's LDS writes (rows and queue are its own)
+      __builtin_amdgcn_wave_barrier();
+      if (at == from) MESH_STAMP(3);   // this wave's first batch: its faces are set up
+
+      int qn = 0;   // queued pixels (wave-uniform)
+      auto drain = [&](int take) {
+        if (lane < take) {
+          const uint32_t e = s_queue[qn - take + lane];
+          const int cx = (int)((e >> 5) & 127u), cy = (int)(e >> 12);
+          const float4 *r4 = reinterpret_cast<const float4 *>(&s_face[e & 31u]);
+          const float4 f0v = r4[0], f1v = r4[1], f2v = r4[2], zv = r4[4];
+          const float fi[9] = {f0v.x, f0v.y, f0v.z, f0v.w, f1v.x, f1v.y, f1v.z, f1v.w, f2v.x};
+          // ---- pixel (.cu:97-110) ----------------------------------------------------
+          const float xf = (float)src_of(cx), yf = (float)src_of(cy);
+          float w[3], w_sum = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            w[k] = (fi[3 * k] * xf + fi[3 * k + 1] * yf) + fi[3 * k + 2];
+            w[k] = fminf(fmaxf(w[k], 0.f), 1.f);
+            w_sum += w[k];
+          }
+#pragma unroll
+          for (int k = 0; k < 3; k++) w[k] = w[k] / w_sum;
+          const float zp = 1.0f / ((w[0] / zv.x + w[1] / zv.y) + w[2] / zv.z);
+          if (zp == zp) atomicMin(&s_z[cy * LP + cx], mkey(zp));
+        }
+        qn -= take;
+      };
+      for (int k0 = 0; k0 < ncols; k0 += 64) {
+        const int k = k0 + lane;
+        const bool colv = k < ncols;
+        // the face of column item k: the faces whose first column lies in this chunk mark it (their number + 1, the
+        // numbers rise with the position), a max-scan over the lanes spreads the marks, and the face that covers the
+        // chunk's first column is one ballot -- a face holds ~3 lattice columns, nearly every run ends inside the chunk
+        // (run_of's one-by-one loop over those ends was 1 000 cycles per chunk)
+        s_mark[lane] = 0;
+        const int start = fincl - ncol;
+        if (ncol > 0 && start >= k0 && start < k0 + 64) s_mark[start - k0] = (unsigned char)(lane + 1);
+        const int before = __popcll(__ballot(ncol > 0 && start < k0)) ;   // faces (with columns) that start before the chunk
+        const int cover = before == 0 ? 0 : (int)(63 - __builtin_clzll(__ballot(ncol > 0 && start < k0)));   // the last of them
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        int mk = (int)s_mark[lane];
+        mk = max(mk, __builtin_amdgcn_update_dpp(0, mk, 0x111, 0xF, 0xF, false));   // row_shr:1
+        mk = max(mk, __builtin_amdgcn_update_dpp(0, mk, 0x112, 0xF, 0xF, false));   // row_shr:2
+        mk = max(mk, __builtin_amdgcn_update_dpp(0, mk, 0x114, 0xF, 0xF, false));   // row_shr:4
+        mk = max(mk, __builtin_amdgcn_update_dpp(0, mk, 0x118, 0xF, 0xF, false));   // row_shr:8
+        {
+          const int m0 = __builtin_amdgcn_readlane(mk, 15), m1 = __builtin_amdgcn_readlane(mk, 31), m2 = __builtin_amdgcn_readlane(mk, 47);
+          const int rowi = lane >> 4;
+          mk = max(mk, rowi >= 1 ? m0 : 0);
+          mk = max(mk, rowi >= 2 ? m1 : 0);
+          mk = max(mk, rowi >= 3 ? m2 : 0);
+        }
+        const int face = mk > 0 ? mk - 1 : cover;
+        __builtin_amdgcn_wave_barrier();   // (the marks are rewritten by the next chunk)
+        const float4 *r4 = reinterpret_cast<const float4 *>(&s_face[face]);
+        const float4 sl = r4[2], pv = r4[3], iv = r4[5];       // . s01 s12 s02 | x0 y0 x1 y1 | yr flags pad0 pad1
+        const int flags = __float_as_int(iv.y);
+        const int cx = k + __float_as_int(iv.z);
+        // ---- column span (.cu:72-90; the slopes are the face's) --------------------------
+        const float xf = (float)src_of(cx);
+        float yi1;
+        if (xf <= pv.z) yi1 = (flags & 1) ? sl.y * (xf - pv.x) + pv.y : pv.w;
+        else yi1 = (flags & 2) ? sl.z * (xf - pv.z) + pv.w : pv.w;
+        const float yi2 = sl.w * (xf - pv.x) + pv.y;
+        const int yi_min = m_cvt_rz_sat(fmaxf(0.f, ceilf(fminf(yi1, yi2))));
+        const int yi_max = m_cvt_rz_sat(fminf(fmaxf(yi1, yi2), (float)src - 1.f));
+        int cy_lo = 0, cnt = 0;
+        if (colv && yi_min <= yi_max) {
+          cy_lo = first_lat(yi_min);
+          cnt = max(0, last_lat(yi_max) - cy_lo + 1);
+        }
+        const uint32_t packed = (uint32_t)face | ((uint32_t)cx << 5) | ((uint32_t)cy_lo << 12);
+        for (int t = 0;; t++) {
+          const bool on = cnt > t;
+          const unsigned long long m = __ballot(on);
+          if (m == 0ull) break;
+          if (on)
+            s_queue[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                packed + ((uint32_t)t << 12);
+          qn += __popcll(m);
+          if (qn >= 64) drain(64);
+        }
+      }
+      if (qn > 0) drain(qn);
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // the queue's and the rows' last reads: the next batch rewrites them
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  MESH_STAMP(6);
+  __syncthreads();
+
+  // ---- 3. clamp + bilinear (mesh/render.py:286, :311; ATen upsample_bilinear2d) -----------------------------------
+  float *out = depth + (size_t)b * S * S;
+  if (SL == 1 && (S & 3) == 0) {
+    typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+    for (int i = tid; i < S * S / 4; i += kLatWaves * 64) {
+      const int oy = i / (S / 4), ox = (i - oy * (S / 4)) * 4;
+      v4u_t v;
+#pragma unroll
+      for (int c = 0; c < 4; c++) v[c] = __float_as_uint(fminf(mkey_inv(s_z[oy * LP + ox + c]), clamp_max));
+      float *dst = out + (size_t)oy * S + ox;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+    }
+  } else {
+    const float scale = (float)src / (float)S;
+    for (int i = tid; i < S * S; i += kLatWaves * 64) {
+      const int oy = i / S, ox = i - oy * S;
+      if (SL == 1) {   // weights are exactly (1, 0)
+        out[i] = fminf(mkey_inv(s_z[oy * LP + ox]), clamp_max);
+      } else {
+        const Lin lx = lin_index(ox, scale, src), ly = lin_index(oy, scale, src);
+        float v[2][2];
+#pragma unroll
+        for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+          for (int sx = 0; sx < 2; sx++) v[sy][sx] = fminf(mkey_inv(s_z[(2 * oy + sy) * LP + 2 * ox + sx]), clamp_max);
+        out[i] = ly.l0 * (lx.l0 * v[0][0] + lx.l1 * v[0][1]) + ly.l1 * (lx.l0 * v[1][0] + lx.l1 * v[1][1]);
+      }
+    }
+  }
+  MESH_STAMP(7);
+}
+
 }  // namespace shr
 
 #ifdef MESH_TL
@@ -479,6 +733,24 @@ extern "C" int shr_mesh_depth_fwd(const float *vertices, const int32_t *faces, i
     hipLaunchKernelGGL((mesh_depth_kernel<TO, SL, EX>), dim3((unsigned)(t * t), (unsigned)B), dim3(1024), 0, s,  \
                        v4, faces, NV, F, src_size, S, clamp_max, depth);                                         \
   } while (0)
+  // integer ratio and a lattice of sampled source pixels that fits one workgroup's LDS: the lattice kernel
+  // (SHR_MESH_LATTICE=0 in the environment keeps the tile kernel: tests and tools compare the two)
+  static const bool lattice_off = [] { const char *e = getenv("SHR_MESH_LATTICE"); return e && e[0] == '0'; }();
+  const int SLx = single ? 1 : 2;
+  const size_t lat_lds = lattice_lds_bytes(SLx * S, F);
+  if (!lattice_off && (single || even) && SLx * S <= kLatMax && F > 0 && F <= 65535 && lat_lds <= 160 * 1024 - 512) {
+    static bool attr_done[2] = {false, false};
+    auto launch = [&](auto kernel, int which) -> int {
+      if (!attr_done[which]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (e != hipSuccess) return (int)e;
+        attr_done[which] = true;
+      }
+      hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(kLatWaves * 64), lat_lds, s, v4, faces, NV, F, src_size, S, clamp_max, depth);
+      return (int)hipGetLastError();
+    };
+    return single ? launch(mesh_lattice_kernel<1>, 0) : launch(mesh_lattice_kernel<2>, 1);
+  }
   if (single) {
     if (S > 64) MESH_LAUNCH(128, 1, true); else MESH_LAUNCH(64, 1, true);
   } else if (even) {

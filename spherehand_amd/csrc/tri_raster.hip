@@ -163,30 +163,6 @@ constexpr int kWaveScratchBytes = wave_scratch_bytes(kFacesPerWave);            
 // One batch: lane l < 32 brings face set-up `s` (`have`: the lane holds a face; rows [s.r_lo, s.r_hi] already clipped
 // to what the caller wants rasterized); every pixel inside its column's span goes to sink(xi, yi, depth) once.
 // `scratch`: this wave's kWaveScratchBytes of LDS (16-byte aligned); nothing of it is live between two batches.
-// inclusive prefix sum over the 64 lanes (4 DPP steps inside each row of 16, then the row totals)
-__device__ __forceinline__ int wave_scan_incl(int v, int lane) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
-  const int r0s = __builtin_amdgcn_readlane(v, 15), r1s = __builtin_amdgcn_readlane(v, 31), r2s = __builtin_amdgcn_readlane(v, 47);
-  const int row = lane >> 4;
-  return v + (row >= 1 ? r0s : 0) + (row >= 2 ? r1s : 0) + (row >= 3 ? r2s : 0);
-}
-// Item k of a sequence cut into 64 consecutive runs whose inclusive ends the lanes hold (non-decreasing; `mine`: this
-// lane's run exists): the run that holds k = the number of runs that END at or before k.  Those that end at or
-// before k0 (wave-uniform, <= k) are counted by one ballot, the few that end inside [k0, k0 + 63] one by one.
-__device__ __forceinline__ int run_of(int incl, bool mine, int k0, int k) {
-  int run = __popcll(__ballot(mine && incl <= k0));
-  unsigned long long inner = __ballot(mine && incl > k0 && incl <= k0 + 63);
-  while (inner) {
-    const int c = __builtin_ctzll(inner);
-    inner &= inner - 1;
-    run += (__builtin_amdgcn_readlane(incl, c) <= k) ? 1 : 0;
-  }
-  return run;
-}
-
 // One batch, the reference's own loop structure spread over a wave (.cu:70-111: for each column of the face its span
 // of rows, for each row of the span a pixel):
 //   columns  lanes = the COLUMNS of the batch's faces, 64 at a time whatever face they belong to: the column's span

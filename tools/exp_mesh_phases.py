@@ -1,4 +1,4 @@
-"""Where `mesh_depth_kernel` spends its time: s_memtime stamps of every wave at the phase boundaries (mesh_depth.hip
+"""Where `mesh_depth_kernel` / `mesh_lattice_kernel` (SHR_MESH_LATTICE=0 for the former) spend their time: s_memtime stamps of every wave at the phase boundaries (mesh_depth.hip
 built alone with -DMESH_TL into tools/libmesh_tl.so; the product build carries no stamps).
     python tools/exp_mesh_phases.py build     (anywhere)
     python tools/exp_mesh_phases.py           (GPU box: prints medians over the 256 workgroups of one launch, in us)
@@ -56,11 +56,19 @@ def main():
             rel = (tl - t0[:, :, None]) / (ghz * 1e3)                 # us since then
             med = lambda a: float(np.median(a))
             names = ["entry", "culls done", "scans through", "rows stand", "queue written (round 1)", "B starts (round 1)", "queue empty (last round)", "stored"]
+            lattice = int(items.max()) == 0        # (the lattice kernel leaves the item count alone)
+            if lattice:
+                names = ["entry", "culls done", "survivors listed", "first batch set up", None, "second batch starts", "last batch done", "stored"]
             print("B=%d S=%d: launch %.1f us (stamped build); per workgroup, us since its first wave's entry "
                   "(median over workgroups of the FIRST / LAST wave to get there):" % (B, S, us))
-            print("   work items per crop: median %d, max %d (a round of the queue holds 3584); surviving faces: median %d, max %d (768 rows)"
-                  % (np.median(items), items.max(), np.median(rows), rows.max()))
+            if lattice:
+                print("   mesh_lattice_kernel; surviving faces per crop: median %d, max %d" % (np.median(rows), rows.max()))
+            else:
+                print("   work items per crop: median %d, max %d (a round of the queue holds 3584); surviving faces: median %d, max %d (768 rows)"
+                      % (np.median(items), items.max(), np.median(rows), rows.max()))
             for k in range(8):
+                if names[k] is None:
+                    continue
                 print("   %d %-24s first %6.2f  last %6.2f" % (k, names[k], med(rel[:, :, k].min(axis=1)), med(rel[:, :, k].max(axis=1))))
             sys.stdout.flush()
 
