@@ -474,20 +474,22 @@ mesh_depth_kernel(const float4 *__restrict__ vertices, const int *__restrict__ f
 // lane -- 68 batches x 3-4 iterations of ~140 instructions for a crop's ~4 800 sampled pixels, three lanes in ten busy
 // (EXPERIMENTS R4) -- and rebuilds the faces its 768-row table cannot hold; here every face is set up once and the
 // division chains run on full waves.  Same pixels, same arithmetic per pixel, integer minima: bit-identical images.
-constexpr int kLatWaves = 16;
-constexpr int kLatFaces = 32;                                   // faces per batch (5 bits in a queue entry)
+// WAVES x NF: waves per workgroup x faces per batch.  16 x 32 (3.6 KB of scratch per wave) or 12 x 64 (6.7 KB): full
+// lanes in the set-up and fuller chunks and drains for a quarter fewer waves to hide latency with.
 constexpr int kLatQueue = 128;                                  // queued pixels per wave (4-byte entries)
-constexpr int kLatScratchBytes = kLatFaces * (int)sizeof(FaceRow) + kLatQueue * 4 + 64;   // rows | queue | start marks: 3648
+constexpr int lat_scratch_bytes(int nf) { return nf * (int)sizeof(FaceRow) + kLatQueue * 4 + 64; }   // rows | queue | start marks
 constexpr int kLatMax = 128;                                    // lattice rows / columns (7 bits each in a queue entry)
 
-__host__ __device__ inline size_t lattice_lds_bytes(int L, int F) {
-  return (size_t)L * (L + 1) * 4 + (size_t)((F + 7) & ~7) * 2 + (size_t)kLatWaves * kLatScratchBytes;
+__host__ __device__ inline size_t lattice_lds_bytes(int L, int F, int waves, int nf) {
+  return (size_t)L * (L + 1) * 4 + (size_t)((F + 7) & ~7) * 2 + (size_t)waves * lat_scratch_bytes(nf);
 }
 
-template <int SL>
+template <int SL, int kLatWaves, int kLatFaces>
 __global__ void __launch_bounds__(kLatWaves * 64)
 mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__ faces, int NV, int F, int src, int S,
                     float clamp_max, float *__restrict__ depth) {
+  static_assert(kLatFaces == 32 || kLatFaces == 64, "queue entries: 5 or 6 bits of face");
+  constexpr int kFaceBits = kLatFaces == 64 ? 6 : 5;
   extern __shared__ __attribute__((aligned(16))) unsigned char lat_smem[];
   const int L = SL * S, LP = L + 1;
   uint32_t *s_z = reinterpret_cast<uint32_t *>(lat_smem);                                   // [L][L + 1] keys
@@ -524,10 +526,11 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
   __syncthreads();
 
   // ---- 1. culls; the survivors' numbers ---------------------------------------------------------------------------
-  for (int f0 = 0; f0 < F; f0 += kLatWaves * 64 * kMeshFaces) {
-    bool keep[kMeshFaces];
+  constexpr int kPer = kLatWaves >= 16 ? 4 : 5;   // faces per thread and round: one round for the 3382-face hand mesh
+  for (int f0 = 0; f0 < F; f0 += kLatWaves * 64 * kPer) {
+    bool keep[kPer];
 #pragma unroll
-    for (int k = 0; k < kMeshFaces; k++) {
+    for (int k = 0; k < kPer; k++) {
       const int f = f0 + k * kLatWaves * 64 + tid;
       keep[k] = false;
       if (f < F) {
@@ -536,7 +539,7 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
       }
     }
 #pragma unroll
-    for (int k = 0; k < kMeshFaces; k++) {
+    for (int k = 0; k < kPer; k++) {
       const unsigned long long m = __ballot(keep[k]);
       if (m == 0ull) continue;
       int at = 0;
@@ -553,9 +556,9 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
 
   // ---- 2. the survivors, 32 at a time per wave ------------------------------------------------------------------------
   {
-    FaceRow *s_face = reinterpret_cast<FaceRow *>(s_scr + (size_t)wave * kLatScratchBytes);
-    uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_scr + (size_t)wave * kLatScratchBytes + kLatFaces * sizeof(FaceRow));
-    unsigned char *s_mark = s_scr + (size_t)wave * kLatScratchBytes + kLatFaces * sizeof(FaceRow) + kLatQueue * 4;
+    FaceRow *s_face = reinterpret_cast<FaceRow *>(s_scr + (size_t)wave * lat_scratch_bytes(kLatFaces));
+    uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_scr + (size_t)wave * lat_scratch_bytes(kLatFaces) + kLatFaces * sizeof(FaceRow));
+    unsigned char *s_mark = s_scr + (size_t)wave * lat_scratch_bytes(kLatFaces) + kLatFaces * sizeof(FaceRow) + kLatQueue * 4;
     const int n = s_nsurv;
     MESH_NOTE(9, n);
     // batches of 32 survivors dealt round robin (face numbers cluster: a wave's own contiguous share was all palm or all
@@ -588,8 +591,8 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
       auto drain = [&](int take) {
         if (lane < take) {
           const uint32_t e = s_queue[qn - take + lane];
-          const int cx = (int)((e >> 5) & 127u), cy = (int)(e >> 12);
-          const float4 *r4 = reinterpret_cast<const float4 *>(&s_face[e & 31u]);
+          const int cx = (int)((e >> kFaceBits) & 127u), cy = (int)(e >> (kFaceBits + 7));
+          const float4 *r4 = reinterpret_cast<const float4 *>(&s_face[e & (uint32_t)(kLatFaces - 1)]);
           const float4 f0v = r4[0], f1v = r4[1], f2v = r4[2], zv = r4[4];
           const float fi[9] = {f0v.x, f0v.y, f0v.z, f0v.w, f1v.x, f1v.y, f1v.z, f1v.w, f2v.x};
           // ---- pixel (.cu:97-110) ----------------------------------------------------
@@ -653,14 +656,14 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
           cy_lo = first_lat(yi_min);
           cnt = max(0, last_lat(yi_max) - cy_lo + 1);
         }
-        const uint32_t packed = (uint32_t)face | ((uint32_t)cx << 5) | ((uint32_t)cy_lo << 12);
+        const uint32_t packed = (uint32_t)face | ((uint32_t)cx << kFaceBits) | ((uint32_t)cy_lo << (kFaceBits + 7));
         for (int t = 0;; t++) {
           const bool on = cnt > t;
           const unsigned long long m = __ballot(on);
           if (m == 0ull) break;
           if (on)
             s_queue[qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
-                packed + ((uint32_t)t << 12);
+                packed + ((uint32_t)t << (kFaceBits + 7));
           qn += __popcll(m);
           if (qn >= 64) drain(64);
         }
@@ -735,21 +738,23 @@ extern "C" int shr_mesh_depth_fwd(const float *vertices, const int32_t *faces, i
   } while (0)
   // integer ratio and a lattice of sampled source pixels that fits one workgroup's LDS: the lattice kernel
   // (SHR_MESH_LATTICE=0 in the environment keeps the tile kernel: tests and tools compare the two)
-  static const bool lattice_off = [] { const char *e = getenv("SHR_MESH_LATTICE"); return e && e[0] == '0'; }();
+  static const int lattice_mode = [] { const char *e = getenv("SHR_MESH_LATTICE"); return e ? atoi(e) : 1; }();   // 0: off, 1: 16 x 32, 2: 12 x 64
   const int SLx = single ? 1 : 2;
-  const size_t lat_lds = lattice_lds_bytes(SLx * S, F);
-  if (!lattice_off && (single || even) && SLx * S <= kLatMax && F > 0 && F <= 65535 && lat_lds <= 160 * 1024 - 512) {
-    static bool attr_done[2] = {false, false};
+  const int lw = lattice_mode == 2 ? 12 : 16, lf = lattice_mode == 2 ? 64 : 32;
+  const size_t lat_lds = lattice_lds_bytes(SLx * S, F, lw, lf);
+  if (lattice_mode != 0 && (single || even) && SLx * S <= kLatMax && F > 0 && F <= 65535 && lat_lds <= 160 * 1024 - 512) {
+    static bool attr_done[4] = {false, false, false, false};
     auto launch = [&](auto kernel, int which) -> int {
       if (!attr_done[which]) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         if (e != hipSuccess) return (int)e;
         attr_done[which] = true;
       }
-      hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(kLatWaves * 64), lat_lds, s, v4, faces, NV, F, src_size, S, clamp_max, depth);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(lw * 64), lat_lds, s, v4, faces, NV, F, src_size, S, clamp_max, depth);
       return (int)hipGetLastError();
     };
-    return single ? launch(mesh_lattice_kernel<1>, 0) : launch(mesh_lattice_kernel<2>, 1);
+    if (lattice_mode == 2) return single ? launch(mesh_lattice_kernel<1, 12, 64>, 2) : launch(mesh_lattice_kernel<2, 12, 64>, 3);
+    return single ? launch(mesh_lattice_kernel<1, 16, 32>, 0) : launch(mesh_lattice_kernel<2, 16, 32>, 1);
   }
   if (single) {
     if (S > 64) MESH_LAUNCH(128, 1, true); else MESH_LAUNCH(64, 1, true);
