@@ -367,6 +367,17 @@ int shr_lbs_project(const float *T, int B, int NB, int NV, const int32_t *skin_v
                     int project, float cx, float cy, float fx, float fy,
                     const float *rand_f, float *out, void *stream);
 
+/* DepthRender.forward (mesh/render.py:315-331: LinearBlendSkinning -> OthographicalProjection -> DepthRasterization ->
+ * clamp -> resize) in ONE launch where the resize ratio src_size / S is an integer and the sampled source pixels form a
+ * lattice of at most 128 x 128 (S = 128, 64, 32 from 640): every workgroup skins and projects its crop's vertices into
+ * LDS (shr_lbs_project's arguments and arithmetic, project = 1) and rasterizes from there (shr_mesh_depth_fwd's
+ * arguments).  Any other size: the two launches through vertices_ws[B,NV,4] (16-byte aligned; may be NULL when the
+ * caller knows the fused kernel applies -- SHR_EINVAL otherwise).  The images are the same bits either way. */
+int shr_mesh_render_fwd(const float *T, int B, int NB, int NV, const int32_t *skin_vertex_start,
+                        const int32_t *skin_bone, const float *skin_wv, int right_hand, float cx, float cy,
+                        float fx, float fy, const float *rand_f, const int32_t *faces, int F, int src_size,
+                        int S, float clamp_max, float *vertices_ws, float *depth, void *stream);
+
 /* Key-point skinning -> sphere records -----------------------------------------------------
  * Replaces, inside HandBallPrimitiveRender (mesh/render.py:65-88), the LinearBlendSkinning of the key-points (each
  * bound to ONE bone with weight 1: mesh/pointTransformation.py:39-46 reduces to p = T[bone[j]] @ wv[j], x -> -x for

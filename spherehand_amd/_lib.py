@@ -15,7 +15,7 @@ import torch  # noqa: F401  (device memory, streams: the plumbing this library s
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libspherehand_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -63,6 +63,7 @@ SIGNATURES = {
     "shr_tri_raster_fwd": ([_vp, _i, _i, _i, _i, _vp, _vp], _i),
     "shr_tri_raster_indexed_fwd": ([_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
     "shr_mesh_depth_fwd": ([_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp], _i),
+    "shr_mesh_render_fwd": ([_vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp], _i),
     "shr_lbs_project": ([_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp], _i),
     "shr_fk_fwd": ([_vp, _i, _vp, _vp, _vp, _vp], _i),
     "shr_fk_bwd": ([_vp, _i, _vp, _vp, _vp, _vp, _vp], _i),

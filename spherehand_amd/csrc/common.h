@@ -188,6 +188,23 @@ int tri_set_band(int rows);         // tri_raster.hip: SHR_TUNE_TRI_BAND
 int d2m_compact_check(const float *depth, int M, int H, int W, void *workspace, int **counts);
 int d2m_compact_launch(const float *depth, int M, int H, int W, void *workspace, hipStream_t s);
 
+// Linear blend skinning of one vertex for one sample, shared by lbs_project_kernel (tri_raster.hip) and the fused
+// mesh_lattice_kernel (mesh_depth.hip): one (bone, weighted vertex) entry added to the four rows of the sum, and the
+// sign flip + orthographic camera of mesh/render.py:320-329 on the finished sum.  M = the bone's 4 x 4 matrix.
+__device__ __forceinline__ void lbs_add_entry(float (&acc)[4], const float *M, const float4 q) {
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+    acc[r] += ((M[4 * r] * q.x + M[4 * r + 1] * q.y) + M[4 * r + 2] * q.z) + M[4 * r + 3] * q.w;
+}
+__device__ __forceinline__ float4 lbs_finish(const float (&acc)[4], int right_hand, int project, float cx, float cy, float fx,
+                                             float fy, bool has_rand, float rf) {
+  float a0 = acc[0];
+  if (right_hand) a0 = -a0;
+  if (!project) return make_float4(a0, acc[1], acc[2], acc[3]);
+  if (!has_rand) return make_float4(fx * a0 + cx * acc[3], fy * acc[1] + cy * acc[3], acc[2], acc[3]);
+  return make_float4(a0 * rf * fx + cx, acc[1] * rf * fy + cy, acc[2], 1.0f);
+}
+
 // inclusive prefix sum over the 64 lanes (4 DPP steps inside each row of 16, then the row totals)
 __device__ __forceinline__ int wave_scan_incl(int v, int lane) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);

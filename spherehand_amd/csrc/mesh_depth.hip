@@ -480,26 +480,97 @@ constexpr int kLatQueue = 128;                                  // queued pixels
 constexpr int lat_scratch_bytes(int nf) { return nf * (int)sizeof(FaceRow) + kLatQueue * 4 + 64; }   // rows | queue | start marks
 constexpr int kLatMax = 128;                                    // lattice rows / columns (7 bits each in a queue entry)
 
-__host__ __device__ inline size_t lattice_lds_bytes(int L, int F, int waves, int nf) {
-  return (size_t)L * (L + 1) * 4 + (size_t)((F + 7) & ~7) * 2 + (size_t)waves * lat_scratch_bytes(nf);
+__host__ __device__ inline size_t lattice_lds_bytes(int L, int F, int waves, int nf, int skinned_vertices = 0) {
+  return (((size_t)L * (L + 1) * 4 + 15) & ~(size_t)15) + (size_t)((F + 7) & ~7) * 2 + (size_t)waves * lat_scratch_bytes(nf) +
+         (size_t)skinned_vertices * 16;
 }
+// SKIN (shr_mesh_render_fwd: all of DepthRender.forward in one launch): the crop's vertices are skinned and projected by
+// the workgroup itself into LDS (lbs_project_kernel's arithmetic, common.h) -- no vertex array in HBM, no second launch,
+// and the culls' and the set-up's gathers are LDS reads.
+struct LatticeSkin {
+  const float *T;            // [B][NB][16]
+  const int *vstart, *sbone;
+  const float4 *swv;
+  const float *rand_f;
+  int NB, right_hand;
+  float cx, cy, fx, fy;
+};
 
-template <int SL, int kLatWaves, int kLatFaces>
+template <int SL, int kLatWaves, int kLatFaces, bool SKIN = false>
 __global__ void __launch_bounds__(kLatWaves * 64)
 mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__ faces, int NV, int F, int src, int S,
-                    float clamp_max, float *__restrict__ depth) {
+                    float clamp_max, float *__restrict__ depth, LatticeSkin skin) {
   static_assert(kLatFaces == 32 || kLatFaces == 64, "queue entries: 5 or 6 bits of face");
   constexpr int kFaceBits = kLatFaces == 64 ? 6 : 5;
   extern __shared__ __attribute__((aligned(16))) unsigned char lat_smem[];
   const int L = SL * S, LP = L + 1;
   uint32_t *s_z = reinterpret_cast<uint32_t *>(lat_smem);                                   // [L][L + 1] keys
-  uint16_t *s_surv = reinterpret_cast<uint16_t *>(lat_smem + (size_t)L * LP * 4);        // the surviving faces' numbers
-  unsigned char *s_scr = lat_smem + (size_t)L * LP * 4 + (size_t)((F + 7) & ~7) * 2;
+  const size_t zbytes = ((size_t)L * LP * 4 + 15) & ~(size_t)15;
+  uint16_t *s_surv = reinterpret_cast<uint16_t *>(lat_smem + zbytes);        // the surviving faces' numbers
+  unsigned char *s_scr = lat_smem + zbytes + (size_t)((F + 7) & ~7) * 2;
   __shared__ int s_nsurv;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const float4 *verts = vertices + (size_t)b * NV;
+  float4 *s_verts = reinterpret_cast<float4 *>(s_scr + (size_t)kLatWaves * lat_scratch_bytes(kLatFaces));   // SKIN: [NV]
+  const float4 *verts = SKIN ? s_verts : vertices + (size_t)b * NV;
   MESH_STAMP(0);
   if (tid == 0) s_nsurv = 0;
+  // SKIN: the corners of this thread's faces of the first round of culls are requested now -- they depend on nothing, and
+  // by the time the vertices stand in LDS the culls' only global round trip is over
+  constexpr int kPer = kLatWaves >= 16 ? 4 : 5;   // faces per thread and round of culls: one round for the 3382-face hand mesh
+  int corner[kPer][3];
+  if (SKIN) {
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int f = k * kLatWaves * 64 + tid;
+#pragma unroll
+      for (int c = 0; c < 3; c++) corner[k][c] = f < F ? faces[f * 3 + c] : 0;
+    }
+  }
+  if (SKIN) {
+    // ---- 0. skinning + camera (mesh/render.py:320-329; tri_raster.hip lbs_project_kernel) ----------------------------
+    float *s_T = reinterpret_cast<float *>(s_scr);                     // the bones' matrices, in the scratch nobody uses yet
+    // A chain of round trips -- matrices, entry ranges, entries -- of which only the sum needs the matrices: a thread's
+    // first two vertices' ranges and their first four entries each (a hand vertex has 1 .. 5) are requested before the
+    // barrier that the matrices need.
+    constexpr int kVerts = 2, kAhead = 4;
+    int e0[kVerts], e1[kVerts], bone_a[kVerts][kAhead];
+    float4 q_a[kVerts][kAhead];
+#pragma unroll
+    for (int j = 0; j < kVerts; j++) {
+      const int v = tid + j * kLatWaves * 64;
+      e0[j] = v < NV ? skin.vstart[v] : 0;
+      e1[j] = v < NV ? skin.vstart[v + 1] : 0;
+    }
+    for (int i = tid; i < skin.NB * 16; i += kLatWaves * 64) s_T[i] = skin.T[(size_t)b * skin.NB * 16 + i];
+    const bool has_rand = skin.rand_f != nullptr;
+    const float rf = has_rand ? skin.rand_f[b] : 0.f;
+#pragma unroll
+    for (int j = 0; j < kVerts; j++)
+#pragma unroll
+      for (int k = 0; k < kAhead; k++) {
+        const bool on = e0[j] + k < e1[j];
+        bone_a[j][k] = on ? skin.sbone[e0[j] + k] : 0;
+        q_a[j][k] = on ? skin.swv[e0[j] + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kVerts; j++) {
+      const int v = tid + j * kLatWaves * 64;
+      if (v >= NV) continue;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < kAhead; k++)
+        if (e0[j] + k < e1[j]) lbs_add_entry(acc, s_T + bone_a[j][k] * 16, q_a[j][k]);     // (ascending entries: the reference's sum)
+      for (int e = e0[j] + kAhead; e < e1[j]; e++) lbs_add_entry(acc, s_T + skin.sbone[e] * 16, skin.swv[e]);
+      s_verts[v] = lbs_finish(acc, skin.right_hand, 1, skin.cx, skin.cy, skin.fx, skin.fy, has_rand, rf);
+    }
+    for (int v = tid + kVerts * kLatWaves * 64; v < NV; v += kLatWaves * 64) {                // (meshes above 2 x 1024 vertices)
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int e = skin.vstart[v]; e < skin.vstart[v + 1]; e++) lbs_add_entry(acc, s_T + skin.sbone[e] * 16, skin.swv[e]);
+      s_verts[v] = lbs_finish(acc, skin.right_hand, 1, skin.cx, skin.cy, skin.fx, skin.fy, has_rand, rf);
+    }
+    // (the barrier in front of phase 1 below orders these writes)
+  }
   for (int i = tid; i < L * LP; i += kLatWaves * 64) s_z[i] = 0x447A0000u ^ 0x80000000u;  // 1000.0f
 
   // lattice index <-> source index.  SL = 1 (odd ratio R): c -> R c + (R - 1) / 2.  SL = 2 (even R): c = 2 d + s ->
@@ -512,8 +583,8 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
   auto first_lat = [&](int lo) {
     const int a = lo - base;
     if (a <= 0) return 0;
+    if (SL == 1) return fdiv(a + ratio - 1);                   // ceil(a / R)
     const int d = fdiv(a), rem = a - d * ratio;
-    if (SL == 1) return rem == 0 ? d : d + 1;
     return rem == 0 ? 2 * d : (rem == 1 ? 2 * d + 1 : 2 * d + 2);
   };
   auto last_lat = [&](int hi) {
@@ -523,10 +594,11 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
     const int c = SL == 1 ? d : (rem >= 1 ? 2 * d + 1 : 2 * d);
     return min(c, L - 1);
   };
+  MESH_STAMP(4);   // (SKIN: this wave's vertices are skinned) the lattice is initialised
   __syncthreads();
+  MESH_STAMP(8);   // the culls start
 
   // ---- 1. culls; the survivors' numbers ---------------------------------------------------------------------------
-  constexpr int kPer = kLatWaves >= 16 ? 4 : 5;   // faces per thread and round: one round for the 3382-face hand mesh
   for (int f0 = 0; f0 < F; f0 += kLatWaves * 64 * kPer) {
     bool keep[kPer];
 #pragma unroll
@@ -534,7 +606,14 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
       const int f = f0 + k * kLatWaves * 64 + tid;
       keep[k] = false;
       if (f < F) {
-        const FaceSetup fs = face_setup_sorted(verts, faces, f, src);
+        FaceSetup fs;
+        if (SKIN && f0 == 0) {   // (corners requested at the kernel's start, vertices in LDS)
+          const float4 a = verts[corner[k][0]], bq = verts[corner[k][1]], c = verts[corner[k][2]];
+          const float fv[9] = {a.x, a.y, a.z, bq.x, bq.y, bq.z, c.x, c.y, c.z};
+          fs = face_setup_from(fv, src);
+        } else {
+          fs = face_setup_sorted(verts, faces, f, src);
+        }
         keep[k] = fs.live && first_lat(fs.xi_min) <= last_lat(fs.xi_max) && first_lat(fs.r_lo) <= last_lat(fs.r_hi);
       }
     }
@@ -716,6 +795,39 @@ extern "C" int shr_mesh_debug_timeline(unsigned long long *host_out) {
 }
 #endif
 
+// the lattice kernel's launch (vertices: skinned ones in HBM, or nullptr with `skin` for the fused kernel); returns -1
+// when the problem is not the lattice kernel's (non-integer ratio, lattice above 128 x 128, LDS)
+static int mesh_lattice_launch(const float4 *v4, const shr::LatticeSkin *skin, const int32_t *faces, int B, int NV, int F,
+                               int src_size, int S, float clamp_max, float *depth, hipStream_t s) {
+  using namespace shr;
+  static const int lattice_mode = [] { const char *e = getenv("SHR_MESH_LATTICE"); return e ? atoi(e) : 1; }();   // 0: off, 1: 16 x 32, 2: 12 x 64
+  const bool single = (src_size % S == 0) && (((src_size / S) & 1) == 1);
+  const bool even = (src_size % S == 0) && (((src_size / S) & 1) == 0);
+  const int SLx = single ? 1 : 2;
+  const int lw = lattice_mode == 2 ? 12 : 16, lf = lattice_mode == 2 ? 64 : 32;
+  const size_t lat_lds = lattice_lds_bytes(SLx * S, F, lw, lf, skin ? NV : 0);
+  if (lattice_mode == 0 || !(single || even) || SLx * S > kLatMax || F <= 0 || F > 65535 || lat_lds > 160 * 1024 - 512) return -1;
+  if (skin && (skin->NB * 64 > lw * lat_scratch_bytes(lf))) return -1;     // (the matrices are staged in the scratch)
+  static bool attr_done[8] = {false, false, false, false, false, false, false, false};
+  LatticeSkin sk = {};
+  if (skin) sk = *skin;
+  auto launch = [&](auto kernel, int which) -> int {
+    if (!attr_done[which]) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+      if (e != hipSuccess) return (int)e;
+      attr_done[which] = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(lw * 64), lat_lds, s, v4, faces, NV, F, src_size, S, clamp_max, depth, sk);
+    return (int)hipGetLastError();
+  };
+  if (skin) {
+    if (lattice_mode == 2) return single ? launch(mesh_lattice_kernel<1, 12, 64, true>, 6) : launch(mesh_lattice_kernel<2, 12, 64, true>, 7);
+    return single ? launch(mesh_lattice_kernel<1, 16, 32, true>, 4) : launch(mesh_lattice_kernel<2, 16, 32, true>, 5);
+  }
+  if (lattice_mode == 2) return single ? launch(mesh_lattice_kernel<1, 12, 64>, 2) : launch(mesh_lattice_kernel<2, 12, 64>, 3);
+  return single ? launch(mesh_lattice_kernel<1, 16, 32>, 0) : launch(mesh_lattice_kernel<2, 16, 32>, 1);
+}
+
 extern "C" int shr_mesh_depth_fwd(const float *vertices, const int32_t *faces, int B, int NV, int F, int src_size,
                                   int S, float clamp_max, float *depth, void *stream) {
   using namespace shr;
@@ -736,25 +848,10 @@ extern "C" int shr_mesh_depth_fwd(const float *vertices, const int32_t *faces, i
     hipLaunchKernelGGL((mesh_depth_kernel<TO, SL, EX>), dim3((unsigned)(t * t), (unsigned)B), dim3(1024), 0, s,  \
                        v4, faces, NV, F, src_size, S, clamp_max, depth);                                         \
   } while (0)
-  // integer ratio and a lattice of sampled source pixels that fits one workgroup's LDS: the lattice kernel
-  // (SHR_MESH_LATTICE=0 in the environment keeps the tile kernel: tests and tools compare the two)
-  static const int lattice_mode = [] { const char *e = getenv("SHR_MESH_LATTICE"); return e ? atoi(e) : 1; }();   // 0: off, 1: 16 x 32, 2: 12 x 64
-  const int SLx = single ? 1 : 2;
-  const int lw = lattice_mode == 2 ? 12 : 16, lf = lattice_mode == 2 ? 64 : 32;
-  const size_t lat_lds = lattice_lds_bytes(SLx * S, F, lw, lf);
-  if (lattice_mode != 0 && (single || even) && SLx * S <= kLatMax && F > 0 && F <= 65535 && lat_lds <= 160 * 1024 - 512) {
-    static bool attr_done[4] = {false, false, false, false};
-    auto launch = [&](auto kernel, int which) -> int {
-      if (!attr_done[which]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        if (e != hipSuccess) return (int)e;
-        attr_done[which] = true;
-      }
-      hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(lw * 64), lat_lds, s, v4, faces, NV, F, src_size, S, clamp_max, depth);
-      return (int)hipGetLastError();
-    };
-    if (lattice_mode == 2) return single ? launch(mesh_lattice_kernel<1, 12, 64>, 2) : launch(mesh_lattice_kernel<2, 12, 64>, 3);
-    return single ? launch(mesh_lattice_kernel<1, 16, 32>, 0) : launch(mesh_lattice_kernel<2, 16, 32>, 1);
+  {   // integer ratio and a lattice of sampled source pixels that fits one workgroup's LDS: the lattice kernel
+      // (SHR_MESH_LATTICE=0 in the environment keeps the tile kernel: tests and tools compare the two)
+    const int r = mesh_lattice_launch(v4, nullptr, faces, B, NV, F, src_size, S, clamp_max, depth, s);
+    if (r >= 0) return r;
   }
   if (single) {
     if (S > 64) MESH_LAUNCH(128, 1, true); else MESH_LAUNCH(64, 1, true);
@@ -765,4 +862,34 @@ extern "C" int shr_mesh_depth_fwd(const float *vertices, const int32_t *faces, i
   }
 #undef MESH_LAUNCH
   return (int)hipGetLastError();
+}
+
+/* DepthRender.forward (mesh/render.py:315-331) in ONE launch where the lattice kernel applies: skinning + camera
+ * (shr_lbs_project's arguments, always projecting) + raster + clamp + resize (shr_mesh_depth_fwd's).  Otherwise the two
+ * launches, through `vertices_ws` [B][NV][4] (16-byte aligned; may be NULL only if the caller knows the fused kernel
+ * applies: SHR_EINVAL then).  Same images either way. */
+extern "C" int shr_lbs_project(const float *T, int B, int NB, int NV, const int32_t *skin_vertex_start, const int32_t *skin_bone,
+                               const float *skin_wv, int right_hand, int project, float cx, float cy, float fx, float fy,
+                               const float *rand_f, float *out, void *stream);
+extern "C" int shr_mesh_render_fwd(const float *T, int B, int NB, int NV, const int32_t *skin_vertex_start,
+                                   const int32_t *skin_bone, const float *skin_wv, int right_hand, float cx, float cy,
+                                   float fx, float fy, const float *rand_f, const int32_t *faces, int F, int src_size,
+                                   int S, float clamp_max, float *vertices_ws, float *depth, void *stream) {
+  using namespace shr;
+  if (B == 0) return SHR_OK;
+  if (!T || !skin_vertex_start || !skin_bone || !skin_wv || (!faces && F > 0) || !depth || B < 0 || NB <= 0 || NV <= 0 ||
+      F < 0 || src_size <= 0 || S <= 0)
+    return SHR_EINVAL;
+  if (((uintptr_t)skin_wv & 15u) != 0) return SHR_EINVAL;
+  if (B > 65535 || S > 16384 || src_size > 32767 || S > src_size || F > (1 << 24) || NB > 160) return SHR_ETOOLARGE;
+  LatticeSkin sk;
+  sk.T = T; sk.vstart = skin_vertex_start; sk.sbone = skin_bone; sk.swv = reinterpret_cast<const float4 *>(skin_wv);
+  sk.rand_f = rand_f; sk.NB = NB; sk.right_hand = right_hand; sk.cx = cx; sk.cy = cy; sk.fx = fx; sk.fy = fy;
+  const int r = mesh_lattice_launch(nullptr, &sk, faces, B, NV, F, src_size, S, clamp_max, depth, (hipStream_t)stream);
+  if (r >= 0) return r;
+  if (!vertices_ws) return SHR_EINVAL;
+  const int e = shr_lbs_project(T, B, NB, NV, skin_vertex_start, skin_bone, skin_wv, right_hand, 1, cx, cy, fx, fy, rand_f,
+                                vertices_ws, stream);
+  if (e != SHR_OK) return e;
+  return shr_mesh_depth_fwd(vertices_ws, faces, B, NV, F, src_size, S, clamp_max, depth, stream);
 }

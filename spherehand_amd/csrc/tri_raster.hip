@@ -519,27 +519,14 @@ lbs_project_kernel(const float *__restrict__ T, int B, int NB, int NV, const int
 #pragma unroll
     for (int c = 0; c < kLbsCrops; c++) {
       if (c >= nb) continue;
-      const float *M = s_T + (c * NB + bone) * 16;
-#pragma unroll
-      for (int r = 0; r < 4; r++)
-        acc[c][r] += ((M[4 * r] * q.x + M[4 * r + 1] * q.y) + M[4 * r + 2] * q.z) + M[4 * r + 3] * q.w;
+      lbs_add_entry(acc[c], s_T + (c * NB + bone) * 16, q);
     }
   }
 #pragma unroll
   for (int c = 0; c < kLbsCrops; c++) {
     if (c >= nb) continue;
     const int b = b0 + c;
-    float a0 = acc[c][0];
-    if (right_hand) a0 = -a0;
-    float4 o;
-    if (!project) {
-      o = make_float4(a0, acc[c][1], acc[c][2], acc[c][3]);
-    } else if (!rand_f) {
-      o = make_float4(fx * a0 + cx * acc[c][3], fy * acc[c][1] + cy * acc[c][3], acc[c][2], acc[c][3]);
-    } else {
-      const float rf = rand_f[b];
-      o = make_float4(a0 * rf * fx + cx, acc[c][1] * rf * fy + cy, acc[c][2], 1.0f);
-    }
+    const float4 o = lbs_finish(acc[c], right_hand, project, cx, cy, fx, fy, rand_f != nullptr, rand_f ? rand_f[b] : 0.f);
     // (written through: the vertices are read next by the rasterizer, left dirty they are flushed at the kernel's end)
     const v4u_t t = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(out + (size_t)b * NV + v), "v"(t) : "memory");

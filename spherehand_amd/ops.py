@@ -751,6 +751,33 @@ def mesh_depth_fwd(vertices, faces, out_size, src_size=640, clamp_max=100.0):
     return depth
 
 
+def mesh_render_fwd(T, skin_vertex_start, skin_bone, skin_wv, right_hand, camera, rand_f, faces, out_size, src_size=640,
+                    clamp_max=100.0):
+    """DepthRender.forward as one call (shr_mesh_render_fwd): T [B,NB,4,4] -> depth [B,S,S].  One launch where the fused
+    kernel applies (integer src_size / S, lattice <= 128 x 128); otherwise skinning and raster through a vertex workspace."""
+    _check_input(T, "bone_transformations")
+    _check_input(skin_vertex_start, "skin_vertex_start", torch.int32)
+    _check_input(skin_bone, "skin_bone", torch.int32)
+    _check_input(skin_wv, "skin_wv")
+    _check_input(faces, "faces", torch.int32)
+    if rand_f is not None:
+        _check_input(rand_f, "rand_f")
+    if T.dim() != 4 or T.shape[2:] != (4, 4) or faces.dim() != 2 or faces.shape[1] != 3:
+        raise RuntimeError("T must be [B,NB,4,4] and faces [F,3]")
+    B, NB = T.shape[0], T.shape[1]
+    NV = skin_vertex_start.numel() - 1
+    cx, cy, fx, fy = camera
+    with _on(T.device):
+        depth = torch.empty((B, out_size, out_size), dtype=torch.float32, device=T.device)
+        ws = torch.empty((B, NV, 4), dtype=torch.float32, device=T.device)     # (the caching allocator: no launch; unused
+        #                                                                         when the fused kernel takes the call)
+        _lib.check(_lib.lib().shr_mesh_render_fwd(_ptr(T), B, NB, NV, _ptr(skin_vertex_start), _ptr(skin_bone), _ptr(skin_wv),
+                                                  int(bool(right_hand)), cx, cy, fx, fy, _ptr(rand_f), _ptr(faces),
+                                                  faces.shape[0], src_size, out_size, clamp_max, _ptr(ws), _ptr(depth),
+                                                  _stream()), "shr_mesh_render_fwd")
+    return depth
+
+
 def group_norm_relu_supported(x, num_groups):
     """True when the NHWC GroupNorm+ReLU kernels take this activation (CUDA fp32, channels-last)."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] > 0

@@ -204,6 +204,15 @@ class DepthRender(nn.Module):
         self.rasterizer = DepthRasterization(image_size, image_size, self.lbs.vertex_index[np.asarray(mesh['faces'], np.int64)])
 
     def forward(self, transformation_mats, rand_fx=None):
+        ras = self.rasterizer
+        T = transformation_mats
+        if T.is_cuda and ras.fused and ras.width == ras.height and 2 * ras.width <= 641:
+            # skinning + camera + raster + clamp + resize: one launch where the lattice kernel applies
+            # (shr_mesh_render_fwd), the two launches below through a workspace otherwise -- the same bits
+            return ops.mesh_render_fwd(T.contiguous().float(), self.lbs.skin_vertex_start, self.lbs.skin_bone,
+                                       self.lbs.skin_wv, self.lbs.right_hand, self.camera,
+                                       None if rand_fx is None else rand_fx.contiguous().float(), ras.faces_i32,
+                                       ras.height, 640, 100.0)
         skinned_points = self.lbs(transformation_mats, self.camera, rand_fx)
         return self.rasterizer(skinned_points)
 

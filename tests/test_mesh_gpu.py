@@ -340,3 +340,29 @@ def test_depth_render_on_the_distinct_vertices_equals_the_full_mesh():
             assert torch.equal(vu[:, torch.from_numpy(dr.lbs.vertex_index).cuda()], va)
             want = DepthRasterization(S, S, mesh["faces"]).cuda()(va)
             assert torch.equal(dr(T, rand_f), want)
+
+
+@pytest.mark.parametrize("S", [128, 64, 32, 256, 200])
+def test_mesh_render_one_launch_equals_skinning_then_raster(S):
+    """shr_mesh_render_fwd (DepthRender.forward as one call: the lattice kernel skins its crop's vertices into LDS where
+    it applies -- S = 128 / 64 / 32 from 640 --, two launches through the workspace otherwise) against shr_lbs_project
+    followed by shr_mesh_depth_fwd: the same bits, with and without the random focal factor."""
+    from spherehand_amd import hand_model, ops
+    from spherehand_amd.joint_angle import sample_poses
+    from spherehand_amd.kinematicsTransformation import HandTransformationMat
+    from spherehand_amd.render import DepthRender
+    mesh = hand_model.load_mesh()
+    fk = HandTransformationMat([b["offset_matrix"].astype(np.float32) for b in mesh["bones"]]).cuda()
+    dr = DepthRender(mesh, S).cuda()
+    for B in (1, 37):
+        T = fk(sample_poses(B, seed=11 + B).cuda()).contiguous()
+        rf = torch.rand(B, device="cuda") * 0.3 + 0.85
+        for rand_f in (None, rf):
+            verts = ops.lbs_project(T, dr.lbs.skin_vertex_start, dr.lbs.skin_bone, dr.lbs.skin_wv, dr.lbs.right_hand,
+                                    dr.camera, rand_f)
+            want = ops.mesh_depth_fwd(verts, dr.rasterizer.faces_i32, S, 640, 100.0)
+            got = ops.mesh_render_fwd(T, dr.lbs.skin_vertex_start, dr.lbs.skin_bone, dr.lbs.skin_wv, dr.lbs.right_hand,
+                                      dr.camera, rand_f, dr.rasterizer.faces_i32, S, 640, 100.0)
+            assert torch.equal(got, want)
+            assert torch.equal(dr(T, rand_f), want)
+            assert float((want < 100.0).float().mean()) > 0.02          # a hand is there

@@ -13,7 +13,8 @@ SO = os.path.join(ROOT, "tools", "libmesh_tl%s.so" % os.environ.get("VARIANT", "
 def build():
     from spherehand_amd import build as b
     subprocess.check_call([b.HIPCC] + list(b.FLAGS) + ["-DMESH_TL"] + os.environ.get("XFLAGS", "").split() + ["-I", os.path.join(ROOT, "include"),
-                           "-I", os.path.join(b.PKG, "csrc"), "-o", SO, os.path.join(b.PKG, "csrc", "mesh_depth.hip")])
+                           "-I", os.path.join(b.PKG, "csrc"), "-o", SO, os.path.join(b.PKG, "csrc", "mesh_depth.hip"),
+                           os.path.join(b.PKG, "csrc", "tri_raster.hip")])      # (tri_raster.hip: shr_lbs_project, the fused entry's fallback)
     print(SO)
 
 
@@ -43,6 +44,14 @@ def main():
             NV, F = verts.shape[1], faces.shape[0]
             out = torch.empty(B, S, S, device="cuda")
             fn = lambda s: lib.shr_mesh_depth_fwd(verts.data_ptr(), faces.data_ptr(), B, NV, F, 640, S, 100.0, out.data_ptr(), s)
+            if os.environ.get("FUSED"):      # shr_mesh_render_fwd: skinning inside the lattice kernel
+                l = dr.lbs
+                cx, cy, fx, fy = dr.camera
+                Tc = T.contiguous()
+                lib.shr_mesh_render_fwd.argtypes = [vp, i, i, i, vp, vp, vp, i, f, f, f, f, vp, vp, i, i, i, f, vp, vp, vp]
+                fn = lambda s: lib.shr_mesh_render_fwd(Tc.data_ptr(), B, 17, NV, l.skin_vertex_start.data_ptr(), l.skin_bone.data_ptr(),
+                                                       l.skin_wv.data_ptr(), 1, cx, cy, fx, fy, None, faces.data_ptr(), F, 640, S, 100.0,
+                                                       verts.data_ptr(), out.data_ptr(), s)
             assert fn(stream.cuda_stream) == 0
             us = bench.mean_launch_us(fn, stream, 100, 3, 5, warm_ms=30.0)
             stream.synchronize()
@@ -58,7 +67,7 @@ def main():
             names = ["entry", "culls done", "scans through", "rows stand", "queue written (round 1)", "B starts (round 1)", "queue empty (last round)", "stored"]
             lattice = int(items.max()) == 0        # (the lattice kernel leaves the item count alone)
             if lattice:
-                names = ["entry", "culls done", "survivors listed", "first batch set up", None, "second batch starts", "last batch done", "stored"]
+                names = ["entry", "culls done", "survivors listed", "first batch set up", "lattice initialised (fused: vertices skinned)", "second batch starts", "last batch done", "stored"]
             print("B=%d S=%d: launch %.1f us (stamped build); per workgroup, us since its first wave's entry "
                   "(median over workgroups of the FIRST / LAST wave to get there):" % (B, S, us))
             if lattice:
