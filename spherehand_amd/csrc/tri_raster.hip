@@ -157,7 +157,8 @@ constexpr int kFaceRow = 28;          // x0 y0 x1 y1 x2 y2 s01 s12 | z0 z1 z2 fi
 constexpr int kFacesPerWave = 32;     // 4.5 KB of LDS per wave (rows, queue): eight waves per SIMD fit
 // a wave's private scratch: face rows | pixel queue
 constexpr int kScratchQueueBytes = 128 * 8;                                        // 1024
-constexpr int wave_scratch_bytes(int nf) { return nf * kFaceRow * 4 + kScratchQueueBytes; }
+constexpr int kScratchMarkBytes = 64;                                               // start marks of a chunk's faces
+constexpr int wave_scratch_bytes(int nf) { return nf * kFaceRow * 4 + kScratchQueueBytes + kScratchMarkBytes; }
 constexpr int kWaveScratchBytes = wave_scratch_bytes(kFacesPerWave);               // 3584 + 1024
 
 // One batch: lane l < 32 brings face set-up `s` (`have`: the lane holds a face; rows [s.r_lo, s.r_hi] already clipped
@@ -186,6 +187,7 @@ __device__ __forceinline__ void raster_batch(const FaceSetup &s, bool have, int 
                                              Sink &&sink) {
   float (*s_face)[kFaceRow] = reinterpret_cast<float (*)[kFaceRow]>(scratch);
   uint2 *s_queue = reinterpret_cast<uint2 *>(scratch + NF * kFaceRow * 4);
+  unsigned char *s_mark = scratch + NF * kFaceRow * 4 + kScratchQueueBytes;
   const int bw = s.xi_max - s.xi_min + 1, bh = s.r_hi - s.r_lo + 1;
   const bool alive = have && s.live && bh > 0 && bw > 0;
   const int ncol = alive ? bw : 0;                     // (<= 65535 columns each, 32 faces: 32 bits)
@@ -222,7 +224,31 @@ __device__ __forceinline__ void raster_batch(const FaceSetup &s, bool have, int 
   for (int k0 = 0; k0 < ncols; k0 += 64) {
     const int k = k0 + lane;
     const bool colv = k < ncols;
-    const int face = min(run_of(fincl, lane < NF, k0, k), NF - 1);   // (faces without a column count as runs too)
+    // the face of column item k: the faces whose first column lies in this chunk mark it (their number + 1: the numbers
+    // rise with the position), a max-scan over the lanes spreads the marks, and the face that covers the chunk's first
+    // column is one ballot (run_of's loop over the runs that end inside the chunk: ~5 of them here, ~25 on the lattice
+    // of mesh_depth.hip, where this replaced 1 000 cycles per chunk)
+    s_mark[lane] = 0;
+    const int start = fincl - ncol;
+    const unsigned long long before = __ballot(ncol > 0 && start < k0);
+    if (ncol > 0 && start >= k0 && start < k0 + 64) s_mark[start - k0] = (unsigned char)(lane + 1);
+    const int cover = before ? (int)(63 - __builtin_clzll(before)) : 0;       // the last face that starts before the chunk
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    int mk = (int)s_mark[lane];
+    mk = max(mk, __builtin_amdgcn_update_dpp(0, mk, 0x111, 0xF, 0xF, false));   // row_shr:1
+    mk = max(mk, __builtin_amdgcn_update_dpp(0, mk, 0x112, 0xF, 0xF, false));   // row_shr:2
+    mk = max(mk, __builtin_amdgcn_update_dpp(0, mk, 0x114, 0xF, 0xF, false));   // row_shr:4
+    mk = max(mk, __builtin_amdgcn_update_dpp(0, mk, 0x118, 0xF, 0xF, false));   // row_shr:8
+    {
+      const int m0 = __builtin_amdgcn_readlane(mk, 15), m1 = __builtin_amdgcn_readlane(mk, 31), m2 = __builtin_amdgcn_readlane(mk, 47);
+      const int rowi = lane >> 4;
+      mk = max(mk, rowi >= 1 ? m0 : 0);
+      mk = max(mk, rowi >= 2 ? m1 : 0);
+      mk = max(mk, rowi >= 3 ? m2 : 0);
+    }
+    const int face = mk > 0 ? mk - 1 : cover;
+    __builtin_amdgcn_wave_barrier();   // (the marks are rewritten by the next chunk)
     const float4 *r4 = reinterpret_cast<const float4 *>(s_face[face]);
     const float4 a0 = r4[0], a1 = r4[1], i0 = r4[5];
     const int fl = __float_as_int(s_face[face][24]);
@@ -447,14 +473,17 @@ tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, in
       // equal shares of the list, 16 faces at a time.  (Drawing batches of 16 from a counter instead -- a face costs what
       // its box holds -- measured 1022 us against 634 for 256 crops: a batch costs its LATENCY, the gather of its
       // vertices and the set-up's chain of divisions, whatever it holds; fewer, fuller batches win.)
+      // The shares are STRIDED (wave w takes entries w, w + 16, ...): the list is in face order, neighbouring faces are
+      // neighbours on the hand and of one size -- a contiguous share was all palm or all finger tips, and the band
+      // waited for the wave with the palm.
       const int n = s_npend;
-      const int from = (int)(((long long)wave * n) / kBandWaves), to = (int)(((long long)(wave + 1) * n) / kBandWaves);
-      for (int at = from; at < to; at += kBandFaces) {
-        const int count = min(kBandFaces, to - at);
+      const int mine = (n - wave + kBandWaves - 1) / kBandWaves;            // entries wave, wave + 16, ... below n
+      for (int at = 0; at < mine; at += kBandFaces) {
+        const int count = min(kBandFaces, mine - at);
         float f[9];
         const bool have = lane < count;
         if (have) {
-          load_face<INDEXED>(src, faces, b, F, NV, (int)s_pend[at + lane], f);
+          load_face<INDEXED>(src, faces, b, F, NV, (int)s_pend[wave + kBandWaves * (at + lane)], f);
         } else {
 #pragma unroll
           for (int k = 0; k < 9; k++) f[k] = 0.f;
