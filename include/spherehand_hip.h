@@ -86,6 +86,10 @@ int shr_set_tuning(int key, int value);
  * differs from the correctly rounded one. */
 int shr_selftest_sqrt(unsigned lo_bits, unsigned hi_bits,
                       unsigned long long *mismatches, void *stream);
+/* Self-test: adds to *mismatches the number of pseudo-random (weights, corner depths) cases -- 4096 x 256 threads x
+ * per_thread of them -- for which the triangle kernels' pixel depth with shared reciprocals (common.h tri_pixel_depth)
+ * differs in any bit from the reference's seven plain IEEE divisions (.cu:97-110). */
+int shr_selftest_division(unsigned seed, unsigned per_thread, unsigned long long *mismatches, void *stream);
 /* Measurement hook (bench.py `roofline.launch_floor`, not part of the path): N workgroups of 1024 threads with
  * lds_bytes of dynamic LDS -- the sphere forward's launch shape at one crop per CU -- that only move the forward's
  * bytes: read spheres[N,J,4], write depth[N,H,W] (background) and the owner bytes of rows [row0, row1) of every crop

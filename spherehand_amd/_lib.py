@@ -15,7 +15,7 @@ import torch  # noqa: F401  (device memory, streams: the plumbing this library s
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libspherehand_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -70,6 +70,7 @@ SIGNATURES = {
     "shr_pose_spheres_fwd": ([_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp], _i),
     "shr_pose_spheres_bwd": ([_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp], _i),
     "shr_selftest_sqrt": ([ctypes.c_uint, ctypes.c_uint, _vp, _vp], _i),
+    "shr_selftest_division": ([ctypes.c_uint, ctypes.c_uint, _vp, _vp], _i),
     "shr_selftest_launch_floor": ([_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp], _i),
 }
 

@@ -3,7 +3,7 @@
 
 #include "sphere_zbuf.h"
 
-extern "C" int shr_abi_version(void) { return 19; }
+extern "C" int shr_abi_version(void) { return 20; }
 
 extern "C" const char *shr_error_string(int code) {
   switch (code) {
@@ -46,6 +46,53 @@ extern "C" int shr_selftest_sqrt(unsigned lo_bits, unsigned hi_bits, unsigned lo
   if (!mismatches || hi_bits < lo_bits) return SHR_EINVAL;
   hipLaunchKernelGGL(sqrt_selftest_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, lo_bits, hi_bits,
                      mismatches);
+  return (int)hipGetLastError();
+}
+
+// Self-test hook: tri_pixel_depth's shared-reciprocal divisions against the plain ones on pseudo-random operands (weights
+// in [0, 1] with exponents down to 2^-70 and exact zeros and ones among them, corner depths over 2^-45 .. 2^45 and negative
+// ones: both sides of every guard) -- counts the cases whose depth differs in any bit.
+__device__ __forceinline__ unsigned st_hash(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__global__ void division_selftest_kernel(unsigned seed, unsigned per_thread, unsigned long long *mismatches) {
+  unsigned long long bad = 0;
+  unsigned h = st_hash(seed ^ (blockIdx.x * blockDim.x + threadIdx.x) * 0x9e3779b9u);
+  auto next = [&]() { h = st_hash(h + 0x6d2b79f5u); return h; };
+  auto weight = [&]() {
+    const unsigned r = next();
+    if ((r & 15u) == 0u) return 0.f;
+    if ((r & 15u) == 1u) return 1.f;
+    const int e = (r & 16u) ? -(int)((r >> 5) % 71u) : -(int)((r >> 5) % 8u);          // down to 2^-70, mostly near 1
+    const float m = 1.0f + (float)(next() >> 9) * 0x1p-23f;
+    return fminf(ldexpf(m, e), 1.f);
+  };
+  auto depth_z = [&]() {
+    const unsigned r = next();
+    const int e = (r & 3u) ? (int)((r >> 2) % 12u) : (int)((r >> 2) % 91u) - 45;       // mostly 1 .. 2^11, sometimes anything
+    const float m = 1.0f + (float)(next() >> 9) * 0x1p-23f;
+    const float z = ldexpf(m, e);
+    return ((r >> 20) & 3u) == 0u ? -z : z;
+  };
+  for (unsigned i = 0; i < per_thread; i++) {
+    const float w0 = weight(), w1 = weight(), w2 = weight();
+    const float w_sum = (w0 + w1) + w2;
+    const float pz[3] = {depth_z(), depth_z(), depth_z()};
+    const bool tame = shr::div_tame_z(pz[0]) && shr::div_tame_z(pz[1]) && shr::div_tame_z(pz[2]);
+    float rz[3] = {0.f, 0.f, 0.f};
+    if (tame) { rz[0] = shr::div_rcp_refined(pz[0]); rz[1] = shr::div_rcp_refined(pz[1]); rz[2] = shr::div_rcp_refined(pz[2]); }
+    const float a = shr::tri_pixel_depth(w0, w1, w2, w_sum, pz, rz, tame);
+    const float q0 = w0 / w_sum, q1 = w1 / w_sum, q2 = w2 / w_sum;
+    const float b = 1.0f / ((q0 / pz[0] + q1 / pz[1]) + q2 / pz[2]);
+    bad += (__float_as_uint(a) != __float_as_uint(b)) && !(a != a && b != b);
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+extern "C" int shr_selftest_division(unsigned seed, unsigned per_thread, unsigned long long *mismatches, void *stream) {
+  if (!mismatches) return SHR_EINVAL;
+  hipLaunchKernelGGL(division_selftest_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, seed, per_thread, mismatches);
   return (int)hipGetLastError();
 }
 

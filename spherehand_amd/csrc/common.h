@@ -188,6 +188,57 @@ int tri_set_band(int rows);         // tri_raster.hip: SHR_TUNE_TRI_BAND
 int d2m_compact_check(const float *depth, int M, int H, int W, void *workspace, int **counts);
 int d2m_compact_launch(const float *depth, int M, int H, int W, void *workspace, hipStream_t s);
 
+// ---- the triangle pixel's seven IEEE divisions (.cu:97-110) with the denominators' work shared -------------------------
+// hipcc's fp32 division a / d (-fhip-fp32-correctly-rounded-divide-sqrt) is
+//     ds = v_div_scale(d, d, a); as = v_div_scale(a, d, a); r = v_rcp(ds); e = fma(-ds, r, 1); r1 = fma(e, r, r);
+//     q0 = as * r1; e1 = fma(-ds, q0, as); q1 = fma(e1, r1, q0); e2 = fma(-ds, q1, as); q = v_div_fmas(e2, r1, q1);
+//     v_div_fixup(q, d, a)
+// and v_div_scale leaves BOTH operands alone (ds = d, as = a, v_div_fmas = fma, v_div_fixup = identity up to the sign it
+// would give anyway) when d is normal and below 2^126, a is zero or at least 2^-103, and the exponents differ by less than
+// 96 upwards and 126 downwards.  Inside that domain r1 depends on d only: three divisions by one denominator share it
+// (w[k] / w_sum), and a denominator that is a constant of the face (its corners' z) brings it from the set-up.  These are
+// the compiler's own instructions on the compiler's own operands -- the quotients are the same bits (shr_selftest_division
+// compares them over random and edge operands; every oracle / reference-kernel test runs through them).
+__device__ __forceinline__ float div_rcp_refined(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float div_with(float a, float d, float r1) {
+  const float q0 = a * r1;
+  const float e1 = __builtin_fmaf(-d, q0, a);
+  const float q1 = __builtin_fmaf(e1, r1, q0);
+  const float e2 = __builtin_fmaf(-d, q1, a);
+  return __builtin_fmaf(e2, r1, q1);
+}
+// a corner depth whose reciprocal may be shared: 2^-40 <= |z| <= 2^40 (a hand's are within +-100 of the crop's centre; the
+// sign rides through the same instructions as in the compiler's sequence, a zero quotient's included)
+__device__ __forceinline__ bool div_tame_z(float z) { return fabsf(z) >= 0x1p-40f && fabsf(z) <= 0x1p40f; }
+// The pixel: clamped barycentric weights w (each in [0, 1]), their sum, the corners' z and -- `tame`: all three
+// div_tame_z -- their refined reciprocals rz.  Fast path when every weight is zero or at least 2^-60 (the sum is then
+// within [2^-60, 3], w / w_sum zero or at least 2^-62, and that over z zero or at least 2^-102: all inside the domain
+// above); the plain divisions otherwise.
+__device__ __forceinline__ float tri_pixel_depth(float w0, float w1, float w2, float w_sum, const float (&pz)[3],
+                                                 const float (&rz)[3], bool tame) {
+  // "every weight is zero or at least 2^-60" on the bit patterns of the non-negative weights: bits - 1 wraps a zero
+  // to the top, so one unsigned minimum and one compare.  (The sum needs no test of its own: it is at least the largest
+  // weight; all three zero or a NaN among them give NaN on either path, and the pixel is skipped.)  As a chain of && / ||
+  // over float compares the test compiled into a branch per clause and cost what the shared reciprocals save: 256 crops
+  // 284 us, 275 as one mask of compares, against 264 with no test of the weights at all.
+  const uint32_t t = __float_as_uint(0x1p-60f) - 1u;
+  const uint32_t m = min(min(__float_as_uint(w0) - 1u, __float_as_uint(w1) - 1u), __float_as_uint(w2) - 1u);
+  const bool ok = tame & (m >= t);
+  if (ok) {
+    const float rs = div_rcp_refined(w_sum);
+    const float u0 = div_with(div_with(w0, w_sum, rs), pz[0], rz[0]);
+    const float u1 = div_with(div_with(w1, w_sum, rs), pz[1], rz[1]);
+    const float u2 = div_with(div_with(w2, w_sum, rs), pz[2], rz[2]);
+    return 1.0f / ((u0 + u1) + u2);
+  }
+  w0 = w0 / w_sum; w1 = w1 / w_sum; w2 = w2 / w_sum;
+  return 1.0f / ((w0 / pz[0] + w1 / pz[1]) + w2 / pz[2]);
+}
+
 // Linear blend skinning of one vertex for one sample, shared by lbs_project_kernel (tri_raster.hip) and the fused
 // mesh_lattice_kernel (mesh_depth.hip): one (bone, weighted vertex) entry added to the four rows of the sum, and the
 // sign flip + orthographic camera of mesh/render.py:320-329 on the finished sum.  M = the bone's 4 x 4 matrix.

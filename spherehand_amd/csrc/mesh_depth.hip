@@ -660,6 +660,13 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
       const int ncols = __builtin_amdgcn_readlane(fincl, 63);
       if (lane < count) {
         row.pad[0] = c_lo - (fincl - ncol);                    // column item k of the face is lattice column k + this
+        // the corners' z: their refined reciprocals for the pixels' divisions (common.h tri_pixel_depth) in the words this
+        // kernel does not read (xr, yr, pad[1]), flags bit 2: all three tame
+        const bool tame = div_tame_z(row.z0) && div_tame_z(row.z1) && div_tame_z(row.z2);
+        row.xr = __float_as_int(tame ? div_rcp_refined(row.z0) : 0.f);
+        row.yr = __float_as_int(tame ? div_rcp_refined(row.z1) : 0.f);
+        row.pad[1] = __float_as_int(tame ? div_rcp_refined(row.z2) : 0.f);
+        row.flags |= tame ? 4 : 0;
         s_face[lane] = row;
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);                      // this wave's LDS writes (rows and queue are its own)
@@ -672,7 +679,7 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
           const uint32_t e = s_queue[qn - take + lane];
           const int cx = (int)((e >> kFaceBits) & 127u), cy = (int)(e >> (kFaceBits + 7));
           const float4 *r4 = reinterpret_cast<const float4 *>(&s_face[e & (uint32_t)(kLatFaces - 1)]);
-          const float4 f0v = r4[0], f1v = r4[1], f2v = r4[2], zv = r4[4];
+          const float4 f0v = r4[0], f1v = r4[1], f2v = r4[2], zv = r4[4], iv = r4[5];   // . | z0 z1 z2 rz0 | rz1 flags pad0 rz2
           const float fi[9] = {f0v.x, f0v.y, f0v.z, f0v.w, f1v.x, f1v.y, f1v.z, f1v.w, f2v.x};
           // ---- pixel (.cu:97-110) ----------------------------------------------------
           const float xf = (float)src_of(cx), yf = (float)src_of(cy);
@@ -683,9 +690,8 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
             w[k] = fminf(fmaxf(w[k], 0.f), 1.f);
             w_sum += w[k];
           }
-#pragma unroll
-          for (int k = 0; k < 3; k++) w[k] = w[k] / w_sum;
-          const float zp = 1.0f / ((w[0] / zv.x + w[1] / zv.y) + w[2] / zv.z);
+          const float pz[3] = {zv.x, zv.y, zv.z}, rz[3] = {zv.w, iv.x, iv.w};
+          const float zp = tri_pixel_depth(w[0], w[1], w[2], w_sum, pz, rz, (__float_as_int(iv.y) & 4) != 0);
           if (zp == zp) atomicMin(&s_z[cy * LP + cx], mkey(zp));
         }
         qn -= take;

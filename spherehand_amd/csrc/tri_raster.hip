@@ -137,7 +137,8 @@ __device__ __forceinline__ bool span_inside(float x0, float y0, float x1, float 
 }
 
 // .cu:97-110 for a pixel inside its column's span: the depth the reference offers to its atomicMin (NaN: none)
-__device__ __forceinline__ float span_depth(const float pz[3], const float fi[9], int xi, int yi) {
+__device__ __forceinline__ float span_depth(const float (&pz)[3], const float (&rz)[3], bool tame, const float (&fi)[9], int xi,
+                                            int yi) {
   const float xf = (float)xi, yf = (float)yi;
   float w[3];
   float w_sum = 0.f;
@@ -147,9 +148,7 @@ __device__ __forceinline__ float span_depth(const float pz[3], const float fi[9]
     w[k] = fminf(fmaxf(w[k], 0.f), 1.f);
     w_sum += w[k];
   }
-#pragma unroll
-  for (int k = 0; k < 3; k++) w[k] = w[k] / w_sum;
-  return 1.0f / ((w[0] / pz[0] + w[1] / pz[1]) + w[2] / pz[2]);
+  return tri_pixel_depth(w[0], w[1], w[2], w_sum, pz, rz, tame);   // (the seven divisions of .cu:104-110)
 }
 
 // A wave sets up to 32 faces up with lanes = faces and parks each face's values in an LDS row (raster_batch below).
@@ -202,7 +201,12 @@ __device__ __forceinline__ void raster_batch(const FaceSetup &s, bool have, int 
     r[6] = s.s01; r[7] = s.s12;
     r[20] = __int_as_float(s.xi_min - (fincl - ncol));   // column item k of the face is pixel column k + this
     r[21] = __int_as_float(s.r_lo); r[22] = __int_as_float(s.r_hi); r[23] = s.s02;
-    r[24] = __int_as_float(s.sflags);
+    {   // the corners' z: their refined reciprocals for the pixels' divisions (common.h tri_pixel_depth), bit 2: all tame
+      const bool tame = div_tame_z(s.p[0][2]) && div_tame_z(s.p[1][2]) && div_tame_z(s.p[2][2]);
+#pragma unroll
+      for (int a = 0; a < 3; a++) r[25 + a] = tame ? div_rcp_refined(s.p[a][2]) : 0.f;
+      r[24] = __int_as_float(s.sflags | (tame ? 4 : 0));
+    }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);   // this wave's LDS writes (rows and queue are private to the wave)
   __builtin_amdgcn_wave_barrier();
@@ -212,11 +216,12 @@ __device__ __forceinline__ void raster_batch(const FaceSetup &s, bool have, int 
     if (lane < take) {
       const uint2 e = s_queue[qn - take + lane];
       const float4 *r4 = reinterpret_cast<const float4 *>(s_face[e.x]);
-      const float4 b2 = r4[2], b3 = r4[3], b4 = r4[4];
+      const float4 b2 = r4[2], b3 = r4[3], b4 = r4[4], b6 = r4[6];
       const float pz[3] = {b2.x, b2.y, b2.z};
       const float fi[9] = {b2.w, b3.x, b3.y, b3.z, b3.w, b4.x, b4.y, b4.z, b4.w};
+      const float rz[3] = {b6.y, b6.z, b6.w};                                  // (row words 25 .. 27; word 24: the flags)
       const int xi = (int)(e.y & 0xffffu), yi = (int)(e.y >> 16);
-      const float zp = span_depth(pz, fi, xi, yi);
+      const float zp = span_depth(pz, rz, (__float_as_int(b6.x) & 4) != 0, fi, xi, yi);
       if (zp == zp) sink(xi, yi, zp);  // fminf(NaN, old) = old
     }
     qn -= take;

@@ -4,7 +4,7 @@
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LEVELS = (65, 40, 24, 12, 1)
+LEVELS = (65, 1)
 
 
 def so(n):
