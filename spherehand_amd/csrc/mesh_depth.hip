@@ -596,7 +596,7 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
   };
   MESH_STAMP(4);   // (SKIN: this wave's vertices are skinned) the lattice is initialised
   __syncthreads();
-  MESH_STAMP(8);   // the culls start
+  MESH_NOTE(8, 0);   // (work items: none -- tools/exp_mesh_phases.py tells the lattice kernel by it)
 
   // ---- 1. culls; the survivors' numbers ---------------------------------------------------------------------------
   for (int f0 = 0; f0 < F; f0 += kLatWaves * 64 * kPer) {
