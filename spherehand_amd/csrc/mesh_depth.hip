@@ -641,7 +641,9 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
     const int n = s_nsurv;
     MESH_NOTE(9, n);
     // batches of 32 survivors dealt round robin (face numbers cluster: a wave's own contiguous share was all palm or all
-    // finger tips, and the waves finished between 21 and 30 us).  Measured on top and not kept: batches drawn from a
+    // finger tips, and the waves finished between 21 and 30 us).  Measured on top and not kept: equal strided shares in
+    // equal batches (1 630 survivors = 102 per wave = four batches of 26 each, instead of three waves with a fourth full
+    // batch): 29.1 -> 30.5 us -- a batch costs nearly the same with 26 faces as with 32; batches drawn from a
     // counter with the next batch's vertices requested a batch ahead (corner numbers in the list instead of face
     // numbers: one round trip) -- 29.9 -> 31.6 us: the kernel is VALU-bound (82 % busy), not waiting for its gathers.
     const int from = wave * kLatFaces;
