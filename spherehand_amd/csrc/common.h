@@ -198,7 +198,7 @@ int d2m_compact_launch(const float *depth, int M, int H, int W, void *workspace,
 // 96 upwards and 126 downwards.  Inside that domain r1 depends on d only: three divisions by one denominator share it
 // (w[k] / w_sum), and a denominator that is a constant of the face (its corners' z) brings it from the set-up.  These are
 // the compiler's own instructions on the compiler's own operands -- the quotients are the same bits (shr_selftest_division
-// compares them over random and edge operands; every oracle / reference-kernel test runs through them).
+// compares them over random and edge operands; every parity test of the triangle kernels runs through them).
 __device__ __forceinline__ float div_rcp_refined(float d) {
   const float r = __builtin_amdgcn_rcpf(d);
   const float e = __builtin_fmaf(-d, r, 1.0f);
