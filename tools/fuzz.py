@@ -283,6 +283,7 @@ def sa_case():
               (hm.grad.double() - hd.grad).abs().max().item(), hd.grad.abs().max().item(), "torch fp32:", ex_t, eg_t)
 
 _skin = None
+_uskin = None
 def lbs_case():
     """skinning + camera against the oracle, bit for bit (random bone matrices, with / without camera and rand_f)"""
     global fails, _skin
@@ -301,6 +302,31 @@ def lbs_case():
     if not np.array_equal(bits(out), bits(o)):
         fails += 1
         print("LBS MISMATCH", dict(B=B, mode=mode, right_hand=rh), np.abs(out - o).max())
+    if cam is not None and rs.rand() < 0.5:
+        # DepthRender.forward as one launch (the lattice kernel skins its crop's vertices into LDS) against skinning followed
+        # by the raster: the mesh's distinct vertices (1 721: they fit next to the lattice), random faces over them
+        global _uskin
+        if _uskin is None:
+            from spherehand_amd import hand_model
+            from spherehand_amd.render import unique_skin
+            _uskin = unique_skin(hand_model.load_mesh())[:3]
+        us, ub, uw = _uskin
+        NV = len(us) - 1
+        F = int(rs.choice([1, 50, 900, 3382]))
+        base = rs.randint(0, NV, (F, 1))
+        faces = ((base + rs.randint(0, max(2, NV // rs.choice([4, 40, 400])), (F, 3))) % NV).astype(np.int32)
+        S = int(rs.choice([128, 64, 32, 80]))
+        T2 = T.copy()
+        T2[:, :, :3, 3] = rs.uniform(-60, 60, (B, 17, 3))          # (keep a part of the mesh on the screen)
+        T2[:, :, :3, :3] = (rs.standard_normal((B, 17, 3, 3)) * 0.6).astype(np.float32)
+        cam2 = (320.0 + float(rs.uniform(-40, 40)), 320.0 + float(rs.uniform(-40, 40)), float(rs.uniform(1.0, 3.0)), float(rs.uniform(1.0, 3.0)))
+        rfd = None if rf is None else dev(rf)
+        verts = ops.lbs_project(dev(T2), dev(us), dev(ub), dev(uw), rh, cam2, rfd)
+        want = ops.mesh_depth_fwd(verts, dev(faces), S, 640, 100.0)
+        got = ops.mesh_render_fwd(dev(T2), dev(us), dev(ub), dev(uw), rh, cam2, rfd, dev(faces), S, 640, 100.0)
+        if not torch.equal(got, want):
+            fails += 1
+            print("MESH RENDER MISMATCH", dict(B=B, F=F, S=S, right_hand=rh), (got - want).abs().max().item())
 
 _hm = {}
 def hm_case():
