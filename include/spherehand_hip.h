@@ -192,6 +192,15 @@ int shr_data_to_model_from_points_indexed(const void *workspace, int M, const in
                                           const float *radii, int N, int J, int H, int W, int parts,
                                           float *loss_parts, float *grad_parts, void *stream);
 
+/* The same search in another LAUNCH ORDER: `order` is a permutation of the N record sets, workgroup w searches for set
+ * order[w] against image depth_index[w] (the caller permutes that array alike) and writes that set's slots -- the
+ * results of shr_data_to_model_from_points bit for bit.  What it is for: XCD placement -- workgroups w, w + 8, ... share
+ * an L2, and the V pairs of a multi-view batch that read one image's list belong on one of them, one after the other. */
+int shr_data_to_model_from_points_ordered(const void *workspace, int M, const int32_t *depth_index,
+                                          const int32_t *order, const float *centres, int centre_stride,
+                                          const float *radii, int N, int J, int H, int W, int parts,
+                                          float *loss_parts, float *grad_parts, void *stream);
+
 /* Fused render-and-compare: the model->data term of mesh/multiview_utility.py:98-101 and
  * :107-113 (MSELoss(BallRender(...).min(), observed)) with its whole backward, one
  * launch: e = raster(spheres[n]) - target[target_index ? target_index[n] : n],
@@ -214,6 +223,13 @@ int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, int W,
  * sse_partial / grad_spheres_partial ([N][R], [N][R][J][4]).  The same-view pairs of MutualProjectionLoss with
  * is_mv = False (mesh/multiview_utility.py:107-113) out of the [B,V,V] projections, no gather in front. */
 int shr_sphere_raster_mse_indexed(const float *spheres, const int32_t *crop_index, int N, int J, int H, int W,
+                                  const float *target, const int32_t *target_index, float *depth,
+                                  float *sse_partial, float *grad_spheres_partial, void *stream);
+
+/* shr_sphere_raster_mse in another LAUNCH ORDER: `order` is a permutation of the N crops, workgroup w renders crop
+ * order[w] and writes that crop's slots of depth / sse_partial / grad_spheres_partial -- the same results bit for bit;
+ * the caller places the crops that compare against one observed image on one XCD (workgroups w, w + 8, ...). */
+int shr_sphere_raster_mse_ordered(const float *spheres, const int32_t *order, int N, int J, int H, int W,
                                   const float *target, const int32_t *target_index, float *depth,
                                   float *sse_partial, float *grad_spheres_partial, void *stream);
 

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (device memory, streams: the plumbing this library s
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libspherehand_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -41,6 +41,7 @@ SIGNATURES = {
     "shr_mv_project_compact": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "shr_data_to_model_from_points": ([_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "shr_data_to_model_from_points_indexed": ([_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
+    "shr_data_to_model_from_points_ordered": ([_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp], _i),
     "shr_mv_loss_combine": ([_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
     "shr_sphere_raster_mse_regions": ([_i, _i], _i),
     "shr_pair_losses": ([_vp, ctypes.c_longlong, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
@@ -58,6 +59,7 @@ SIGNATURES = {
     "shr_group_norm_relu_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "shr_sphere_raster_mse": ([_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "shr_sphere_raster_mse_indexed": ([_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "shr_sphere_raster_mse_ordered": ([_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "shr_mutual_project_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "shr_mutual_project_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "shr_tri_raster_fwd": ([_vp, _i, _i, _i, _i, _vp, _vp], _i),

@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 d2m_points_kernel(const uint2 *__restrict__ points, const int *__restrict__ counts, int P,
                   const int *__restrict__ depth_index, const float *__restrict__ centres, int centre_stride,
                   const float *__restrict__ radii, int J, int H, int W, int parts, float *__restrict__ loss_sum,
-                  float *__restrict__ grad_centres, const int *__restrict__ centre_index) {
+                  float *__restrict__ grad_centres, const int *__restrict__ centre_index, int slot_by_centre) {
   constexpr int K = 4, GS = 64 * K;
   __shared__ float4 s_c[SHR_MAX_SPHERES];
   __shared__ int s_odd, s_nan;
@@ -428,6 +428,9 @@ d2m_points_kernel(const uint2 *__restrict__ points, const int *__restrict__ coun
   const int n = blockIdx.x / parts, part = blockIdx.x - n * parts;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = depth_index ? depth_index[n] : n;
+  // (slot_by_centre, shr_data_to_model_from_points_ordered: centre_index is a permutation that only changes the launch
+  // order -- the results go to the record set's own slots, not the workgroup's)
+  const int out_slot = (slot_by_centre ? centre_index[n] : n) * parts + part;
   const int T = counts[m], G = (T + GS - 1) / GS;
   const uint2 *img = points + (size_t)m * P;
   // group g = points [256 g, 256 g + 256) of the image's list; lane l holds the four points 256 g + 4 l ... (32
@@ -486,13 +489,13 @@ d2m_points_kernel(const uint2 *__restrict__ points, const int *__restrict__ coun
   if (loss_fx) atomicAdd(&s_loss, (unsigned long long)loss_fx);
   __syncthreads();
   if (tid == 0)
-    loss_sum[blockIdx.x] = s_nan ? __builtin_nanf("") : (float)((double)(long long)s_loss * (1.0 / (double)kLossScale));
+    loss_sum[out_slot] = s_nan ? __builtin_nanf("") : (float)((double)(long long)s_loss * (1.0 / (double)kLossScale));
   if (WANT_GRAD && tid < J * 3) {
     const int j = tid / 3, c = tid - j * 3;
     long long t = 0;
 #pragma unroll
     for (int k = 0; k < kD2mTables; k++) t += (long long)s_acc[k * kD2mTableStride + j * 4 + c];
-    grad_centres[(size_t)blockIdx.x * J * 3 + tid] = (float)((double)t * (1.0 / (double)kGradScale));
+    grad_centres[(size_t)out_slot * J * 3 + tid] = (float)((double)t * (1.0 / (double)kGradScale));
   }
 }
 
@@ -668,10 +671,9 @@ extern "C" int shr_data_to_model_from_points(const void *workspace, int M, const
                                                parts, loss_parts, grad_parts, stream);
 }
 
-extern "C" int shr_data_to_model_from_points_indexed(const void *workspace, int M, const int32_t *depth_index,
-                                                     const int32_t *centre_index, const float *centres, int centre_stride,
-                                                     const float *radii, int N, int J, int H, int W, int parts,
-                                                     float *loss_parts, float *grad_parts, void *stream) {
+static int d2m_from_points_launch(const void *workspace, int M, const int32_t *depth_index, const int32_t *centre_index,
+                                  int slot_by_centre, const float *centres, int centre_stride, const float *radii, int N, int J,
+                                  int H, int W, int parts, float *loss_parts, float *grad_parts, void *stream) {
   using namespace shr;
   if (N == 0) return SHR_OK;
   if (!workspace || !centres || !radii || !loss_parts || N < 0 || M <= 0 || J <= 0 || H <= 0 || W <= 0) return SHR_EINVAL;
@@ -685,9 +687,29 @@ extern "C" int shr_data_to_model_from_points_indexed(const void *workspace, int 
   const long long wgs = (long long)N * parts;
   const int waves = g_d2m_waves ? g_d2m_waves : (wgs >= 2048 ? 4 : (wgs >= 768 ? 8 : 16));
 #define D2P_LAUNCH(G, NW) hipLaunchKernelGGL((d2m_points_kernel<G, NW>), grid, dim3(NW * 64), 0, s, points, counts, H * W, \
-                                             depth_index, centres, centre_stride, radii, J, H, W, parts, loss_parts, grad_parts, centre_index)
+                                             depth_index, centres, centre_stride, radii, J, H, W, parts, loss_parts, grad_parts, centre_index, slot_by_centre)
   if (grad_parts) { if (waves >= 16) D2P_LAUNCH(true, 16); else if (waves >= 8) D2P_LAUNCH(true, 8); else D2P_LAUNCH(true, 4); }
   else { if (waves >= 16) D2P_LAUNCH(false, 16); else if (waves >= 8) D2P_LAUNCH(false, 8); else D2P_LAUNCH(false, 4); }
 #undef D2P_LAUNCH
   return (int)hipGetLastError();
+}
+
+extern "C" int shr_data_to_model_from_points_indexed(const void *workspace, int M, const int32_t *depth_index,
+                                                     const int32_t *centre_index, const float *centres, int centre_stride,
+                                                     const float *radii, int N, int J, int H, int W, int parts,
+                                                     float *loss_parts, float *grad_parts, void *stream) {
+  return d2m_from_points_launch(workspace, M, depth_index, centre_index, 0, centres, centre_stride, radii, N, J, H, W, parts,
+                                loss_parts, grad_parts, stream);
+}
+
+// `order`: a permutation of the N record sets -- workgroup w searches for record set order[w] (against image
+// depth_index[w]: the caller permutes that array alike) and writes that SET's slots: shr_data_to_model_from_points'
+// results in another launch order (XCD placement: the pairs that read one image's list on one L2)
+extern "C" int shr_data_to_model_from_points_ordered(const void *workspace, int M, const int32_t *depth_index,
+                                                     const int32_t *order, const float *centres, int centre_stride,
+                                                     const float *radii, int N, int J, int H, int W, int parts,
+                                                     float *loss_parts, float *grad_parts, void *stream) {
+  if (!order || !depth_index) return SHR_EINVAL;
+  return d2m_from_points_launch(workspace, M, depth_index, order, 1, centres, centre_stride, radii, N, J, H, W, parts,
+                                loss_parts, grad_parts, stream);
 }

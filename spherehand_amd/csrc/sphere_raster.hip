@@ -370,10 +370,11 @@ extern "C" int shr_sphere_raster_mse(const float *spheres, int N, int J, int H, 
                                        grad_spheres_partial, stream);
 }
 
-extern "C" int shr_sphere_raster_mse_indexed(const float *spheres, const int32_t *crop_index, int N, int J, int H, int W,
-                                             const float *target, const int32_t *target_index, float *depth,
-                                             float *sse_partial, float *grad_spheres_partial, void *stream) {
+static int sphere_raster_mse_launch(const float *spheres, const int32_t *crop_index, bool slot_by_crop, int N, int J, int H,
+                                    int W, const float *target, const int32_t *target_index, float *depth,
+                                    float *sse_partial, float *grad_spheres_partial, void *stream) {
   using namespace shr;
+  const int by_crop = slot_by_crop ? 0x100 : 0;
   if (N == 0) return SHR_OK;
   if (!spheres || !target || !sse_partial || !grad_spheres_partial || N < 0 || J <= 0 || H <= 0 || W <= 0)
     return SHR_EINVAL;
@@ -408,21 +409,21 @@ extern "C" int shr_sphere_raster_mse_indexed(const float *spheres, const int32_t
     const hipError_t e = allow_big_lds(k, seg2 ? &attr_d : &attr_c);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(1024), blds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
-                       target_index, rows, log2_if_pow2(W / 4), zcells, g_tune.fwd_shares, g_tune.bwd_shares, depth,
+                       target_index, rows, (log2_if_pow2(W / 4) & 0xff) | by_crop, zcells, g_tune.fwd_shares, g_tune.bwd_shares, depth,
                        sse_partial, reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H), crop_index);
   } else if (is_pow2(W) && is_pow2(H)) {
     auto k = sphere_zbuf_mse_kernel<true, false>;
     const hipError_t e = allow_big_lds(k, &attr_a);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
-                       target_index, rows, log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, depth, sse_partial,
+                       target_index, rows, (log2_if_pow2(W / 4) & 0xff) | by_crop, g_tune.fwd_shares, g_tune.bwd_shares, depth, sse_partial,
                        reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H), crop_index);
   } else {
     auto k = sphere_zbuf_mse_kernel<false, false>;
     const hipError_t e = allow_big_lds(k, &attr_b);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k, grid, dim3(1024), lds, s, reinterpret_cast<const float4 *>(spheres), N, J, H, W, target,
-                       target_index, rows, log2_if_pow2(W / 4), g_tune.fwd_shares, g_tune.bwd_shares, depth, sse_partial,
+                       target_index, rows, (log2_if_pow2(W / 4) & 0xff) | by_crop, g_tune.fwd_shares, g_tune.bwd_shares, depth, sse_partial,
                        reinterpret_cast<float4 *>(grad_spheres_partial), make_axis_k(W, H), crop_index);
   }
   return (int)hipGetLastError();
@@ -448,3 +449,19 @@ extern "C" int shr_debug_timeline_clear(void) {
 }
 #endif
 
+extern "C" int shr_sphere_raster_mse_indexed(const float *spheres, const int32_t *crop_index, int N, int J, int H, int W,
+                                             const float *target, const int32_t *target_index, float *depth,
+                                             float *sse_partial, float *grad_spheres_partial, void *stream) {
+  return sphere_raster_mse_launch(spheres, crop_index, false, N, J, H, W, target, target_index, depth, sse_partial,
+                                  grad_spheres_partial, stream);
+}
+
+// `order`: a permutation of the N crops -- workgroup w works on crop order[w] and writes that CROP's slots: the results
+// of shr_sphere_raster_mse, in another launch order (the caller's XCD placement: workgroups w, w + 8, ... share an L2)
+extern "C" int shr_sphere_raster_mse_ordered(const float *spheres, const int32_t *order, int N, int J, int H, int W,
+                                             const float *target, const int32_t *target_index, float *depth,
+                                             float *sse_partial, float *grad_spheres_partial, void *stream) {
+  if (!order) return SHR_EINVAL;
+  return sphere_raster_mse_launch(spheres, order, true, N, J, H, W, target, target_index, depth, sse_partial,
+                                  grad_spheres_partial, stream);
+}

@@ -1552,7 +1552,10 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   // Every crop starts from OPAQUE copies of the launch constants and of the thread index: otherwise the compiler
   // hoists each crop-invariant value out of the crop loop and keeps it in a register (forward: 92 instead of 51
   // VGPRs; the fused kernel spilled).
-  int J = J_, H = H_, W = W_, rows_per_region = rows_per_region_, w4_shift = w4_shift_, tid = threadIdx.x;
+  // (w4_shift_: log2(W / 4) or -1 in the low byte (signed); bit 8: the partial results go to the CROP's slots, not the
+  // workgroup's -- shr_sphere_raster_mse_ordered, where crop_index is a permutation that only changes the launch order)
+  int J = J_, H = H_, W = W_, rows_per_region = rows_per_region_, w4_shift = (int)(signed char)(w4_shift_ & 0xff), tid = threadIdx.x;
+  const bool slot_by_crop = (w4_shift_ & 0x100) != 0;
   int zcells = zcells_;
   if (PERSIST) {
     asm volatile("" : "+s"(J), "+s"(H), "+s"(W), "+s"(rows_per_region), "+s"(w4_shift), "+s"(zcells));
@@ -1865,7 +1868,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   float *s_wsum = reinterpret_cast<float *>(s_items);   // the work list is done with
   if (lane == 63) s_wsum[wave] = sse;
   __syncthreads();
-  const size_t slot = (size_t)n * nregions + region;
+  const size_t slot = (size_t)(slot_by_crop ? c : n) * nregions + region;
   if (tid == 0) {
     float t = 0.f;
     for (int w = 0; w < kZWaves; w++) t += s_wsum[w];

@@ -96,7 +96,7 @@ class MutualProjectionLoss(nn.Module):
                 ws, fresh, keep = self._point_lists(observed) if ops.d2m_two_step_pays(observed) else (None, False, None)
                 loss, projected = ops.MutualProjectionLossFused.apply(camera_poses, inv_camera_poses, joints, observed, radii,
                                                                       index, diag, bool(is_mv), 500.0, ws, fresh, diag_target,
-                                                                      bool(self.return_projections))
+                                                                      bool(self.return_projections), self._order, self._order_target)
                 if keep is not None:        # (kept only once the call that fills them has been issued)
                     self._points = keep
                 return loss, (projected.view(B, V, V, H, W) if self.return_projections else None)
@@ -149,6 +149,17 @@ class MutualProjectionLoss(nn.Module):
             self._diag_index = torch.arange(B * V * V, device=dev, dtype=torch.int32).view(B, V, V) \
                 .diagonal(dim1=1, dim2=2).reshape(-1).contiguous()                      # the V same-view pairs
             self._diag_target = self._index.index_select(0, self._diag_index.long()).contiguous()   # ... and their images
+            # XCD placement of the all-pairs mode: the V pairs (b, i, j), i = 0 .. V-1, that compare against image b*V+j and
+            # search its point list run on ONE XCD one after the other -- workgroup w lands on XCD w % 8, so image t's
+            # pairs take the workgroups 8 (V p + i) + x with t = 8 p + x.  (The batch's own order puts them V apart, on
+            # three different L2s: every observed image and every point list crossed the fabric V times.)
+            self._order = self._order_target = None
+            if (B * V) % 8 == 0:
+                w = torch.arange(B * V * V, device=dev)
+                x, k = w % 8, w // 8
+                t = 8 * (k // V) + x
+                self._order = (((t // V) * V + k % V) * V + t % V).to(torch.int32).contiguous()
+                self._order_target = self._index.index_select(0, self._order.long()).contiguous()
             self._index_key = key
         return self._index, self._diag_index, self._diag_target
 

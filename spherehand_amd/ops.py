@@ -372,7 +372,7 @@ class MutualProjectionLossFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cam, inv_cam, joints, observed, radii, index, diag_index, is_mv, d2m_weight, points_ws=None,
-                points_fresh=False, diag_target=None, want_depth=True):
+                points_fresh=False, diag_target=None, want_depth=True, order=None, order_target=None):
         cam, inv_cam, joints = (t.detach().contiguous().float() for t in (cam, inv_cam, joints))
         observed, radii = observed.contiguous().float(), radii.contiguous().float()
         for t, name in ((cam, "camera_poses"), (inv_cam, "inv_camera_poses"), (joints, "joints"), (observed, "depth_maps"),
@@ -467,14 +467,23 @@ class MutualProjectionLossFused(torch.autograd.Function):
                 if want_depth:
                     _lib.check(lib.shr_sphere_raster_fwd_ex(_ptr(spheres), N, J, H, W, dptr, None, 0, s_main),
                                "shr_sphere_raster_fwd_ex")
+            elif is_mv and order is not None:
+                # all pairs, in the XCD-aware launch order (multiview_utility._indices): the same slots, the same bits
+                _lib.check(lib.shr_sphere_raster_mse_ordered(_ptr(spheres), _ptr(order), N, J, H, W, _ptr(observed), _ptr(index),
+                                                             dptr, p_sse, p_gsp, s_main), "shr_sphere_raster_mse_ordered")
             else:
                 _lib.check(lib.shr_sphere_raster_mse(_ptr(spheres), N, J, H, W, _ptr(observed), _ptr(index), dptr,
                                                      p_sse, p_gsp, s_main), "shr_sphere_raster_mse")
             if two_step:
                 ws = points_ws
-                _lib.check(lib.shr_data_to_model_from_points_indexed(_ptr(ws), int(observed.shape[0]), _ptr(cidx), _ptr(cen_index),
-                                                                     _ptr(spheres), 4, _ptr(radii), E, J, H, W, Rd, p_d2m,
-                                                                     p_gd2m, s_d2m), "shr_data_to_model_from_points")
+                if is_mv and order is not None:
+                    _lib.check(lib.shr_data_to_model_from_points_ordered(_ptr(ws), int(observed.shape[0]), _ptr(order_target),
+                                                                         _ptr(order), _ptr(spheres), 4, _ptr(radii), E, J, H, W,
+                                                                         Rd, p_d2m, p_gd2m, s_d2m), "shr_data_to_model_from_points_ordered")
+                else:
+                    _lib.check(lib.shr_data_to_model_from_points_indexed(_ptr(ws), int(observed.shape[0]), _ptr(cidx), _ptr(cen_index),
+                                                                         _ptr(spheres), 4, _ptr(radii), E, J, H, W, Rd, p_d2m,
+                                                                         p_gd2m, s_d2m), "shr_data_to_model_from_points")
                 if overlap:
                     main.wait_stream(side)
             else:
@@ -495,9 +504,9 @@ class MutualProjectionLossFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_depth):
         if g_loss is None:
-            return (None,) * 13
+            return (None,) * 15
         (gj,) = ctx.saved_tensors
-        return (None, None, gj * g_loss) + (None,) * 10
+        return (None, None, gj * g_loss) + (None,) * 12
 
 
 class MutualProject(torch.autograd.Function):

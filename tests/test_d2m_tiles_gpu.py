@@ -527,3 +527,32 @@ def test_loss_without_materialised_projections_is_the_same_loss(S, B, is_mv):
         else:      # (the default may take the one-launch wiring on a small stack: same per-pair values, another summation order)
             assert abs(l1.item() - l2.item()) <= 1e-6 * abs(l1.item())
         assert torch.equal(j1.grad, j2.grad)
+
+
+@pytest.mark.parametrize("S,B", [(64, 8), (128, 16), (256, 48)])
+@pytest.mark.parametrize("lean", [False, True])
+def test_xcd_aware_launch_order_gives_the_same_bits(S, B, lean):
+    """All pairs, B * V a multiple of 8: the fused render-and-compare kernel and the point search are launched in the
+    order that puts the V pairs of one observed image on one XCD (shr_sphere_raster_mse_ordered,
+    shr_data_to_model_from_points_ordered; multiview_utility._indices) -- against the batch's own order: loss,
+    projections and d loss / d joints bit for bit, below and above the two-step threshold."""
+    from spherehand_amd import hand_model
+    from spherehand_amd.datasets import SyntheticMultiviewDataset
+    from spherehand_amd.multiview_utility import MutualProjectionLoss
+    mesh = hand_model.load_mesh()
+    ds = SyntheticMultiviewDataset(mesh, B, S, seed=13, device="cuda")
+    ordered, plain = MutualProjectionLoss(S, mesh).cuda(), MutualProjectionLoss(S, mesh).cuda()
+    ordered.return_projections = plain.return_projections = not lean
+    cam, inv, dms = ds.cam.cuda(), ds.inv_cam.cuda(), ds.dms.cuda()
+    plain._indices(B, 3, cam.device)
+    plain._order = plain._order_target = None               # the batch's own launch order
+    for k in range(2):
+        j1 = (ds.joints.cuda() + 0.3 * (k + 1)).requires_grad_(True)
+        j2 = j1.detach().clone().requires_grad_(True)
+        l1, p1 = ordered(cam, inv, j1, dms, True)
+        assert ordered._order is not None and sorted(ordered._order.tolist()) == list(range(B * 9))
+        l2, p2 = plain(cam, inv, j2, dms, True)
+        l1.backward()
+        l2.backward()
+        assert torch.equal(l1, l2) and torch.equal(j1.grad, j2.grad)
+        assert lean or torch.equal(p1, p2)
