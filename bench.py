@@ -489,8 +489,16 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     t_md = mean_launch_us(lambda s: _lib.check(lib.shr_mesh_depth_fwd(v[0], v[1], BATCH, nv, nf, 640, S, 100.0, v[2], s),
                                                "mesh_depth"), stream, 20, 3, 3)
     # vertices (16 NV B) + shared indices + the S x S output per crop
+    # ... and the module's own call: skinning + camera + raster + clamp + resize as ONE launch (shr_mesh_render_fwd)
+    l = dr.lbs
+    rf = [T.contiguous().data_ptr(), l.skin_vertex_start.data_ptr(), l.skin_bone.data_ptr(), l.skin_wv.data_ptr()]
+    cxy = dr.camera
+    t_fr = mean_launch_us(lambda s: _lib.check(lib.shr_mesh_render_fwd(rf[0], BATCH, 17, nv, rf[1], rf[2], rf[3], 1, cxy[0], cxy[1], cxy[2],
+                                                                       cxy[3], None, v[1], nf, 640, S, 100.0, v[0], v[2], s),
+                                               "mesh_render"), stream, 20, 3, 3)
     sec["depth_render_256_crops_128x128"] = {"module_us": round(t_dr, 1),
-                                             "mesh_depth_kernel": dict(us=round(t_md, 1), **roof(BATCH * (16 * nv + 4 * S * S) + 12 * nf, t_md))}
+                                             "one_launch_mesh_lattice_kernel_with_skinning_us": round(t_fr, 1),
+                                             "mesh_lattice_kernel": dict(us=round(t_md, 1), **roof(BATCH * (16 * nv + 4 * S * S) + 12 * nf, t_md))}
     raw = torch.empty(BATCH, 640, 640, device=dev)
     r = [fv.data_ptr(), raw.data_ptr()]
     t_tri = mean_launch_us(lambda s: _lib.check(lib.shr_tri_raster_fwd(r[0], BATCH, nf, 640, 640, r[1], s), "tri"),
