@@ -65,7 +65,7 @@ def main():
                         R = l.shr_sphere_raster_mse_regions(S, S)
                         tgt = (ref.get("d", depth) + 3.0 * torch.randn_like(depth)).contiguous()
                         sse = torch.empty(n * R, device=dev); gsp = torch.empty(n * R * J * 4, device=dev)
-                        m = lambda s: l.shr_sphere_raster_mse(p[0], n, J, S, S, tgt.data_ptr(), None, p[1], sse.data_ptr(), gsp.data_ptr(), s)
+                        m = lambda s: l.shr_sphere_raster_mse(p[0], n, J, S, S, tgt.data_ptr(), None, None if os.environ.get("NODEPTH") else p[1], sse.data_ptr(), gsp.data_ptr(), s)
                         assert m(stream.cuda_stream) == 0
                         print("n %5d %-8s render-and-compare %7.2f us" % (n, name, bench.mean_launch_us(m, stream, reps, 3, 3, warm_ms=30.0)), flush=True)
                     print("n %5d %-8s fwd+owner %7.2f  bwd %7.2f  fwd depth-only %7.2f us%s" % (n, name, tf, tb, t0, same), flush=True)
