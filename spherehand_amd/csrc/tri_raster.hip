@@ -181,6 +181,13 @@ constexpr int kWaveScratchBytes = wave_scratch_bytes(kFacesPerWave);            
 // neighbouring columns at one height.  For an LDS sink (band kernel): 1 crop 54 -> 37 us.  NOT for the global atomics:
 // 64 lanes in a few cache lines resolve slower in the L2 than 64 lanes in 64 lines (256 crops 461 -> 544 us;
 // tools/exp_tri_level.py, EXPERIMENTS R3c).
+// (tools/exp_tri_level.py builds this file with the two kernels' walks swapped: the measurements behind the defaults)
+#ifndef SHR_TRI_ATOMIC_LEVELS
+#define SHR_TRI_ATOMIC_LEVELS 0
+#endif
+#ifndef SHR_TRI_BAND_LEVELS
+#define SHR_TRI_BAND_LEVELS 1
+#endif
 template <int NF, bool LEVELS, typename Sink>
 __device__ __forceinline__ void raster_batch(const FaceSetup &s, bool have, int lane, unsigned char *scratch, int height,
                                              Sink &&sink) {
@@ -341,7 +348,7 @@ tri_raster_kernel(const float *__restrict__ src, const int *__restrict__ faces, 
   const FaceSetup s = face_setup(f, width, height);
   float *zimg = zbuf + (size_t)b * width * height;
   __shared__ __attribute__((aligned(16))) unsigned char s_scratch[4][kWaveScratchBytes];
-  raster_batch<kFacesPerWave, false>(s, have, lane, s_scratch[threadIdx.x >> 6], height,
+  raster_batch<kFacesPerWave, SHR_TRI_ATOMIC_LEVELS != 0>(s, have, lane, s_scratch[threadIdx.x >> 6], height,
                [&](int xi, int yi, float zp) { zmin(zimg + (size_t)yi * width + xi, zp); });
 }
 
@@ -496,7 +503,7 @@ tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, in
         FaceSetup fs = face_setup(f, width, height);
         fs.r_lo = max(fs.r_lo, lo);
         fs.r_hi = min(fs.r_hi, hi);
-        raster_batch<kBandFaces, true>(fs, have, lane, scratch, height, sink);
+        raster_batch<kBandFaces, SHR_TRI_BAND_LEVELS != 0>(fs, have, lane, scratch, height, sink);
       }
     }
     __syncthreads();

@@ -1,10 +1,13 @@
-"""Triangle rasterizer: how many columns a LEVEL must hold to be walked as a level (raster_batch, SHR_TRI_DENSE_LEVEL).
-    python tools/exp_tri_level.py build     (anywhere: tri_raster.hip alone, tools/libtri_lv{1,12,24,40,65}.so; 65 = never)
-    python tools/exp_tri_level.py           (GPU box: depth_rasterization.forward's launches at B = 1 / 48 / 256, same-bits check)"""
+"""Triangle rasterizer: raster_batch's level walk against its pixel-order walk in BOTH kernels (tri_raster.hip built alone
+with -DSHR_TRI_ATOMIC_LEVELS / -DSHR_TRI_BAND_LEVELS; the defaults are levels in the band kernel only).  EXPERIMENTS
+R3c's first table also swept a threshold (columns a level must hold to be walked as a level) that is no longer in the code.
+    python tools/exp_tri_level.py build     (anywhere: tools/libtri_lv{0,1}.so -- 0: pixel order everywhere, 1: levels everywhere)
+    python tools/exp_tri_level.py           (GPU box: shr_tri_raster_fwd at B = 256 / 48 / 1 with the launcher's own choice of
+                                             kernel, same-bits check)"""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LEVELS = (65, 1)
+LEVELS = (0, 1)
 
 
 def so(n):
@@ -14,7 +17,7 @@ def so(n):
 def build():
     from spherehand_amd import build as b
     for n in LEVELS:
-        subprocess.check_call([b.HIPCC] + list(b.FLAGS) + ["-DSHR_TRI_DENSE_LEVEL=%d" % n, "-I", os.path.join(ROOT, "include"),
+        subprocess.check_call([b.HIPCC] + list(b.FLAGS) + ["-DSHR_TRI_ATOMIC_LEVELS=%d" % n, "-DSHR_TRI_BAND_LEVELS=%d" % n, "-I", os.path.join(ROOT, "include"),
                                "-I", os.path.join(b.PKG, "csrc"), "-o", so(n), os.path.join(b.PKG, "csrc", "tri_raster.hip")])
         print(so(n))
 
@@ -52,7 +55,7 @@ def main():
                         ref = out.clone()
                     same = torch.equal(out, ref)
                     t = bench.mean_launch_us(fn, stream, 10 if B > 1 else 50, 3, 3, warm_ms=20.0)
-                    print("B=%3d level >= %2d: %8.1f us  same bits: %s" % (B, n, t, same), flush=True)
+                    print("B=%3d %s: %8.1f us  same bits: %s" % (B, "levels everywhere" if n else "pixel order everywhere", t, same), flush=True)
 
 
 if __name__ == "__main__":
