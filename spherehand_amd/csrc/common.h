@@ -283,4 +283,33 @@ __device__ __forceinline__ int run_of(int incl, bool mine, int k0, int k) {
 
 __device__ __forceinline__ bool is_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// ---- host side: what a launcher caches PER DEVICE -------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device function attribute and the CU count a per-device number:
+// a process that launches on a second GPU must set / read them there too (ops._on() may launch on a non-current device).
+constexpr int kMaxDevices = 64;
+struct AttrDone { bool dev[kMaxDevices] = {}; };
+
+// the opt-in to `bytes` of dynamic LDS for `kernel` on the CURRENT device, once per (kernel, device)
+template <typename K>
+inline hipError_t allow_dynamic_lds(K kernel, int bytes, AttrDone *done) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = -1;
+  if (d >= 0 && done->dev[d]) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && d >= 0) done->dev[d] = true;
+  return e;
+}
+
+// compute units of the current device (256 when it cannot be asked)
+inline int device_cus() {
+  static int cus[kMaxDevices] = {};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return 256;
+  if (cus[d] == 0) {
+    int v = 0;
+    cus[d] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && v > 0) ? v : 256;
+  }
+  return cus[d];
+}
+
 }  // namespace shr

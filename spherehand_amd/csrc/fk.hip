@@ -233,8 +233,9 @@ pose_bwd_kernel(const float *__restrict__ params, const float *__restrict__ offs
     // Stage the sample's gradient records (as they lie: one coalesced load) and the key-points in bone order
     // (entry k = point bone_points[k]) in LDS, in flight while the sincos run.  (Walking the CSR lists straight from
     // HBM was a chain of dependent loads per point -- 11 for the palm -- and 3 us of this kernel's 6.2.)
+    // (point numbers clamped into [0, J): a malformed table can then neither index wv[] nor the LDS copies out of range)
     for (int k = lane; k < J && k < kMaxPoints; k += 64) {
-      const int j = bone_points[k];
+      const int j = min(max(bone_points[k], 0), min(J, kMaxPoints) - 1);
       sg[k] = grad_spheres[(size_t)b * J + k];
       sj[k] = j;
       sw[k] = wv[j];
@@ -262,8 +263,8 @@ pose_bwd_kernel(const float *__restrict__ params, const float *__restrict__ offs
         float4 gs[4], w[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const int kk = min(k + q, kMaxPoints - 1);
-          gs[q] = sg[min(sj[kk], kMaxPoints - 1)];
+          const int kk = min(max(k + q, 0), min(J, kMaxPoints) - 1);   // (entries past J are uninitialised LDS: never read)
+          gs[q] = sg[sj[kk]];
           w[q] = sw[kk];
         }
 #pragma unroll

@@ -816,15 +816,12 @@ static int mesh_lattice_launch(const float4 *v4, const shr::LatticeSkin *skin, c
   const size_t lat_lds = lattice_lds_bytes(SLx * S, F, lw, lf, skin ? NV : 0);
   if (lattice_mode == 0 || !(single || even) || SLx * S > kLatMax || F <= 0 || F > 65535 || lat_lds > 160 * 1024 - 512) return -1;
   if (skin && (skin->NB * 64 > lw * lat_scratch_bytes(lf))) return -1;     // (the matrices are staged in the scratch)
-  static bool attr_done[8] = {false, false, false, false, false, false, false, false};
+  static AttrDone attr_done[8];   // per (kernel, device)
   LatticeSkin sk = {};
   if (skin) sk = *skin;
   auto launch = [&](auto kernel, int which) -> int {
-    if (!attr_done[which]) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-      if (e != hipSuccess) return (int)e;
-      attr_done[which] = true;
-    }
+    const hipError_t e = allow_dynamic_lds(kernel, 160 * 1024 - 512, &attr_done[which]);
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(lw * 64), lat_lds, s, v4, faces, NV, F, src_size, S, clamp_max, depth, sk);
     return (int)hipGetLastError();
   };

@@ -49,21 +49,9 @@ int log2_if_pow2(int v) {
   return s;
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: the flag is kept per device ordinal
-// (ops._on() may launch on a non-current device of the same process).
-constexpr int kMaxDevices = 64;
-struct AttrDone { bool dev[kMaxDevices] = {}; };
-
+// (the per-device bookkeeping -- AttrDone, allow_dynamic_lds, device_cus -- lives in common.h)
 template <typename K>
-hipError_t allow_big_lds(K kernel, AttrDone *done) {
-  int d = 0;
-  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = -1;
-  if (d >= 0 && done->dev[d]) return hipSuccess;
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-  if (e == hipSuccess && d >= 0) done->dev[d] = true;
-  return e;
-}
+hipError_t allow_big_lds(K kernel, AttrDone *done) { return allow_dynamic_lds(kernel, kMaxLds, done); }
 
 int pick_waves(int ntiles) {
   int w = 16;
@@ -76,16 +64,7 @@ bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // Workgroups along x for a launch over N crops: all of them when they are resident at once anyway; otherwise as many
 // as the device holds at a time (CUs x workgroups per CU by LDS), each looping over its crops with the next crop's
 // records prefetched (sphere_zbuf.h).  Needs a wave that is neither the list wave nor a background wave.
-int num_cus() {
-  static int cus[kMaxDevices] = {};
-  int d = 0;
-  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return 256;
-  if (cus[d] == 0) {
-    int v = 0;
-    cus[d] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && v > 0) ? v : 256;
-  }
-  return cus[d];
-}
+int num_cus() { return device_cus(); }
 
 int persistent_grid(int N, int regions, size_t lds, int nwaves) {
   if (g_tune.persistent == 0 || nwaves <= kBgWaves + 1) return N;

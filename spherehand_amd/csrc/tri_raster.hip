@@ -406,7 +406,8 @@ tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, in
   uint32_t *s_range = reinterpret_cast<uint32_t *>(smem);
   uint16_t *s_pend = reinterpret_cast<uint16_t *>(smem + (size_t)Fpad * 4);          // the faces that reach the current band
   float *s_band = reinterpret_cast<float *>(smem + (size_t)Fpad * 6);
-  unsigned char *s_scr = smem + (size_t)Fpad * 6 + (size_t)R * width * 4;
+  // (the band rounded up to 16 bytes: the scratch is read through float4 / uint2 -- odd widths would leave it 4-byte aligned)
+  unsigned char *s_scr = smem + (size_t)Fpad * 6 + (((size_t)R * width * 4 + 15) & ~(size_t)15);
   __shared__ int s_bandcnt[kBandMaxBands];
   __shared__ int s_npend;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -586,7 +587,7 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
   // The band kernel: the row ranges of all faces (4 F bytes) + sixteen wave scratches + a band of at least 8 rows
   // in one CU's LDS, 16-bit face numbers and row numbers.
   constexpr int kLds = 160 * 1024;
-  const long long fixed = (long long)((F + 7) & ~7) * 6 + (long long)kBandWaves * kBandScratchBytes + 4096;   // (+ the static arrays: band counters, pending faces)
+  const long long fixed = (long long)((F + 7) & ~7) * 6 + (long long)kBandWaves * kBandScratchBytes + 4096 + 16;   // (+ the static arrays: band counters, pending faces; + the band's rounding to 16 bytes)
   long long Rmax = (kLds - fixed) / (4LL * W);
   if (Rmax > H) Rmax = H;
   // Which kernel: the band kernel wherever it fits (round 5, after raster_batch's level walk: hand mesh @640x640,
@@ -594,11 +595,7 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
   // against 461); the atomic kernel for what does not (more than 65535 faces, rows too wide for 8 of them in LDS).
   // SHR_TUNE_TRI_BAND: 0 forces the atomic kernel, n > 0 bands of at most n rows.
   if (g_tri_band != 0 && F > 0 && F <= 65535 && Rmax >= 8 && H <= 65535 && W <= 65535) {
-    static int cus = 0;
-    if (cus == 0) {
-      int d = 0, v = 0;
-      cus = (hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && v > 0) ? v : 256;
-    }
+    const int cus = device_cus();   // (per device: common.h)
     // Rows per band and workgroups per crop.  A band costs a fixed part -- one batch's latency: the gather of its faces,
     // the set-up's chain of divisions, three barriers -- worth ~24 rows of raster and stream-out (256 crops: 8.8 us per
     // band of 8 rows, 13.4 per band of 25), a workgroup its pass over all faces' row ranges (~10 rows' worth), and a
@@ -637,14 +634,11 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
     const int nbands = (H + R - 1) / R;
     if (segs > nbands) segs = nbands;
     if (segs > 65535) segs = 65535;
-    const size_t lds = (size_t)((F + 7) & ~7) * 6 + (size_t)R * W * 4 + (size_t)kBandWaves * kBandScratchBytes;
-    static bool attr_done[2] = {false, false};
+    const size_t lds = (size_t)((F + 7) & ~7) * 6 + (((size_t)R * W * 4 + 15) & ~(size_t)15) + (size_t)kBandWaves * kBandScratchBytes;
+    static AttrDone attr_done[2];   // per (kernel, device)
     auto launch = [&](auto kernel, int which) -> int {
-      if (!attr_done[which]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds - 4096);   // (the static arrays take the rest)
-        if (e != hipSuccess) return (int)e;
-        attr_done[which] = true;
-      }
+      const hipError_t e = allow_dynamic_lds(kernel, kLds - 4096, &attr_done[which]);   // (the static arrays take the rest)
+      if (e != hipSuccess) return (int)e;
       hipLaunchKernelGGL(kernel, dim3((unsigned)B, (unsigned)segs), dim3(kBandWaves * 64), lds, s, src, faces, B, F, NV, W, H,
                          depth, R, nbands);
       return (int)hipGetLastError();

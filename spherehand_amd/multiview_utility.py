@@ -76,6 +76,8 @@ class MutualProjectionLoss(nn.Module):
         # visualiser; Engine's epoch loops (which drop them) switch this off, everything else gets the reference's
         # return value.
         self.return_projections = True
+        # the XCD-aware launch order of the all-pairs mode (_indices) is used from this many crops on
+        self.xcd_order_min_crops = 512
 
     def invalidate(self):
         """Forget the cached point lists (and release the observed tensor and the workspace they pin)."""
@@ -153,8 +155,10 @@ class MutualProjectionLoss(nn.Module):
             # search its point list run on ONE XCD one after the other -- workgroup w lands on XCD w % 8, so image t's
             # pairs take the workgroups 8 (V p + i) + x with t = 8 p + x.  (The batch's own order puts them V apart, on
             # three different L2s: every observed image and every point list crossed the fabric V times.)
+            # Only where that placement holds and was measured: an 8-XCD part (gfx942 / gfx950) and a stack of at least two
+            # workgroups per CU (1152 crops: -4 % / -2 % on the two kernels); elsewhere the permutation would be pure overhead.
             self._order = self._order_target = None
-            if (B * V) % 8 == 0:
+            if (B * V) % 8 == 0 and B * V * V >= self.xcd_order_min_crops and _eight_xcds(dev):
                 w = torch.arange(B * V * V, device=dev)
                 x, k = w % 8, w // 8
                 t = 8 * (k // V) + x
@@ -162,6 +166,15 @@ class MutualProjectionLoss(nn.Module):
                 self._order_target = self._index.index_select(0, self._order.long()).contiguous()
             self._index_key = key
         return self._index, self._diag_index, self._diag_target
+
+
+def _eight_xcds(dev):
+    """True on the parts whose workgroup w is dispatched to XCD w % 8 (MI300X / MI355X)."""
+    try:
+        arch = torch.cuda.get_device_properties(dev).gcnArchName
+    except Exception:
+        return False
+    return arch.split(":")[0] in ("gfx942", "gfx950")
 
 
 class MultiviewConsistencyLoss(nn.Module):

@@ -263,11 +263,19 @@ def d2m_two_step_pays(depth, shared=False):
 
 MV_OVERLAP = True        # MutualProjectionLossFused: render-and-compare beside the point search (see there)
 SAME_VIEW_SPLIT = True   # ... and, for the same-view pairs only, the compare on those pairs alone (see there)
+# The side stream and its 'projection done' event are kept per (device, caller's stream): two callers on different
+# streams of one device (two training loops in one process) get a side stream and an event each, so neither orders the
+# other's work.  One caller stream = one pair, reused call after call (creating them costs ~20 us).
 _SIDE = {}
 
 
+def _side_key(dev):
+    d = dev.index if dev.index is not None else _cur_device()
+    return (d, _raw_stream(d))
+
+
 def _side_stream(dev):
-    k = dev.index if dev.index is not None else _cur_device()
+    k = _side_key(dev)
     if k not in _SIDE:
         _SIDE[k] = torch.cuda.Stream(device=dev)
     return _SIDE[k]
@@ -277,8 +285,8 @@ _SIDE_EVENT = {}
 
 
 def _side_event(dev):
-    """One reusable event per device for the 'projection done' edge between the two streams."""
-    k = dev.index if dev.index is not None else _cur_device()
+    """One reusable event per (device, caller's stream) for the 'projection done' edge between the two streams."""
+    k = _side_key(dev)
     if k not in _SIDE_EVENT:
         _SIDE_EVENT[k] = torch.cuda.Event()
     return _SIDE_EVENT[k]
@@ -476,7 +484,9 @@ class MutualProjectionLossFused(torch.autograd.Function):
                                                      p_sse, p_gsp, s_main), "shr_sphere_raster_mse")
             if two_step:
                 ws = points_ws
-                if is_mv and order is not None:
+                # (ordered: workgroup = crop; with several parts per crop blockIdx.x = crop * parts + part and the XCD
+                # placement the order was built for no longer holds -- the batch's own order then)
+                if is_mv and order is not None and Rd == 1:
                     _lib.check(lib.shr_data_to_model_from_points_ordered(_ptr(ws), int(observed.shape[0]), _ptr(order_target),
                                                                          _ptr(order), _ptr(spheres), 4, _ptr(radii), E, J, H, W,
                                                                          Rd, p_d2m, p_gd2m, s_d2m), "shr_data_to_model_from_points_ordered")
@@ -485,6 +495,9 @@ class MutualProjectionLossFused(torch.autograd.Function):
                                                                          _ptr(spheres), 4, _ptr(radii), E, J, H, W, Rd, p_d2m,
                                                                          p_gd2m, s_d2m), "shr_data_to_model_from_points")
                 if overlap:
+                    # the join: everything the side stream wrote into `scratch` / read from `spheres` is ordered before
+                    # the assembly kernel on the caller's stream -- and before the caching allocator can hand either
+                    # block to a later allocation of that stream (which is why no record_stream() is needed)
                     main.wait_stream(side)
             else:
                 cen = spheres if is_mv else spheres.index_select(0, diag_index.long())

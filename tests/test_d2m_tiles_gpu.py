@@ -543,6 +543,7 @@ def test_xcd_aware_launch_order_gives_the_same_bits(S, B, lean):
     ds = SyntheticMultiviewDataset(mesh, B, S, seed=13, device="cuda")
     ordered, plain = MutualProjectionLoss(S, mesh).cuda(), MutualProjectionLoss(S, mesh).cuda()
     ordered.return_projections = plain.return_projections = not lean
+    ordered.xcd_order_min_crops = 0                         # (the module orders stacks of >= 512 crops only)
     cam, inv, dms = ds.cam.cuda(), ds.inv_cam.cuda(), ds.dms.cuda()
     plain._indices(B, 3, cam.device)
     plain._order = plain._order_target = None               # the batch's own launch order
