@@ -288,6 +288,49 @@ int shr_heatmap_paint(const float *uvd, int BJ, int S, float sigma, float uv_sca
 int shr_depth_noise(const float *depth, const float *normal3, int B, int H, int W,
                     float sigma_xy, float sigma_z, float *out, void *stream);
 
+/* HandSynthesizer.forward (network/util_modules.py:104-122) as THREE launches, capturable in a hipGraph -- no host
+ * random numbers, no torch launches in between:
+ *   shr_synth_pose_fwd        forward kinematics (shr_fk_fwd) + RandScale (mesh/pointTransformation.py:128-148:
+ *                             diag(s) T, s_k = rand * rand_scale + 0.90 - rand_scale / 2) + the sample's draws
+ *                             draws[6][B] = s_x, s_y, s_z, the focal jitter rand * 0.2 + 0.9 (:110), and the two uint32
+ *                             keys of the sample's pixel-noise stream (as float bits);
+ *   shr_mesh_render_post_fwd  DepthRender (shr_mesh_render_fwd) + `* depth_scale` + DepthNoise (:46-84) in the
+ *                             rasterizer's epilogue; advances the generator's call counter;
+ *   shr_heatmap_render_fwd    Hand3DHeatmapRender (mesh/render.py:274-279): key-point skinning + heat-map camera
+ *                             (shr_lbs_project on the key-point CSR table kp_start[J+1], kp_bone, kp_wv) + shr_heatmap_paint.
+ * Random numbers: rng_state[3] = (seed, call counter, ticket) in device memory; a draw is a hash of (seed, counter, sample,
+ * word) and, per pixel, of (sample key, pixel index) -- csrc/common.h rng_*, restated in numpy by
+ * spherehand_amd/synth_rng.py.  Parity with the reference's torch generator is in distribution (as for any RNG-
+ * dependent step); with the noise off and the same draws the images are the reference chain's bit for bit. */
+int shr_synth_pose_fwd(const float *params, int B, const float *offset, const float *offset_inv,
+                       const unsigned long long *rng_state, float rand_scale, float *T, float *draws, void *stream);
+int shr_mesh_render_post_fwd(const float *T, int B, int NB, int NV, const int32_t *skin_vertex_start,
+                             const int32_t *skin_bone, const float *skin_wv, int right_hand, float cx, float cy,
+                             float fx, float fy, const float *rand_f, const int32_t *faces, int F, int src_size,
+                             int S, float clamp_max, float depth_scale, const uint32_t *noise_keys,
+                             float sigma_xy, float sigma_z, unsigned long long *rng_state, float *vertices_ws,
+                             float *depth_ws, float *depth, void *stream);
+int shr_mesh_render_one_launch(int NB, int NV, int F, int src_size, int S);   /* 1: no workspaces needed by the two above */
+/* ... and as ONE launch where shr_hand_synth_one_launch() returns 1 (integer resize ratio with a lattice of at most
+ * 128 x 128 sampled pixels -- S = 128, 64, 32 from 640 --, NB = 17, J <= 64 key-points, a power-of-two heat-map side):
+ * every workgroup runs its crop's forward kinematics + RandScale + draws, skins, rasterizes, scales, noises and paints its
+ * heat-maps.  The same bits as the three entries above.  rng_state: uint64 [3] = (seed, call counter, ticket = 0 between
+ * launches); noise: 0 / 1; uv_hm = NULL: depth only.  draws[6][B] receives the samples' draws. */
+int shr_hand_synth_one_launch(int NB, int NV, int F, int src_size, int S, int J, int hm);
+int shr_hand_synth_fwd(const float *params, int B, const float *offset, const float *offset_inv,
+                       unsigned long long *rng_state, float rand_scale, int NV,
+                       const int32_t *skin_vertex_start, const int32_t *skin_bone, const float *skin_wv,
+                       int right_hand, float cx, float cy, float fx, float fy, const int32_t *faces, int F,
+                       int src_size, int S, float clamp_max, float depth_scale, int noise, float sigma_xy,
+                       float sigma_z, int J, const int32_t *kp_start, const int32_t *kp_bone, const float *kp_wv,
+                       int hm, float hcx, float hcy, float hfx, float hfy, float hm_sigma, float uv_scale,
+                       float d_scale, float a00, float a03, float a11, float a13, float *draws, float *depth,
+                       float *uv_hm, float *d_hm, float *xyz, void *stream);
+int shr_heatmap_render_fwd(const float *T, int B, int NB, int J, const int32_t *kp_start, const int32_t *kp_bone,
+                           const float *kp_wv, int right_hand, float cx, float cy, float fx, float fy,
+                           const float *rand_f, int S, float sigma, float uv_scale, float d_scale, float a00,
+                           float a03, float a11, float a13, float *uv_hm, float *d_hm, float *xyz, void *stream);
+
 /* y = relu(GroupNorm(x)) for channels-last (NHWC) fp32 activations x[N][HW][C], forward and
  * backward: the `F.relu(self.bnK(x))` pairs of network/hourglass.py:28-31 without the NCHW
  * round trips of torch's GroupNorm.  G groups of C/G consecutive channels, biased variance,

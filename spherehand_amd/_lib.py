@@ -15,7 +15,7 @@ import torch  # noqa: F401  (device memory, streams: the plumbing this library s
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_PKG, "libspherehand_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -54,6 +54,15 @@ SIGNATURES = {
                              _vp, _vp, _vp], _i),
     "shr_heatmap_paint": ([_vp, _i, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp], _i),
     "shr_depth_noise": ([_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp], _i),
+    "shr_synth_pose_fwd": ([_vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp], _i),
+    "shr_mesh_render_post_fwd": ([_vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _i, _i, _i, _f, _f, _vp, _f, _f,
+                                 _vp, _vp, _vp, _vp, _vp], _i),
+    "shr_mesh_render_one_launch": ([_i, _i, _i, _i, _i], _i),
+    "shr_hand_synth_one_launch": ([_i, _i, _i, _i, _i, _i, _i], _i),
+    "shr_hand_synth_fwd": ([_vp, _i, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _i, _i, _i, _f, _f, _i, _f, _f,
+                           _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "shr_heatmap_render_fwd": ([_vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _vp, _vp,
+                               _vp, _vp], _i),
     "shr_group_norm_relu_supported": ([_i, _i], _i),
     "shr_group_norm_relu_fwd": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp], _i),
     "shr_group_norm_relu_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),

@@ -3,7 +3,7 @@
 
 #include "sphere_zbuf.h"
 
-extern "C" int shr_abi_version(void) { return 21; }
+extern "C" int shr_abi_version(void) { return 22; }
 
 extern "C" const char *shr_error_string(int code) {
   switch (code) {

@@ -283,6 +283,49 @@ __device__ __forceinline__ int run_of(int incl, bool mine, int k0, int k) {
 
 __device__ __forceinline__ bool is_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// ---- counter-based random numbers of the synthetic branch (HandSynthesizer: RandScale, focal jitter, DepthNoise) --------
+// No state is carried between draws: a draw is a HASH of what it is for, so any launch geometry -- and a numpy
+// restatement (spherehand_amd/synth_rng.py) -- produces the same numbers.
+//   rng_hash        lowbias32 (C. Wellons' hash-prospector: xorshift-multiply, 2 rounds; bias 0.17 of an ideal hash)
+//   rng_key         the stream word k of sample b in call `ctr` under `seed`: a chain of rng_hash over the six words
+//   rng_uniform     the top 24 bits as a float in [0, 1) -- torch.rand's float32 construction
+//   pixel p of a sample's noise field: h1 = rng_hash(key0 + p), h2 = rng_hash(key1 + p)  (mesh_depth.hip / synth_post.hip)
+__host__ __device__ inline uint32_t rng_hash(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ inline uint32_t rng_key(unsigned long long seed, unsigned long long ctr, uint32_t b, uint32_t k) {
+  uint32_t h = rng_hash((uint32_t)seed ^ 0x9e3779b9u);
+  h = rng_hash(h ^ (uint32_t)(seed >> 32));
+  h = rng_hash(h ^ (uint32_t)ctr);
+  h = rng_hash(h ^ (uint32_t)(ctr >> 32) ^ 0x85ebca6bu);
+  h = rng_hash(h ^ b);
+  return rng_hash(h ^ (k + 0x27d4eb2fu));
+}
+__host__ __device__ inline float rng_uniform(uint32_t h) { return (float)(h >> 8) * 5.9604644775390625e-8f; }   // 2^-24
+
+// DepthNoise (network/util_modules.py:46-84) on pixel `p` of a sample whose stream keys are (key0, key1):
+//   shift per axis  trunc(n * sigma_xy + 0.5), n ~ N(0, 1): a 16-bit uniform against the three cumulative thresholds
+//                   thr = (P(shift < 0), P(shift < 1), P(shift < 2)) x 65536 -- shifts -1 .. +2; what lies beyond them
+//                   (3e-7 at the reference's sigma 0.5) is folded into the outer two.  x: h1's high half, y: its low half.
+//   depth noise     Box-Muller on h2's halves: sqrt(-2 ln u1) cos(2 pi u2), u1 = (hi + 0.5) / 65536, u2 = lo / 65536.
+struct NoiseShift { int dx, dy; };
+__device__ __forceinline__ NoiseShift noise_shift(uint32_t key0, uint32_t p, uint32_t t0, uint32_t t1, uint32_t t2) {
+  const uint32_t h = rng_hash(key0 + p);
+  const uint32_t ux = h >> 16, uy = h & 0xffffu;
+  NoiseShift s;
+  s.dx = -1 + (int)(ux >= t0) + (int)(ux >= t1) + (int)(ux >= t2);
+  s.dy = -1 + (int)(uy >= t0) + (int)(uy >= t1) + (int)(uy >= t2);
+  return s;
+}
+__device__ __forceinline__ float noise_normal(uint32_t key1, uint32_t p) {
+  const uint32_t h = rng_hash(key1 + p);
+  const float u1 = ((float)(h >> 16) + 0.5f) * 1.52587890625e-5f;    // (0, 1)
+  const float u2 = (float)(h & 0xffffu) * 1.52587890625e-5f;         // [0, 1): v_cos_f32 takes revolutions
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // -2 ln 2 * log2(u1)
+  return r * __builtin_amdgcn_cosf(u2);
+}
+
 // ---- host side: what a launcher caches PER DEVICE -------------------------------------------------------------------
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device function attribute and the CU count a per-device number:
 // a process that launches on a second GPU must set / read them there too (ops._on() may launch on a non-current device).

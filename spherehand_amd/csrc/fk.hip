@@ -25,111 +25,29 @@
 // entries, including its diagonal d = (1 - c) + c on the axis (:40-52), so the result is the reference's up to the
 // association of the sums (FMAs here; the reference's own bmm order is the library's): <= 1e-4 mm from the
 // reference's fp32 T on entries up to 150, 3e-5 from the fp64 value (the reference itself: 1e-4).
-#include "common.h"
+#include "fk_rows.h"
 
 namespace shr {
 
-// u * M for an affine M with rows m0, m1, m2 (and an implied 0 0 0 1): u = (r0, r1, r2, t)
-__device__ __forceinline__ float4 row_times(const float4 u, const float4 m0, const float4 m1, const float4 m2) {
-  float4 o;
-  o.x = __builtin_fmaf(u.z, m2.x, __builtin_fmaf(u.y, m1.x, u.x * m0.x));
-  o.y = __builtin_fmaf(u.z, m2.y, __builtin_fmaf(u.y, m1.y, u.x * m0.y));
-  o.z = __builtin_fmaf(u.z, m2.z, __builtin_fmaf(u.y, m1.z, u.x * m0.z));
-  o.w = __builtin_fmaf(u.z, m2.w, __builtin_fmaf(u.y, m1.w, u.x * m0.w)) + u.w;
-  return o;
-}
-// its adjoint: u_bar given o_bar
-__device__ __forceinline__ float4 row_times_adj(const float4 ob, const float4 m0, const float4 m1, const float4 m2) {
-  float4 u;
-  u.x = __builtin_fmaf(ob.w, m0.w, __builtin_fmaf(ob.z, m0.z, __builtin_fmaf(ob.y, m0.y, ob.x * m0.x)));
-  u.y = __builtin_fmaf(ob.w, m1.w, __builtin_fmaf(ob.z, m1.z, __builtin_fmaf(ob.y, m1.y, ob.x * m1.x)));
-  u.z = __builtin_fmaf(ob.w, m2.w, __builtin_fmaf(ob.z, m2.z, __builtin_fmaf(ob.y, m2.y, ob.x * m2.x)));
-  u.w = ob.w;
-  return u;
-}
-
-// (sin, cos, (1 - cos) + cos) of one angle: the three numbers the reference's axis-aligned rotation matrix holds
-struct Rot { float s, c, d; };
-
-// u * R for the reference's rotation about +x: R = [[d,0,0],[0,c,-s],[0,s,c]] (AxisRotationMatrix with axis 1 0 0)
-__device__ __forceinline__ float4 rot_x(const float4 u, const Rot r) {
-  return make_float4(u.x * r.d, __builtin_fmaf(u.z, r.s, u.y * r.c), __builtin_fmaf(u.z, r.c, -(u.y * r.s)), u.w);
-}
-__device__ __forceinline__ float4 rot_x_adj(const float4 ob, const Rot r) {
-  return make_float4(ob.x * r.d, __builtin_fmaf(-ob.z, r.s, ob.y * r.c), __builtin_fmaf(ob.z, r.c, ob.y * r.s), ob.w);
-}
-__device__ __forceinline__ float rot_x_dangle(const float4 ob, const float4 out) { return ob.y * out.z - ob.z * out.y; }
-// about +z: R = [[c,-s,0],[s,c,0],[0,0,d]]
-__device__ __forceinline__ float4 rot_z(const float4 u, const Rot r) {
-  return make_float4(__builtin_fmaf(u.y, r.s, u.x * r.c), __builtin_fmaf(u.y, r.c, -(u.x * r.s)), u.z * r.d, u.w);
-}
-__device__ __forceinline__ float4 rot_z_adj(const float4 ob, const Rot r) {
-  return make_float4(__builtin_fmaf(-ob.y, r.s, ob.x * r.c), __builtin_fmaf(ob.y, r.c, ob.x * r.s), ob.z * r.d, ob.w);
-}
-__device__ __forceinline__ float rot_z_dangle(const float4 ob, const float4 out) { return ob.x * out.y - ob.y * out.x; }
-// about +y: R = [[c,0,s],[0,d,0],[-s,0,c]]
-__device__ __forceinline__ float4 rot_y(const float4 u, const Rot r) {
-  return make_float4(__builtin_fmaf(-u.z, r.s, u.x * r.c), u.y * r.d, __builtin_fmaf(u.z, r.c, u.x * r.s), u.w);
-}
-__device__ __forceinline__ float4 rot_y_adj(const float4 ob, const Rot r) {
-  return make_float4(__builtin_fmaf(ob.z, r.s, ob.x * r.c), ob.y * r.d, __builtin_fmaf(ob.z, r.c, -(ob.x * r.s)), ob.w);
-}
-__device__ __forceinline__ float rot_y_dangle(const float4 ob, const float4 out) { return ob.z * out.x - ob.x * out.z; }
-
-// The abduction axis is +z for fingers 0, 1, 4 and -y for fingers 2, 3 (:162-164).  About -y the matrix is
-// [[c,0,-s],[0,d,0],[s,0,c]] = the +z form with the y and z components exchanged on both sides.
-__device__ __forceinline__ float4 swap_yz(const float4 u, bool on) { return on ? make_float4(u.x, u.z, u.y, u.w) : u; }
-
-__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-
-constexpr int kBones = 17;
-constexpr int kAngles = 23;          // palm Euler angles + 5 x 4 finger angles
-constexpr int kMaxPoints = 128;      // key-points the one-launch backward stages per sample (the hand has 41)
-
-// One sample's sincos table: lanes 0..22 take one angle each.
-__device__ __forceinline__ void sincos_phase(const float *__restrict__ p, int lane, Rot *sc) {
-  if (lane < kAngles) {
-    const float a = p[lane < 3 ? lane : lane + 3];
-    float s, c;
-    sincosf(a, &s, &c);
-    Rot r;
-    r.s = s;
-    r.c = c;
-    r.d = (1.0f - c) + c;            // xx * i + c with xx = 1, i = 1 - c (:37-41)
-    sc[lane] = r;
-  }
-}
-
-// Row i of the palm transform P = Trans * (Rz * (Ry * Rx)) (:148-152) as a row chain: e_i * Rz, * Ry, * Rx.
-struct PalmRow { float4 a, b, r; };   // after Rz, Ry, Rx (r.w = the translation)
-__device__ __forceinline__ PalmRow palm_row(int i, const Rot rx, const Rot ry, const Rot rz, float t) {
-  PalmRow o;
-  o.a = i == 0 ? make_float4(rz.c, -rz.s, 0.f, 0.f) : i == 1 ? make_float4(rz.s, rz.c, 0.f, 0.f) : make_float4(0.f, 0.f, rz.d, 0.f);
-  o.b = rot_y(o.a, ry);
-  o.r = rot_x(o.b, rx);
-  o.r.w = t;
-  return o;
-}
-
-// The (I, O) rows of a finger's three bones, one lane's copy (the lanes of a finger read the same addresses)
-struct BoneConst { float4 i0, i1, i2, o0, o1, o2; };
-__device__ __forceinline__ BoneConst load_bone(const float *__restrict__ offset, const float *__restrict__ offset_inv, int nb) {
-  BoneConst k;
-  k.i0 = ld4(offset_inv + 16 * nb);     k.i1 = ld4(offset_inv + 16 * nb + 4); k.i2 = ld4(offset_inv + 16 * nb + 8);
-  k.o0 = ld4(offset + 16 * nb);         k.o1 = ld4(offset + 16 * nb + 4);     k.o2 = ld4(offset + 16 * nb + 8);
-  return k;
-}
-
 // ---- forward -----------------------------------------------------------------------------------------------
 // One wave per sample.  WANT_T: write T[b] (17 x 4 x 4).  WANT_SPH: the key-point records too (T stays in LDS).
-template <bool WANT_T, bool WANT_SPH>
+template <bool WANT_T, bool WANT_SPH, bool SYNTH = false>
 __global__ void __launch_bounds__(64)
 pose_fwd_kernel(const float *__restrict__ params, const float *__restrict__ offset, const float *__restrict__ offset_inv,
                 float *__restrict__ T, const int *__restrict__ bone, const float4 *__restrict__ wv,
-                const float *__restrict__ radii, float sx, int J, float4 *__restrict__ spheres) {
+                const float *__restrict__ radii, float sx, int J, float4 *__restrict__ spheres, SynthDraws syn) {
   __shared__ Rot sc[kAngles];
   __shared__ float4 rows[kBones * 3];
+  __shared__ float s_scale[4];
   const int b = blockIdx.x, lane = threadIdx.x;
+  if (SYNTH && lane < 6) {
+    const uint32_t h = rng_key(syn.state[0], syn.state[1], (uint32_t)b, (uint32_t)lane);
+    float val = __uint_as_float(h);                                                   // lanes 4, 5: stream keys, as bits
+    if (lane < 3) val = (rng_uniform(h) * syn.rand_scale + 0.90f) - syn.rand_half;
+    if (lane == 3) val = rng_uniform(h) * 0.2f + 0.9f;
+    syn.draws[(size_t)lane * syn.B + b] = val;
+    if (lane < 3) s_scale[lane] = val;
+  }
   const int g = lane >> 2, i = lane & 3;
   const float *p = params + (size_t)b * 26;
   const bool chain = lane < 24 && i < 3, finger = chain && g < 5;
@@ -153,11 +71,14 @@ pose_fwd_kernel(const float *__restrict__ params, const float *__restrict__ offs
   sincos_phase(p, lane, sc);
   __syncthreads();
   float4 *Tb = reinterpret_cast<float4 *>(T + (size_t)b * kBones * 16);
+  // SYNTH: every entry of row i times s_i -- one fp32 multiply, the module's `transform_mats * diag` (T only)
+  const float si = (SYNTH && chain) ? s_scale[i] : 1.0f;
+  auto scaled = [&](const float4 r) { return SYNTH ? make_float4(r.x * si, r.y * si, r.z * si, r.w * si) : r; };
   if (chain) {
     const PalmRow P = palm_row(i, sc[0], sc[1], sc[2], t);
     if (!finger) {                     // bones 0 and 1 both carry the palm transform (:153-155)
       if (WANT_SPH) rows[i] = rows[3 + i] = P.r;
-      if (WANT_T) Tb[i] = Tb[4 + i] = P.r;
+      if (WANT_T) Tb[i] = Tb[4 + i] = scaled(P.r);
     } else {
       const int a0 = 3 + 4 * g;        // sincos slot of the finger's first angle (parameter 6 + 4 g)
       const bool yaxis = g == 2 || g == 3;
@@ -173,7 +94,7 @@ pose_fwd_kernel(const float *__restrict__ params, const float *__restrict__ offs
         rows[3 * b0 + i] = G1; rows[3 * b0 + 3 + i] = G2; rows[3 * b0 + 6 + i] = G3;
       }
       if (WANT_T) {
-        Tb[4 * b0 + i] = G1; Tb[4 * b0 + 4 + i] = G2; Tb[4 * b0 + 8 + i] = G3;
+        Tb[4 * b0 + i] = scaled(G1); Tb[4 * b0 + 4 + i] = scaled(G2); Tb[4 * b0 + 8 + i] = scaled(G3);
       }
     }
   } else if (WANT_T && lane < 24) {    // i == 3: the homogeneous rows of the group's bones
@@ -374,7 +295,23 @@ extern "C" int shr_fk_fwd(const float *params, int B, const float *offset, const
   if (!T || (((uintptr_t)T) & 15u) != 0) return SHR_EINVAL;
   if (int rc = fk_check(params, B, offset, offset_inv)) return rc;
   hipLaunchKernelGGL((pose_fwd_kernel<true, false>), dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, params, offset,
-                     offset_inv, T, nullptr, nullptr, nullptr, 1.0f, 0, nullptr);
+                     offset_inv, T, nullptr, nullptr, nullptr, 1.0f, 0, nullptr, SynthDraws{});
+  return (int)hipGetLastError();
+}
+
+/* The head of HandSynthesizer.forward (network/util_modules.py:104-110) in one launch: forward kinematics, RandScale
+ * and the sample's random draws (kernel comment above; generator: common.h). */
+extern "C" int shr_synth_pose_fwd(const float *params, int B, const float *offset, const float *offset_inv,
+                                  const unsigned long long *rng_state, float rand_scale, float *T, float *draws,
+                                  void *stream) {
+  using namespace shr;
+  if (B == 0) return SHR_OK;
+  if (!T || !draws || !rng_state || (((uintptr_t)T) & 15u) != 0 || (((uintptr_t)rng_state) & 7u) != 0) return SHR_EINVAL;
+  if (int rc = fk_check(params, B, offset, offset_inv)) return rc;
+  SynthDraws syn;
+  syn.state = rng_state; syn.rand_scale = rand_scale; syn.rand_half = (float)((double)rand_scale / 2.0); syn.draws = draws; syn.B = B;
+  hipLaunchKernelGGL((pose_fwd_kernel<true, false, true>), dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, params, offset,
+                     offset_inv, T, nullptr, nullptr, nullptr, 1.0f, 0, nullptr, syn);
   return (int)hipGetLastError();
 }
 
@@ -402,11 +339,11 @@ extern "C" int shr_pose_spheres_fwd(const float *params, int B, const float *off
   if (T)
     hipLaunchKernelGGL((pose_fwd_kernel<true, true>), dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, params, offset,
                        offset_inv, T, bone, reinterpret_cast<const float4 *>(wv), radii, sx, J,
-                       reinterpret_cast<float4 *>(spheres));
+                       reinterpret_cast<float4 *>(spheres), SynthDraws{});
   else
     hipLaunchKernelGGL((pose_fwd_kernel<false, true>), dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, params, offset,
                        offset_inv, nullptr, bone, reinterpret_cast<const float4 *>(wv), radii, sx, J,
-                       reinterpret_cast<float4 *>(spheres));
+                       reinterpret_cast<float4 *>(spheres), SynthDraws{});
   return (int)hipGetLastError();
 }
 

@@ -22,7 +22,7 @@
 // sampled pixel (an exactly zero 1/z denominator), where the reference's 0 * -inf is NaN.
 #include <cstdlib>
 
-#include "common.h"
+#include "fk_rows.h"
 
 namespace shr {
 
@@ -496,10 +496,57 @@ struct LatticeSkin {
   float cx, cy, fx, fy;
 };
 
-template <int SL, int kLatWaves, int kLatFaces, bool SKIN = false>
+// POST (shr_mesh_render_post_fwd: HandSynthesizer.forward's `* depth_scale` and DepthNoise, network/util_modules.py:112-116,
+// :46-84, in the epilogue): the crop's whole lattice is in this workgroup's LDS, so output pixel (v, u) of the noised
+// image -- the scaled image's pixel (v + dy, u + dx), clamped to the image, plus depth noise where that is foreground --
+// is evaluated straight from the lattice; the draws come from the counter-based generator of common.h, keyed per
+// sample (keys[2][B], drawn by shr_synth_pose_fwd) and per pixel.
+struct LatticePost {
+  float depth_scale;
+  const uint32_t *keys;          // [2][B], or nullptr: no noise
+  uint32_t t0, t1, t2;           // the shift's cumulative thresholds (common.h noise_shift)
+  float sigma_z;
+  unsigned long long *state;     // the generator's (seed, call counter, ticket), or nullptr: the counter is advanced here, by
+  int B;                         // the launch that consumes the call's last draws -- by its LAST workgroup to finish
+  // ONE-LAUNCH synthesizer (shr_hand_synth_fwd): params != nullptr -> the workgroup's first wave runs the crop's forward
+  // kinematics + RandScale + draws (fk_rows.h) into LDS instead of reading T; uv_hm != nullptr -> the crop's heat-maps
+  // (Hand3DHeatmapRender: key-point skinning + heat-map camera + paint, synth_post.hip's arithmetic) in the epilogue
+  const float *params, *offset, *offset_inv;
+  float rand_scale, rand_half;
+  float *draws;                  // [6][B]
+  const int *kp_start, *kp_bone;
+  const float4 *kp_wv;
+  int J, hm_shift;               // key-points (<= 64); log2 of the heat-map's side
+  float hcx, hcy, hfx, hfy, hsigma, uv_scale, d_scale, a00, a03, a11, a13;
+  float *uv_hm, *d_hm;
+  float4 *xyz;
+};
+
+// the same tail for images that are in HBM already (sizes the lattice kernel does not take): same draws, same bits
+__global__ void __launch_bounds__(256)
+depth_post_kernel(const float *__restrict__ in, int B, int H, int W, LatticePost post, float *__restrict__ out) {
+  const int b = blockIdx.y;
+  const float *src = in + (size_t)b * H * W;
+  const bool noise = post.keys != nullptr;
+  const uint32_t key0 = noise ? post.keys[b] : 0u, key1 = noise ? post.keys[post.B + b] : 0u;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+    int v = i / W, u = i - v * W;
+    if (noise) {
+      const NoiseShift sh = noise_shift(key0, (uint32_t)i, post.t0, post.t1, post.t2);
+      v = min(max(v + sh.dy, 0), H - 1);
+      u = min(max(u + sh.dx, 0), W - 1);
+    }
+    float z = src[(size_t)v * W + u] * post.depth_scale;
+    if (noise && z < 1.0f) z = z + noise_normal(key1, (uint32_t)i) * post.sigma_z;
+    out[(size_t)b * H * W + i] = z;
+  }
+  if (post.state && blockIdx.x == 0 && b == 0 && threadIdx.x == 0) post.state[1] += 1ull;
+}
+
+template <int SL, int kLatWaves, int kLatFaces, bool SKIN = false, bool POST = false>
 __global__ void __launch_bounds__(kLatWaves * 64)
 mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__ faces, int NV, int F, int src, int S,
-                    float clamp_max, float *__restrict__ depth, LatticeSkin skin) {
+                    float clamp_max, float *__restrict__ depth, LatticeSkin skin, LatticePost post) {
   static_assert(kLatFaces == 32 || kLatFaces == 64, "queue entries: 5 or 6 bits of face");
   constexpr int kFaceBits = kLatFaces == 64 ? 6 : 5;
   extern __shared__ __attribute__((aligned(16))) unsigned char lat_smem[];
@@ -509,7 +556,11 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
   uint16_t *s_surv = reinterpret_cast<uint16_t *>(lat_smem + zbytes);        // the surviving faces' numbers
   unsigned char *s_scr = lat_smem + zbytes + (size_t)((F + 7) & ~7) * 2;
   __shared__ int s_nsurv;
+  __shared__ Rot s_sc[POST ? kAngles : 1];         // (one-launch synthesizer: the FK wave's sincos table, the sample's draws,
+  __shared__ float s_draw[POST ? 8 : 1];           //  the key-points in the heat-map's camera)
+  __shared__ float4 s_kp[POST ? 64 : 1];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool own_pose = POST && post.params != nullptr, paint = POST && post.uv_hm != nullptr;
   float4 *s_verts = reinterpret_cast<float4 *>(s_scr + (size_t)kLatWaves * lat_scratch_bytes(kLatFaces));   // SKIN: [NV]
   const float4 *verts = SKIN ? s_verts : vertices + (size_t)b * NV;
   MESH_STAMP(0);
@@ -541,9 +592,17 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
       e0[j] = v < NV ? skin.vstart[v] : 0;
       e1[j] = v < NV ? skin.vstart[v + 1] : 0;
     }
-    for (int i = tid; i < skin.NB * 16; i += kLatWaves * 64) s_T[i] = skin.T[(size_t)b * skin.NB * 16 + i];
-    const bool has_rand = skin.rand_f != nullptr;
-    const float rf = has_rand ? skin.rand_f[b] : 0.f;
+    if (own_pose) {
+      if (wave == 0) {      // pose -> diag(s) T straight into the LDS copy (NB = 17: the hand's bones)
+        SynthDraws syn;
+        syn.state = post.state; syn.rand_scale = post.rand_scale; syn.rand_half = post.rand_half; syn.draws = post.draws; syn.B = post.B;
+        pose_transforms_wave<true>(post.params, post.offset, post.offset_inv, b, lane, s_sc, s_draw, reinterpret_cast<float4 *>(s_T), syn);
+      }
+    } else {
+      for (int i = tid; i < skin.NB * 16; i += kLatWaves * 64) s_T[i] = skin.T[(size_t)b * skin.NB * 16 + i];
+    }
+    const bool has_rand = own_pose || skin.rand_f != nullptr;
+    float rf = (!own_pose && has_rand) ? skin.rand_f[b] : 0.f;
 #pragma unroll
     for (int j = 0; j < kVerts; j++)
 #pragma unroll
@@ -553,6 +612,12 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
         q_a[j][k] = on ? skin.swv[e0[j] + k] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     __syncthreads();
+    if (own_pose) rf = s_draw[3];
+    if (paint && tid < post.J) {       // the crop's key-points in the heat-map's camera (lbs_project_kernel's arithmetic)
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int e = post.kp_start[tid]; e < post.kp_start[tid + 1]; e++) lbs_add_entry(acc, s_T + post.kp_bone[e] * 16, post.kp_wv[e]);
+      s_kp[tid] = lbs_finish(acc, skin.right_hand, 1, post.hcx, post.hcy, post.hfx, post.hfy, has_rand, rf);
+    }
 #pragma unroll
     for (int j = 0; j < kVerts; j++) {
       const int v = tid + j * kLatWaves * 64;
@@ -765,6 +830,75 @@ mesh_lattice_kernel(const float4 *__restrict__ vertices, const int *__restrict__
 
   // ---- 3. clamp + bilinear (mesh/render.py:286, :311; ATen upsample_bilinear2d) -----------------------------------
   float *out = depth + (size_t)b * S * S;
+  if (POST) {
+    // the module's pixel (oy, ox) before the noise: clamp, ATen's bilinear formula, * depth_scale (one fp32 multiply)
+    const float scale = (float)src / (float)S;
+    auto value = [&](int oy, int ox) -> float {
+      if (SL == 1) return fminf(mkey_inv(s_z[oy * LP + ox]), clamp_max) * post.depth_scale;
+      const Lin lx = lin_index(ox, scale, src), ly = lin_index(oy, scale, src);
+      float v[2][2];
+#pragma unroll
+      for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+        for (int sx = 0; sx < 2; sx++) v[sy][sx] = fminf(mkey_inv(s_z[(2 * oy + sy) * LP + 2 * ox + sx]), clamp_max);
+      return (ly.l0 * (lx.l0 * v[0][0] + lx.l1 * v[0][1]) + ly.l1 * (lx.l0 * v[1][0] + lx.l1 * v[1][1])) * post.depth_scale;
+    };
+    // (one launch: the keys are this workgroup's own draws; post.keys then only says "noise on")
+    const bool noise = post.keys != nullptr;
+    const uint32_t key0 = !noise ? 0u : (own_pose ? __float_as_uint(s_draw[4]) : post.keys[b]);
+    const uint32_t key1 = !noise ? 0u : (own_pose ? __float_as_uint(s_draw[5]) : post.keys[post.B + b]);
+    auto pixel = [&](int i, int oy, int ox) -> float {
+      if (noise) {
+        const NoiseShift sh = noise_shift(key0, (uint32_t)i, post.t0, post.t1, post.t2);
+        oy = min(max(oy + sh.dy, 0), S - 1);
+        ox = min(max(ox + sh.dx, 0), S - 1);
+      }
+      float z = value(oy, ox);
+      if (noise && z < 1.0f) z = z + noise_normal(key1, (uint32_t)i) * post.sigma_z;
+      return z;
+    };
+    if ((S & 3) == 0) {
+      typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+      for (int i = tid; i < S * S / 4; i += kLatWaves * 64) {
+        const int oy = i / (S / 4), ox = (i - oy * (S / 4)) * 4;
+        v4u_t v;
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[c] = __float_as_uint(pixel(4 * i + c, oy, ox + c));
+        float *dst = out + (size_t)oy * S + ox;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+      }
+    } else {
+      for (int i = tid; i < S * S; i += kLatWaves * 64) {
+        const int oy = i / S;
+        out[i] = pixel(i, oy, i - oy * S);
+      }
+    }
+    if (paint) {
+      // HeatmapRender.forward (mesh/render.py:226-248) for the crop's J maps, element e = j * hm^2 + pixel: coalesced stores
+      const int sh = 2 * post.hm_shift, npx = 1 << sh, hm = 1 << post.hm_shift;
+      float *uo = post.uv_hm + (size_t)b * post.J * npx, *dout = post.d_hm + (size_t)b * post.J * npx;
+      for (int e = tid; e < post.J * npx; e += kLatWaves * 64) {
+        const float4 p = s_kp[e >> sh];
+        const int i = e & (npx - 1), v = i >> post.hm_shift, u = i & (hm - 1);
+        const float du = (float)u - p.x, dv = (float)v - p.y;
+        const float g = __expf(-0.5f * post.hsigma * (du * du + dv * dv));
+        uo[e] = g * post.uv_scale;
+        dout[e] = (g > 0.05f ? p.z : 0.f) * post.d_scale;
+      }
+      if (tid < post.J) {
+        const float4 p = s_kp[tid];
+        post.xyz[(size_t)b * post.J + tid] = make_float4(post.a00 * p.x + post.a03 * p.w, post.a11 * p.y + post.a13 * p.w, p.z, p.w);
+      }
+    }
+    // the call counter advances when the launch's LAST workgroup is through: every workgroup has read it by then
+    if (post.state && tid == 0) {
+      const unsigned long long done = atomicAdd(&post.state[2], 1ull);
+      if (done == (unsigned long long)(gridDim.x - 1)) {
+        post.state[2] = 0ull;
+        post.state[1] += 1ull;
+      }
+    }
+  } else
   if (SL == 1 && (S & 3) == 0) {
     typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
     for (int i = tid; i < S * S / 4; i += kLatWaves * 64) {
@@ -806,7 +940,8 @@ extern "C" int shr_mesh_debug_timeline(unsigned long long *host_out) {
 // the lattice kernel's launch (vertices: skinned ones in HBM, or nullptr with `skin` for the fused kernel); returns -1
 // when the problem is not the lattice kernel's (non-integer ratio, lattice above 128 x 128, LDS)
 static int mesh_lattice_launch(const float4 *v4, const shr::LatticeSkin *skin, const int32_t *faces, int B, int NV, int F,
-                               int src_size, int S, float clamp_max, float *depth, hipStream_t s) {
+                               int src_size, int S, float clamp_max, float *depth, hipStream_t s,
+                               const shr::LatticePost *post = nullptr) {
   using namespace shr;
   static const int lattice_mode = [] { const char *e = getenv("SHR_MESH_LATTICE"); return e ? atoi(e) : 1; }();   // 0: off, 1: 16 x 32, 2: 12 x 64
   const bool single = (src_size % S == 0) && (((src_size / S) & 1) == 1);
@@ -814,17 +949,23 @@ static int mesh_lattice_launch(const float4 *v4, const shr::LatticeSkin *skin, c
   const int SLx = single ? 1 : 2;
   const int lw = lattice_mode == 2 ? 12 : 16, lf = lattice_mode == 2 ? 64 : 32;
   const size_t lat_lds = lattice_lds_bytes(SLx * S, F, lw, lf, skin ? NV : 0);
-  if (lattice_mode == 0 || !(single || even) || SLx * S > kLatMax || F <= 0 || F > 65535 || lat_lds > 160 * 1024 - 512) return -1;
+  if (lattice_mode == 0 || !(single || even) || SLx * S > kLatMax || F <= 0 || F > 65535 || lat_lds > 160 * 1024 - 2048) return -1;   // (+ the static arrays)
   if (skin && (skin->NB * 64 > lw * lat_scratch_bytes(lf))) return -1;     // (the matrices are staged in the scratch)
-  static AttrDone attr_done[8];   // per (kernel, device)
+  static AttrDone attr_done[10];   // per (kernel, device)
   LatticeSkin sk = {};
   if (skin) sk = *skin;
+  LatticePost po = {};
+  if (post) po = *post;
   auto launch = [&](auto kernel, int which) -> int {
-    const hipError_t e = allow_dynamic_lds(kernel, 160 * 1024 - 512, &attr_done[which]);
+    const hipError_t e = allow_dynamic_lds(kernel, 160 * 1024 - 2048, &attr_done[which]);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(lw * 64), lat_lds, s, v4, faces, NV, F, src_size, S, clamp_max, depth, sk);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)B), dim3(lw * 64), lat_lds, s, v4, faces, NV, F, src_size, S, clamp_max, depth, sk, po);
     return (int)hipGetLastError();
   };
+  if (skin && post) {   // (the synthesizer's launch: the default wave x face shape only)
+    if (lattice_mode == 2) return -1;
+    return single ? launch(mesh_lattice_kernel<1, 16, 32, true, true>, 8) : launch(mesh_lattice_kernel<2, 16, 32, true, true>, 9);
+  }
   if (skin) {
     if (lattice_mode == 2) return single ? launch(mesh_lattice_kernel<1, 12, 64, true>, 6) : launch(mesh_lattice_kernel<2, 12, 64, true>, 7);
     return single ? launch(mesh_lattice_kernel<1, 16, 32, true>, 4) : launch(mesh_lattice_kernel<2, 16, 32, true>, 5);
@@ -897,4 +1038,120 @@ extern "C" int shr_mesh_render_fwd(const float *T, int B, int NB, int NV, const 
                                 vertices_ws, stream);
   if (e != SHR_OK) return e;
   return shr_mesh_depth_fwd(vertices_ws, faces, B, NV, F, src_size, S, clamp_max, depth, stream);
+}
+
+/* 1 where shr_mesh_render_fwd / shr_mesh_render_post_fwd take the problem as ONE launch (no workspaces needed), else 0 */
+extern "C" int shr_mesh_render_one_launch(int NB, int NV, int F, int src_size, int S) {
+  using namespace shr;
+  static const int lattice_mode = [] { const char *e = getenv("SHR_MESH_LATTICE"); return e ? atoi(e) : 1; }();
+  if (lattice_mode != 1 || S <= 0 || src_size <= 0 || src_size % S != 0) return 0;
+  const int SLx = ((src_size / S) & 1) ? 1 : 2;
+  if (SLx * S > kLatMax || F <= 0 || F > 65535) return 0;
+  if (lattice_lds_bytes(SLx * S, F, 16, 32, NV) > 160 * 1024 - 2048 || NB * 64 > 16 * lat_scratch_bytes(32)) return 0;
+  return 1;
+}
+
+/* HandSynthesizer.forward's depth branch (network/util_modules.py:111-116): DepthRender, `* depth_scale` and DepthNoise.
+ * ONE launch where the lattice kernel applies (the tail runs in its epilogue); otherwise shr_mesh_render_fwd into
+ * depth_ws[B,S,S] and the tail as a launch of its own -- the same draws, the same bits.  noise_keys[2][B]: the samples'
+ * stream keys (shr_synth_pose_fwd's draws 4 and 5, as uint32), NULL = no noise.  rng_state: the generator's state whose
+ * call counter this launch advances (NULL: left alone). */
+extern "C" int shr_mesh_render_post_fwd(const float *T, int B, int NB, int NV, const int32_t *skin_vertex_start,
+                                        const int32_t *skin_bone, const float *skin_wv, int right_hand, float cx, float cy,
+                                        float fx, float fy, const float *rand_f, const int32_t *faces, int F, int src_size,
+                                        int S, float clamp_max, float depth_scale, const uint32_t *noise_keys,
+                                        float sigma_xy, float sigma_z, unsigned long long *rng_state, float *vertices_ws,
+                                        float *depth_ws, float *depth, void *stream) {
+  using namespace shr;
+  if (B == 0) return SHR_OK;
+  if (!T || !skin_vertex_start || !skin_bone || !skin_wv || (!faces && F > 0) || !depth || B < 0 || NB <= 0 || NV <= 0 ||
+      F < 0 || src_size <= 0 || S <= 0)
+    return SHR_EINVAL;
+  if (((uintptr_t)skin_wv & 15u) != 0 || ((uintptr_t)depth & 15u) != 0 || ((uintptr_t)rng_state & 7u) != 0) return SHR_EINVAL;
+  if (noise_keys && !(sigma_xy > 0.f && sigma_xy <= 0.6f)) return SHR_EINVAL;   // (shifts -1 .. +2 hold all but 1e-5 of the mass)
+  if (B > 65535 || S > 16384 || src_size > 32767 || S > src_size || F > (1 << 24) || NB > 160) return SHR_ETOOLARGE;
+  LatticePost po = {};
+  po.depth_scale = depth_scale; po.keys = noise_keys; po.sigma_z = sigma_z; po.state = rng_state; po.B = B;
+  {   // P(trunc(n sigma + 0.5) < k) = Phi((k - 0.5) / sigma) for k <= 0 (truncation towards zero: shift 0 holds (-1, 1))
+    auto Phi = [](double x) { return 0.5 * erfc(-x / 1.4142135623730951); };
+    const double s = noise_keys ? (double)sigma_xy : 0.5;
+    po.t0 = (uint32_t)llround(65536.0 * Phi((-1.0 - 0.5) / s));     // shift <= -1  <=>  n sigma + 0.5 <= -1
+    po.t1 = (uint32_t)llround(65536.0 * Phi((1.0 - 0.5) / s));      // shift <= 0   <=>  n sigma + 0.5 < 1
+    po.t2 = (uint32_t)llround(65536.0 * Phi((2.0 - 0.5) / s));      // shift <= 1   <=>  n sigma + 0.5 < 2
+  }
+  LatticeSkin sk;
+  sk.T = T; sk.vstart = skin_vertex_start; sk.sbone = skin_bone; sk.swv = reinterpret_cast<const float4 *>(skin_wv);
+  sk.rand_f = rand_f; sk.NB = NB; sk.right_hand = right_hand; sk.cx = cx; sk.cy = cy; sk.fx = fx; sk.fy = fy;
+  const int r = mesh_lattice_launch(nullptr, &sk, faces, B, NV, F, src_size, S, clamp_max, depth, (hipStream_t)stream, &po);
+  if (r >= 0) return r;
+  if (!depth_ws || depth_ws == depth) return SHR_EINVAL;
+  const int e = shr_mesh_render_fwd(T, B, NB, NV, skin_vertex_start, skin_bone, skin_wv, right_hand, cx, cy, fx, fy, rand_f,
+                                    faces, F, src_size, S, clamp_max, vertices_ws, depth_ws, stream);
+  if (e != SHR_OK) return e;
+  const int per = (S * S + 255) / 256;
+  hipLaunchKernelGGL(depth_post_kernel, dim3((unsigned)(per > 64 ? 64 : per), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                     depth_ws, B, S, S, po, depth);
+  return (int)hipGetLastError();
+}
+
+/* HandSynthesizer.forward (network/util_modules.py:104-122) in ONE launch: every workgroup runs its crop's forward
+ * kinematics + RandScale + draws (shr_synth_pose_fwd's arithmetic), skins, rasterizes, scales and noises it
+ * (shr_mesh_render_post_fwd's) and paints its heat-maps (shr_heatmap_render_fwd's) -- the same bits as the three launches.
+ * Only where shr_hand_synth_one_launch() says so (the lattice kernel's sizes, J <= 64, a power-of-two heat-map side);
+ * SHR_EINVAL otherwise.  noise: 0 / 1; uv_hm = NULL: no heat-maps (then d_hm, xyz and the kp_* tables are not read).
+ * rng_state: uint64 [3] = (seed, call counter, ticket -- zero between launches); the launch's last workgroup advances
+ * the counter. */
+extern "C" int shr_hand_synth_one_launch(int NB, int NV, int F, int src_size, int S, int J, int hm) {
+  if (!shr_mesh_render_one_launch(NB, NV, F, src_size, S) || NB != shr::kBones) return 0;
+  if (J < 0 || J > 64 || hm <= 0 || (hm & (hm - 1)) != 0 || hm > 1024) return 0;
+  return 1;
+}
+
+extern "C" int shr_hand_synth_fwd(const float *params, int B, const float *offset, const float *offset_inv,
+                                  unsigned long long *rng_state, float rand_scale, int NV,
+                                  const int32_t *skin_vertex_start, const int32_t *skin_bone, const float *skin_wv,
+                                  int right_hand, float cx, float cy, float fx, float fy, const int32_t *faces, int F,
+                                  int src_size, int S, float clamp_max, float depth_scale, int noise, float sigma_xy,
+                                  float sigma_z, int J, const int32_t *kp_start, const int32_t *kp_bone, const float *kp_wv,
+                                  int hm, float hcx, float hcy, float hfx, float hfy, float hm_sigma, float uv_scale,
+                                  float d_scale, float a00, float a03, float a11, float a13, float *draws, float *depth,
+                                  float *uv_hm, float *d_hm, float *xyz, void *stream) {
+  using namespace shr;
+  if (B == 0) return SHR_OK;
+  if (!params || !offset || !offset_inv || !rng_state || !skin_vertex_start || !skin_bone || !skin_wv || !faces || !draws ||
+      !depth || B < 0 || NV <= 0 || F <= 0 || src_size <= 0 || S <= 0)
+    return SHR_EINVAL;
+  if (uv_hm && (!d_hm || !xyz || !kp_start || !kp_bone || !kp_wv)) return SHR_EINVAL;
+  if ((((uintptr_t)skin_wv | (uintptr_t)depth | (uintptr_t)offset | (uintptr_t)offset_inv | (uintptr_t)kp_wv | (uintptr_t)xyz) & 15u) != 0 ||
+      ((uintptr_t)rng_state & 7u) != 0)
+    return SHR_EINVAL;
+  if (noise && !(sigma_xy > 0.f && sigma_xy <= 0.6f)) return SHR_EINVAL;
+  if (B > 65535) return SHR_ETOOLARGE;
+  if (!shr_hand_synth_one_launch(kBones, NV, F, src_size, S, uv_hm ? J : 0, uv_hm ? hm : 1)) return SHR_EINVAL;
+  LatticePost po = {};
+  po.depth_scale = depth_scale; po.keys = noise ? reinterpret_cast<const uint32_t *>(draws) : nullptr; po.sigma_z = sigma_z;
+  po.state = rng_state; po.B = B;
+  {
+    auto Phi = [](double x) { return 0.5 * erfc(-x / 1.4142135623730951); };
+    const double sg = noise ? (double)sigma_xy : 0.5;
+    po.t0 = (uint32_t)llround(65536.0 * Phi(-1.5 / sg));
+    po.t1 = (uint32_t)llround(65536.0 * Phi(0.5 / sg));
+    po.t2 = (uint32_t)llround(65536.0 * Phi(1.5 / sg));
+  }
+  po.params = params; po.offset = offset; po.offset_inv = offset_inv;
+  po.rand_scale = rand_scale; po.rand_half = (float)((double)rand_scale / 2.0); po.draws = draws;
+  if (uv_hm) {
+    po.kp_start = kp_start; po.kp_bone = kp_bone; po.kp_wv = reinterpret_cast<const float4 *>(kp_wv); po.J = J;
+    int sh = 0;
+    while ((1 << sh) < hm) sh++;
+    po.hm_shift = sh;
+    po.hcx = hcx; po.hcy = hcy; po.hfx = hfx; po.hfy = hfy; po.hsigma = hm_sigma; po.uv_scale = uv_scale; po.d_scale = d_scale;
+    po.a00 = a00; po.a03 = a03; po.a11 = a11; po.a13 = a13;
+    po.uv_hm = uv_hm; po.d_hm = d_hm; po.xyz = reinterpret_cast<float4 *>(xyz);
+  }
+  LatticeSkin sk;
+  sk.T = nullptr; sk.vstart = skin_vertex_start; sk.sbone = skin_bone; sk.swv = reinterpret_cast<const float4 *>(skin_wv);
+  sk.rand_f = nullptr; sk.NB = kBones; sk.right_hand = right_hand; sk.cx = cx; sk.cy = cy; sk.fx = fx; sk.fy = fy;
+  const int r = mesh_lattice_launch(nullptr, &sk, faces, B, NV, F, src_size, S, clamp_max, depth, (hipStream_t)stream, &po);
+  return r >= 0 ? r : SHR_EINVAL;
 }

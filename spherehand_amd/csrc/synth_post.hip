@@ -38,6 +38,33 @@ heatmap_paint_kernel(const float4 *__restrict__ uvd, int S, float sigma, float u
   if (threadIdx.x == 0) xyz[bj] = make_float4(a00 * p.x + a03 * p.w, a11 * p.y + a13 * p.w, p.z, p.w);
 }
 
+// Hand3DHeatmapRender.forward (mesh/render.py:274-279) in ONE launch: the key-point's skinning + heat-map camera
+// (lbs_project_kernel's arithmetic on its CSR entries: common.h lbs_add_entry / lbs_finish -- the same bits as
+// shr_lbs_project followed by shr_heatmap_paint), then the paint above.  One workgroup per (sample, key-point); every
+// thread forms the point itself (a dozen FMAs on uniform operands: cheaper than an LDS round trip).
+__global__ void __launch_bounds__(256)
+heatmap_render_kernel(const float *__restrict__ T, int NB, int J, const int *__restrict__ kstart, const int *__restrict__ kbone,
+                      const float4 *__restrict__ kwv, int right_hand, float cx, float cy, float fx, float fy,
+                      const float *__restrict__ rand_f, int S, float sigma, float uv_scale, float d_scale, float a00,
+                      float a03, float a11, float a13, float *__restrict__ uv_hm, float *__restrict__ d_hm,
+                      float4 *__restrict__ xyz) {
+  const int bj = blockIdx.x;
+  const int b = bj / J, j = bj - b * J;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int e = kstart[j]; e < kstart[j + 1]; e++) lbs_add_entry(acc, T + ((size_t)b * NB + kbone[e]) * 16, kwv[e]);
+  const float4 p = lbs_finish(acc, right_hand, 1, cx, cy, fx, fy, rand_f != nullptr, rand_f ? rand_f[b] : 0.f);
+  const int npx = S * S;
+  float *uo = uv_hm + (size_t)bj * npx, *dout = d_hm + (size_t)bj * npx;
+  for (int i = threadIdx.x; i < npx; i += blockDim.x) {
+    const int v = i / S, u = i - v * S;
+    const float du = (float)u - p.x, dv = (float)v - p.y;
+    const float g = __expf(-0.5f * sigma * (du * du + dv * dv));
+    uo[i] = g * uv_scale;
+    dout[i] = (g > 0.05f ? p.z : 0.f) * d_scale;
+  }
+  if (threadIdx.x == 0) xyz[bj] = make_float4(a00 * p.x + a03 * p.w, a11 * p.y + a13 * p.w, p.z, p.w);
+}
+
 __global__ void __launch_bounds__(256)
 depth_noise_kernel(const float *__restrict__ dm, const float *__restrict__ normal3, int B, int H, int W, float sigma_xy,
                    float sigma_z, float *__restrict__ out) {
@@ -65,6 +92,21 @@ extern "C" int shr_heatmap_paint(const float *uvd, int BJ, int S, float sigma, f
   hipLaunchKernelGGL(heatmap_paint_kernel, dim3((unsigned)BJ), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float4 *>(uvd), S, sigma, uv_scale, d_scale, a00, a03, a11, a13, uv_hm, d_hm,
                      reinterpret_cast<float4 *>(xyz));
+  return (int)hipGetLastError();
+}
+
+extern "C" int shr_heatmap_render_fwd(const float *T, int B, int NB, int J, const int32_t *kp_start, const int32_t *kp_bone,
+                                      const float *kp_wv, int right_hand, float cx, float cy, float fx, float fy,
+                                      const float *rand_f, int S, float sigma, float uv_scale, float d_scale, float a00,
+                                      float a03, float a11, float a13, float *uv_hm, float *d_hm, float *xyz, void *stream) {
+  using namespace shr;
+  if (B == 0 || J == 0) return SHR_OK;
+  if (!T || !kp_start || !kp_bone || !kp_wv || !uv_hm || !d_hm || !xyz || B < 0 || J < 0 || NB <= 0 || S <= 0) return SHR_EINVAL;
+  if ((((uintptr_t)kp_wv | (uintptr_t)xyz) & 15u) != 0) return SHR_EINVAL;
+  if ((long long)B * J > (1LL << 30)) return SHR_ETOOLARGE;
+  hipLaunchKernelGGL(heatmap_render_kernel, dim3((unsigned)(B * J)), dim3(S * S >= 256 ? 256 : 64), 0, (hipStream_t)stream, T, NB, J,
+                     kp_start, kp_bone, reinterpret_cast<const float4 *>(kp_wv), right_hand, cx, cy, fx, fy, rand_f, S, sigma,
+                     uv_scale, d_scale, a00, a03, a11, a13, uv_hm, d_hm, reinterpret_cast<float4 *>(xyz));
   return (int)hipGetLastError();
 }
 

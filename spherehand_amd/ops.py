@@ -800,6 +800,109 @@ def mesh_render_fwd(T, skin_vertex_start, skin_bone, skin_wv, right_hand, camera
     return depth
 
 
+def hand_synth(params, offset, offset_inv, rng_state, rand_scale, lbs, faces, camera, out_size, depth_scale, noise,
+               sigma_xy, sigma_z, heat=None, src_size=640, clamp_max=100.0):
+    """HandSynthesizer.forward in ONE launch (shr_hand_synth_fwd), or None where that kernel does not apply (the caller
+    then takes synth_pose / mesh_render_post / heatmap_render).  lbs: the mesh's SparseSkinning (tables + right_hand);
+    heat: None (depth only) or (kp_start, kp_bone_i32, kp_wv, hm, (hcx, hcy, hfx, hfy), sigma, inv_k, uv_scale, d_scale).
+    Returns (draws [6,B], depth [B,S,S], uv_hm, d_hm, xyz) -- the last three None without `heat`."""
+    params = params.contiguous().float()
+    B = params.shape[0]
+    NV, F = lbs.skin_vertex_start.numel() - 1, faces.shape[0]
+    J, hm = (heat[0].numel() - 1, int(heat[3])) if heat is not None else (0, 1)
+    lib = _lib.lib()
+    if params.dim() != 2 or params.shape[1] != 26 or not lib.shr_hand_synth_one_launch(17, NV, F, src_size, out_size, J, hm):
+        return None
+    _check_input(params, "parameters")
+    _check_input(rng_state, "rng_state", torch.int64)
+    dev = params.device
+    cx, cy, fx, fy = camera
+    with _on(dev):
+        draws = torch.empty((6, B), dtype=torch.float32, device=dev)
+        depth = torch.empty((B, out_size, out_size), dtype=torch.float32, device=dev)
+        uv = d = xyz = None
+        hargs = (0, None, None, None, 1, 0.0, 0.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 1.0, 0.0)
+        if heat is not None:
+            kp_start, kp_bone, kp_wv, _, hcam, hsigma, inv_k, uv_scale, d_scale = heat
+            uv = torch.empty((B, J, hm, hm), dtype=torch.float32, device=dev)
+            d = torch.empty((B, J, hm, hm), dtype=torch.float32, device=dev)
+            xyz = torch.empty((B, J, 4), dtype=torch.float32, device=dev)
+            hargs = (J, _ptr(kp_start), _ptr(kp_bone), _ptr(kp_wv), hm, hcam[0], hcam[1], hcam[2], hcam[3], float(hsigma),
+                     float(uv_scale), float(d_scale), inv_k[0], inv_k[1], inv_k[2], inv_k[3])
+        _lib.check(lib.shr_hand_synth_fwd(_ptr(params), B, _ptr(offset), _ptr(offset_inv), _ptr(rng_state), float(rand_scale), NV,
+                                          _ptr(lbs.skin_vertex_start), _ptr(lbs.skin_bone), _ptr(lbs.skin_wv),
+                                          int(bool(lbs.right_hand)), cx, cy, fx, fy, _ptr(faces), F, src_size, out_size,
+                                          clamp_max, float(depth_scale), int(bool(noise)), float(sigma_xy), float(sigma_z),
+                                          *hargs, _ptr(draws), _ptr(depth), _ptr(uv), _ptr(d), _ptr(xyz), _stream()),
+                   "shr_hand_synth_fwd")
+    return draws, depth, uv, d, xyz
+
+
+def synth_pose(params, offset, offset_inv, rng_state, rand_scale):
+    """pose [B,26] -> (diag(s) T [B,17,4,4], draws [6,B]): forward kinematics, RandScale and the samples' random draws in
+    one launch (shr_synth_pose_fwd).  draws = s_x, s_y, s_z, focal jitter, and the two uint32 noise keys (as float bits);
+    rng_state: int64 [2] = (seed, call counter) on the device (read only here)."""
+    params = params.contiguous().float()
+    for t, name in ((params, "parameters"), (offset, "offset"), (offset_inv, "offset_inv")):
+        _check_input(t, name)
+    _check_input(rng_state, "rng_state", torch.int64)
+    if params.dim() != 2 or params.shape[1] != 26 or rng_state.numel() < 3:
+        raise RuntimeError("parameters must be [B,26] and rng_state int64 [>= 3] (seed, call counter, ticket)")
+    B = params.shape[0]
+    with _on(params.device):
+        T = torch.empty((B, 17, 4, 4), dtype=torch.float32, device=params.device)
+        draws = torch.empty((6, B), dtype=torch.float32, device=params.device)
+        _lib.check(_lib.lib().shr_synth_pose_fwd(_ptr(params), B, _ptr(offset), _ptr(offset_inv), _ptr(rng_state),
+                                                 float(rand_scale), _ptr(T), _ptr(draws), _stream()), "shr_synth_pose_fwd")
+    return T, draws
+
+
+def mesh_render_post(T, skin_vertex_start, skin_bone, skin_wv, right_hand, camera, rand_f, faces, out_size, depth_scale,
+                     noise_keys=None, sigma_xy=0.5, sigma_z=0.05, rng_state=None, src_size=640, clamp_max=100.0):
+    """DepthRender + `* depth_scale` + DepthNoise as one call (shr_mesh_render_post_fwd): T [B,NB,4,4] -> [B,S,S].
+    noise_keys: the samples' stream keys ([2,B] float32 view of uint32: synth_pose's draws[4:6]) or None = no noise;
+    rng_state: the generator state whose call counter the launch advances (None: left alone)."""
+    _check_input(T, "bone_transformations")
+    _check_input(faces, "faces", torch.int32)
+    if T.dim() != 4 or T.shape[2:] != (4, 4) or faces.dim() != 2 or faces.shape[1] != 3:
+        raise RuntimeError("T must be [B,NB,4,4] and faces [F,3]")
+    B, NB = T.shape[0], T.shape[1]
+    NV = skin_vertex_start.numel() - 1
+    cx, cy, fx, fy = camera
+    lib = _lib.lib()
+    with _on(T.device):
+        depth = torch.empty((B, out_size, out_size), dtype=torch.float32, device=T.device)
+        ws = dws = None
+        if not lib.shr_mesh_render_one_launch(NB, NV, faces.shape[0], src_size, out_size):
+            ws = torch.empty((B, NV, 4), dtype=torch.float32, device=T.device)
+            dws = torch.empty_like(depth)
+        _lib.check(lib.shr_mesh_render_post_fwd(_ptr(T), B, NB, NV, _ptr(skin_vertex_start), _ptr(skin_bone), _ptr(skin_wv),
+                                                int(bool(right_hand)), cx, cy, fx, fy, _ptr(rand_f), _ptr(faces),
+                                                faces.shape[0], src_size, out_size, clamp_max, float(depth_scale),
+                                                _ptr(noise_keys), float(sigma_xy), float(sigma_z), _ptr(rng_state),
+                                                _ptr(ws), _ptr(dws), _ptr(depth), _stream()), "shr_mesh_render_post_fwd")
+    return depth
+
+
+def heatmap_render(T, kp_start, kp_bone, kp_wv, right_hand, camera, rand_f, S, sigma, inv_k, uv_scale=1.0, d_scale=1.0):
+    """Hand3DHeatmapRender in one launch (shr_heatmap_render_fwd): T [B,NB,4,4] -> (uv_hm [B,J,S,S] * uv_scale,
+    d_hm [B,J,S,S] * d_scale, xyz [B,J,4]); kp_*: the key-points' CSR skin table (one entry each for the hand)."""
+    _check_input(T, "bone_transformations")
+    B, NB = T.shape[0], T.shape[1]
+    J = kp_start.numel() - 1
+    cx, cy, fx, fy = camera
+    a00, a03, a11, a13 = inv_k
+    with _on(T.device):
+        uv = torch.empty((B, J, S, S), dtype=torch.float32, device=T.device)
+        d = torch.empty((B, J, S, S), dtype=torch.float32, device=T.device)
+        xyz = torch.empty((B, J, 4), dtype=torch.float32, device=T.device)
+        _lib.check(_lib.lib().shr_heatmap_render_fwd(_ptr(T), B, NB, J, _ptr(kp_start), _ptr(kp_bone), _ptr(kp_wv),
+                                                     int(bool(right_hand)), cx, cy, fx, fy, _ptr(rand_f), int(S), float(sigma),
+                                                     float(uv_scale), float(d_scale), a00, a03, a11, a13, _ptr(uv), _ptr(d),
+                                                     _ptr(xyz), _stream()), "shr_heatmap_render_fwd")
+    return uv, d, xyz
+
+
 def group_norm_relu_supported(x, num_groups):
     """True when the NHWC GroupNorm+ReLU kernels take this activation (CUDA fp32, channels-last)."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] > 0

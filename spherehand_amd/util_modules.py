@@ -230,7 +230,17 @@ class TemporalSmoothnessLoss(nn.Module):
 class HandSynthesizer(nn.Module):
     """pose [B,26] -> (noisy scaled depth crop [B,S,S], uv heat-maps, depth heat-maps,
     key-point xyz), all detached: the synthetic training branch (square images).
-    FK, skinning+camera and the triangle rasterizer are HIP kernels."""
+
+    On the GPU the whole of network/util_modules.py:104-122 is THREE launches with nothing in between (`fused`, the
+    default; capturable in a hipGraph): forward kinematics + RandScale + the samples' random draws
+    (ops.synth_pose), skinning + camera + triangle raster + clamp + resize + `* depth_scale` + DepthNoise
+    (ops.mesh_render_post: the noise runs in the rasterizer's epilogue), key-point skinning + heat-map camera + paint
+    (ops.heatmap_render).  The random numbers come from a counter-based generator inside the kernels (synth_rng.py
+    restates it): `rng_state` = (seed, call counter) lives on the device, seed = torch.initial_seed() at the first
+    call -- and again whenever torch.manual_seed() has CHANGED it since; reseed() restarts the stream by hand.  Parity with
+    the reference's torch.rand / randn draws is in distribution; with the same draws (`last_draws`) and the noise off
+    the outputs equal the module-by-module chain bit for bit.  fused = False: that chain -- RandScale's three CPU
+    draws, torch.rand for the focal jitter, DepthRender, DepthNoise on one torch.randn, Hand3DHeatmapRender."""
 
     def __init__(self, mesh, image_size, heatmap_size, uv_hm_scale, depth_scale, add_noise=True, out_heatmap=True):
         super().__init__()
@@ -244,9 +254,41 @@ class HandSynthesizer(nn.Module):
         self.depth_noiser = DepthNoise(image_size, image_size)
         self.add_noise = add_noise
         self.out_heatmap = out_heatmap
+        self.fused = True
+        self.one_launch = True       # the whole forward as ONE kernel where its sizes allow (ops.hand_synth)
+        self.rng_state = None        # int64 [4] on the device: (seed, call counter, the launch's ticket, unused)
+        self._rng_seed = None
+        self.last_draws = None       # [6,B] of the last fused call: s_x, s_y, s_z, focal jitter, the two noise keys (bits)
+        self._kp_bone_i32 = None
+
+    def reseed(self, seed=None, device=None):
+        """Restart the kernels' random stream: seed (default torch.initial_seed()), call counter 0."""
+        seed = torch.initial_seed() if seed is None else int(seed)
+        self._rng_seed = seed
+        s64 = seed & (2 ** 64 - 1)
+        dev = device if device is not None else (self.rng_state.device if self.rng_state is not None else None)
+        if dev is None:
+            self.rng_state = None
+            return
+        self.rng_state = torch.tensor([s64 - 2 ** 64 if s64 >= 2 ** 63 else s64, 0, 0, 0], dtype=torch.int64, device=dev)
+
+    def _state(self, dev):
+        if self.rng_state is None or self.rng_state.device != dev or self._rng_seed != torch.initial_seed():
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("HandSynthesizer: call the module (or reseed(device=...)) once before capturing it: "
+                                   "seeding the generator state is a host-to-device copy")
+            self.reseed(device=dev)
+        return self.rng_state
+
+    def _fused_ok(self, parameters):
+        ras, nz = self.dm_render.rasterizer, self.depth_noiser
+        return (self.fused and parameters.is_cuda and ras.fused and ras.width == ras.height and 2 * ras.width <= 641
+                and nz.sigma_x == nz.sigma_y and 0.0 < nz.sigma_x <= 0.6)
 
     @torch.no_grad()
     def forward(self, parameters):
+        if self._fused_ok(parameters):
+            return self._forward_fused(parameters)
         transform_mats = self.rand_scale(self.hand_skeleton_transform(parameters))
         # focal jitter U(0.9, 1.1) (util_modules.py:110), drawn on the tensors' device (no host round trip)
         rand_f_ratio = torch.rand(transform_mats.shape[0], device=transform_mats.device) * 0.2 + 0.9
@@ -257,3 +299,40 @@ class HandSynthesizer(nn.Module):
             return depth
         uv_hms, depth_hms, xyz_pts = self.hm_render(transform_mats, rand_f_ratio, self.uv_hm_scale, self.depth_scale)
         return depth, uv_hms, depth_hms, xyz_pts
+
+    def _forward_fused(self, parameters):
+        dev = parameters.device
+        state = self._state(dev)
+        fk, dr, hm, nz = self.hand_skeleton_transform, self.dm_render, self.hm_render, self.depth_noiser
+        ras, lbs = dr.rasterizer, dr.lbs
+        heat = None
+        if self.out_heatmap:
+            kl = hm.lbs
+            if self._kp_bone_i32 is None or self._kp_bone_i32.device != dev:
+                self._kp_bone_i32 = kl.skin_bone.to(device=dev, dtype=torch.int32).contiguous()
+                k = hm.inv_camera.inv_k_mat[0].cpu().tolist()
+                self._inv_k = (float(k[0][0]), float(k[0][3]), float(k[1][1]), float(k[1][3]))
+            cam = hm.camera
+            hcam = (cam.cx, cam.cy, cam.fx, cam.fy)
+            heat = (kl.skin_vertex_start, self._kp_bone_i32, kl.skin_wv, hm.width, hcam, hm.hm_renderer.sigma, self._inv_k,
+                    self.uv_hm_scale, self.depth_scale)
+        # (the one-launch kernel flips x once for both tables: the mesh's and the key-points' skinning are for one hand)
+        if self.one_launch and (heat is None or hm.lbs.right_hand == lbs.right_hand):
+            out = ops.hand_synth(parameters, fk.offset, fk.offset_inv, state, self.rand_scale.rand_scale, lbs, ras.faces_i32,
+                                 dr.camera, ras.height, self.depth_scale, self.add_noise, nz.sigma_x, nz.sigma_z, heat)
+            if out is not None:
+                self.last_draws = out[0]
+                return out[1:] if self.out_heatmap else out[1]
+        # three launches: sizes the one-launch kernel does not take (no lattice of sampled pixels: S = 256 ...)
+        T, draws = ops.synth_pose(parameters, fk.offset, fk.offset_inv, state, self.rand_scale.rand_scale)
+        self.last_draws = draws
+        rand_f = draws[3]
+        depth = ops.mesh_render_post(T, lbs.skin_vertex_start, lbs.skin_bone, lbs.skin_wv, lbs.right_hand, dr.camera, rand_f,
+                                     ras.faces_i32, ras.height, self.depth_scale, draws[4:6] if self.add_noise else None,
+                                     nz.sigma_x, nz.sigma_z, state)
+        if not self.out_heatmap:
+            return depth
+        uv_hms, depth_hms, xyz_pts = ops.heatmap_render(T, heat[0], heat[1], heat[2], hm.lbs.right_hand, heat[4], rand_f, heat[3],
+                                                        heat[5], heat[6], heat[7], heat[8])
+        return depth, uv_hms, depth_hms, xyz_pts
+

@@ -95,15 +95,16 @@ def test_hand_synthesizer():
 
 
 @pytest.mark.parametrize("S", [64, 128])
-def test_hand_synthesizer_values_against_the_oracle_chain(S):
-    """HandSynthesizer.forward (network/util_modules.py:104-122) VALUES, not shapes: under one seed the module's outputs
-    equal the chain assembled by hand from pieces that are pinned elsewhere -- the random scale and focal jitter drawn in
-    the module's order, the ORACLE's skinning + camera + triangle raster at 640 x 640 + clamp + bilinear resize
-    (bit-exact: the fused kernel rasterizes the same arithmetic), x depth_scale, DepthNoise's torch formula on the same
-    draws (1e-6: the fused noise kernel consumes one randn of three planes), and the heat-map renderer's torch ops
-    (6e-6 / 4e-4, its bars in tools/fuzz.py)."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_hand_synthesizer_values_against_the_oracle_chain(S, fused):
+    """HandSynthesizer.forward (network/util_modules.py:104-122) VALUES, not shapes: the module's outputs equal the chain
+    assembled by hand from pieces that are pinned elsewhere -- the random scale and focal jitter the module drew (fused:
+    its kernels' counter-based draws, read back from `last_draws`; fused = False: RandScale's three CPU draws and
+    torch.rand, replayed under the same seed), the ORACLE's skinning + camera + triangle raster at 640 x 640 + clamp +
+    bilinear resize (bit-exact: the fused kernel rasterizes the same arithmetic), x depth_scale, DepthNoise's formula on
+    the module's own draws (1e-6), and the heat-map renderer's torch ops (6e-6 / 4e-4, its bars in tools/fuzz.py)."""
     from oracle import oracle
-    from spherehand_amd import hand_model
+    from spherehand_amd import hand_model, synth_rng
     from spherehand_amd.joint_angle import sample_poses
     from spherehand_amd.util_modules import HandSynthesizer
     oracle.build()
@@ -111,12 +112,18 @@ def test_hand_synthesizer_values_against_the_oracle_chain(S):
     B = 6
     pose = sample_poses(B, seed=5).cuda()
     syn = HandSynthesizer(mesh, S, 16, 1.0, 0.01, add_noise=False).cuda()
+    syn.fused = fused
     torch.manual_seed(11)
     depth, uv, dh, xyz = syn(pose)
-    # the same draws, by hand: RandScale's three CPU draws, then the focal jitter on the device
-    torch.manual_seed(11)
-    T = syn.rand_scale(syn.hand_skeleton_transform(pose))
-    rand_f = torch.rand(B, device="cuda") * 0.2 + 0.9
+    if fused:
+        d = syn.last_draws
+        T = syn.hand_skeleton_transform(pose) * torch.cat([d[0:3].t(), torch.ones(B, 1, device="cuda")], 1).view(B, 1, 4, 1)
+        rand_f = d[3].clone()
+    else:       # the same draws, by hand: RandScale's three CPU draws, then the focal jitter on the device
+        torch.manual_seed(11)
+        T = syn.rand_scale(syn.hand_skeleton_transform(pose))
+        rand_f = torch.rand(B, device="cuda") * 0.2 + 0.9
+    assert ((T[:, :, 0, 0].abs() <= 0.95 + 1e-6).all() and (rand_f >= 0.9).all() and (rand_f < 1.1).all())
     start, bone, wv = hand_model.sparse_skin(mesh)
     verts = oracle.lbs_project(T.cpu().numpy(), start, bone, wv, True, syn.dm_render.camera, rand_f.cpu().numpy())
     faces = np.asarray(mesh["faces"], np.int64)[:, [1, 0, 2]]        # [F,3] into the mesh's own vertex list, winding as
@@ -133,20 +140,26 @@ def test_hand_synthesizer_values_against_the_oracle_chain(S):
         assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item())
     gate = (uv_t - 0.05).abs() > 1e-5                      # (depth maps are gated by uv_hm > 0.05: skip pixels on the gate)
     assert ((dh - dh_t) * gate).abs().max().item() <= 1e-6 * max(1.0, dh_t.abs().max().item())
-    # with the noise: DepthNoise's torch formula on the draws the fused kernel consumes (one randn of three planes:
-    # x shift, y shift, z noise)
+    # with the noise: DepthNoise's formula on the draws the module consumes
     noisy = HandSynthesizer(mesh, S, 16, 1.0, 0.01, add_noise=True, out_heatmap=False).cuda()
+    noisy.fused = fused
     torch.manual_seed(11)
     out = noisy(pose)
-    torch.manual_seed(11)
-    noisy.rand_scale(noisy.hand_skeleton_transform(pose)); torch.rand(B, device="cuda")
-    rn = torch.randn(3, B, S, S, device="cuda")
-    u = torch.arange(S, device="cuda").view(1, 1, S); v = torch.arange(S, device="cuda").view(1, S, 1)
-    sx = torch.clamp((rn[0] * 0.5 + 0.5).long() + u, 0, S - 1)
-    sy = torch.clamp((rn[1] * 0.5 + 0.5).long() + v, 0, S - 1)
-    g = torch.gather(depth.reshape(B, S * S), 1, (sy * S + sx).reshape(B, S * S)).view(B, S, S)
-    expect = torch.where(g < 1.0, g + rn[2] * 0.05, g)
+    if fused:       # same seed, same call counter: the same scale / jitter draws, hence the same clean image `depth`
+        assert torch.equal(noisy.last_draws.view(torch.int32), syn.last_draws.view(torch.int32))
+        keys = noisy.last_draws[4:6].cpu().numpy().view(np.uint32)
+        expect = torch.from_numpy(synth_rng.depth_noise(depth.cpu().numpy(), keys, 0.5, 0.05)).cuda()
+    else:           # one randn of three planes: x shift, y shift, z noise
+        torch.manual_seed(11)
+        noisy.rand_scale(noisy.hand_skeleton_transform(pose)); torch.rand(B, device="cuda")
+        rn = torch.randn(3, B, S, S, device="cuda")
+        u = torch.arange(S, device="cuda").view(1, 1, S); v = torch.arange(S, device="cuda").view(1, S, 1)
+        sx = torch.clamp((rn[0] * 0.5 + 0.5).long() + u, 0, S - 1)
+        sy = torch.clamp((rn[1] * 0.5 + 0.5).long() + v, 0, S - 1)
+        g = torch.gather(depth.reshape(B, S * S), 1, (sy * S + sx).reshape(B, S * S)).view(B, S, S)
+        expect = torch.where(g < 1.0, g + rn[2] * 0.05, g)
     assert (out - expect).abs().max().item() <= 1e-6
+    assert (out != depth).float().mean().item() > 0.02     # (the noise did something)
 
 
 def test_engine_train_eval_checkpoint(tmp_path):
