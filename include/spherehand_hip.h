@@ -80,6 +80,9 @@ int shr_device_info(char *name_host, int name_len, int *num_cu_host);
 #define SHR_TUNE_TRI_BAND 16         /* shr_tri_raster_fwd: -1 = the LDS band kernel wherever it fits (default: band height
                                     * and workgroups per crop planned per launch), 0 = always the global-atomic kernel,
                                     * n > 0 = the band kernel with bands of at most n rows */
+#define SHR_TUNE_MESH_BAND 17        /* shr_mesh_depth_fwd / shr_mesh_render_fwd at sizes without a lattice kernel whose resize
+                                    * samples at least half of the source pixels (S = 256 from 640): 1 = the triangle band
+                                    * kernel with clamp + resize as its stream-out (default), 0 = the tile kernel */
 int shr_set_tuning(int key, int value);
 /* Self-test: adds to *mismatches (device, caller-zeroed u64) the number of fp32
  * bit patterns in [lo_bits, hi_bits) where the rasterizer's internal square root

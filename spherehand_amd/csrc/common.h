@@ -184,6 +184,9 @@ int d2m_set_waves(int waves);        // data_to_model.hip: launch-shape hooks be
 int d2m_set_band_units(int units);  // SHR_TUNE_D2M_BAND_UNITS
 int d2m_set_tiled(int on);          // SHR_TUNE_D2M_TILED
 int tri_set_band(int rows);         // tri_raster.hip: SHR_TUNE_TRI_BAND
+int mesh_set_band(int on);          // mesh_depth.hip: SHR_TUNE_MESH_BAND
+int tri_band_resize(const float *vertices, const int *faces, int B, int NV, int F, int src_size, int S, float clamp_max,
+                    float *depth, hipStream_t s);   // tri_raster.hip: the band kernel with the clamp + resize epilogue (-1: not its problem)
 // data_to_model.hip: the two halves of shr_data_to_model_compact (mutual_project.hip: shr_mv_project_compact)
 int d2m_compact_check(const float *depth, int M, int H, int W, void *workspace, int **counts);
 int d2m_compact_launch(const float *depth, int M, int H, int W, void *workspace, hipStream_t s);
@@ -282,6 +285,22 @@ __device__ __forceinline__ int run_of(int incl, bool mine, int k0, int k) {
 
 
 __device__ __forceinline__ bool is_aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ATen area_pixel_compute_source_index (align_corners=False) for output index d:
+// src = scale*(d+0.5)-0.5 clamped at 0; i0 = (int)src; i1 = i0 + (i0 < in-1); l1 = src - i0.
+struct Lin { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lin lin_index(int d, float scale, int in_size) {
+  // (one rounding: ATen's GPU kernel is compiled with contraction, scale * (d + 0.5) - 0.5 is an FMA there;
+  // the two forms differ by an ulp of the source index at non-dyadic ratios, 3e-5 of a pixel at 256)
+  float src = __builtin_fmaf(scale, (float)d + 0.5f, -0.5f);
+  if (src < 0.f) src = 0.f;
+  Lin r;
+  r.i0 = min((int)src, in_size - 1);
+  r.i1 = r.i0 + ((r.i0 < in_size - 1) ? 1 : 0);
+  r.l1 = src - (float)r.i0;
+  r.l0 = 1.0f - r.l1;
+  return r;
+}
 
 // ---- counter-based random numbers of the synthetic branch (HandSynthesizer: RandScale, focal jitter, DepthNoise) --------
 // No state is carried between draws: a draw is a HASH of what it is for, so any launch geometry -- and a numpy

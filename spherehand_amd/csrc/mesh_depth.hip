@@ -61,22 +61,6 @@ __device__ __forceinline__ int m_cvt_rz_sat(float d) {
   return (int)d;
 }
 
-// ATen area_pixel_compute_source_index (align_corners=False) for output index d:
-// src = scale*(d+0.5)-0.5 clamped at 0; i0 = (int)src; i1 = i0 + (i0 < in-1); l1 = src - i0.
-struct Lin { int i0, i1; float l0, l1; };
-__device__ __forceinline__ Lin lin_index(int d, float scale, int in_size) {
-  // (one rounding: ATen's GPU kernel is compiled with contraction, scale * (d + 0.5) - 0.5 is an FMA there;
-  // the two forms differ by an ulp of the source index at non-dyadic ratios, 3e-5 of a pixel at 256)
-  float src = __builtin_fmaf(scale, (float)d + 0.5f, -0.5f);
-  if (src < 0.f) src = 0.f;
-  Lin r;
-  r.i0 = min((int)src, in_size - 1);
-  r.i1 = r.i0 + ((r.i0 < in_size - 1) ? 1 : 0);
-  r.l1 = src - (float)r.i0;
-  r.l0 = 1.0f - r.l1;
-  return r;
-}
-
 // A face set up like the reference kernel (.cu:33-69): culled, vertices sorted by x, pixel
 // box.  `live` = front-facing, non-degenerate and its box meets the image.
 struct FaceSetup {
@@ -937,6 +921,9 @@ extern "C" int shr_mesh_debug_timeline(unsigned long long *host_out) {
 }
 #endif
 
+static int g_mesh_band = 1;   // SHR_TUNE_MESH_BAND
+int shr::mesh_set_band(int on) { g_mesh_band = on; return SHR_OK; }
+
 // the lattice kernel's launch (vertices: skinned ones in HBM, or nullptr with `skin` for the fused kernel); returns -1
 // when the problem is not the lattice kernel's (non-integer ratio, lattice above 128 x 128, LDS)
 static int mesh_lattice_launch(const float4 *v4, const shr::LatticeSkin *skin, const int32_t *faces, int B, int NV, int F,
@@ -998,6 +985,14 @@ extern "C" int shr_mesh_depth_fwd(const float *vertices, const int32_t *faces, i
       // (SHR_MESH_LATTICE=0 in the environment keeps the tile kernel: tests and tools compare the two)
     const int r = mesh_lattice_launch(v4, nullptr, faces, B, NV, F, src_size, S, clamp_max, depth, s);
     if (r >= 0) return r;
+  }
+  {   // no lattice, but the resize samples at least half of the source pixels (S = 256 from 640: 64 %): the triangle BAND
+      // kernel at full resolution with clamp + resize as its stream-out (tri_raster.hip RESIZE) -- 64 crops @256 x 256:
+      // 304 us with the tile kernel below.  SHR_TUNE_MESH_BAND 0 keeps the tile kernel (tests compare the two).
+    if (g_mesh_band != 0 && 8LL * S * S >= (long long)src_size * src_size) {
+      const int r = tri_band_resize(vertices, faces, B, NV, F, src_size, S, clamp_max, depth, s);
+      if (r >= 0) return r;
+    }
   }
   if (single) {
     if (S > 64) MESH_LAUNCH(128, 1, true); else MESH_LAUNCH(64, 1, true);

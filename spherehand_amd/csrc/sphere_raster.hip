@@ -221,6 +221,7 @@ extern "C" int shr_set_tuning(int key, int value) {
     case SHR_TUNE_FWD_RUN_TABLE: if (value < -1 || value > 1) return SHR_EINVAL; g_tune.run_table = value; return SHR_OK;
     case SHR_TUNE_D2M_TILED: return d2m_set_tiled(value);
     case SHR_TUNE_TRI_BAND: if (value < -1) return SHR_EINVAL; return tri_set_band(value);
+    case SHR_TUNE_MESH_BAND: if (value < 0 || value > 1) return SHR_EINVAL; return mesh_set_band(value);
     case SHR_TUNE_D2M_WAVES: return d2m_set_waves(value);
     case SHR_TUNE_D2M_BAND_UNITS: return d2m_set_band_units(value);
     case SHR_TUNE_FWD_SHARES:

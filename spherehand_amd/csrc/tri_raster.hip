@@ -397,10 +397,16 @@ __device__ __forceinline__ uint32_t face_row_range(const float f[9], int width, 
   return live ? ((uint32_t)r_lo | ((uint32_t)r_hi << 16)) : 0xFFFFu;
 }
 
-template <bool INDEXED>
+// RESIZE (DepthRasterization.forward's tail, mesh/render.py:286, :311, for sizes the lattice kernel does not take -- S = 256
+// from 640): the band never leaves LDS as a 640 x 640 image; its stream-out IS clamp(max) + ATen's bilinear resize to
+// S x S.  With src / S = p_src / p_out in lowest terms, output rows [k p_out, (k + 1) p_out) take their two source rows
+// from [k p_src, (k + 1) p_src) (down-sampling: scale > 1), so bands of a multiple of p_src rows hold every tap of their
+// own output rows: zbuf = out [B][S][S], R % p_src == 0, square images.  The rasterized values are the full-resolution
+// kernel's (same code), the epilogue is mesh_depth_kernel's formula: the same bits as raster -> clamp -> F.interpolate.
+template <bool INDEXED, bool RESIZE = false>
 __global__ void __launch_bounds__(kBandWaves * 64)
 tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, int B, int F, int NV, int width, int height,
-                float *__restrict__ zbuf, int R, int nbands) {
+                float *__restrict__ zbuf, int R, int nbands, int S = 0, int p_src = 1, int p_out = 1, float clamp_max = 0.f) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int Fpad = (F + 7) & ~7;
   uint32_t *s_range = reinterpret_cast<uint32_t *>(smem);
@@ -414,7 +420,7 @@ tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, in
   // workgroup y of a crop takes bands y, y + gridDim.y, ...: interleaved, so that every workgroup of a crop gets its
   // share of the hand's rows and of the empty ones (consecutive bands: the top and bottom segments were nearly free)
   const int band_first = blockIdx.y, band_step = gridDim.y;
-  float *zimg = zbuf + (size_t)b * width * height;
+  float *zimg = RESIZE ? zbuf + (size_t)b * S * S : zbuf + (size_t)b * width * height;
   const bool counted = nbands <= kBandMaxBands;
   for (int i = tid; i < min(nbands, kBandMaxBands); i += kBandWaves * 64) s_bandcnt[i] = 0;
   __syncthreads();
@@ -440,8 +446,14 @@ tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, in
   for (int band = band_first; band < nbands; band += band_step) {
     const int lo = band * R, hi = min(height, lo + R) - 1, rows = hi - lo + 1;
     const int npix = rows * width;
-    float *gout = zimg + (size_t)lo * width;
+    // RESIZE: the band's output rows [oy_lo, oy_lo + orows)
+    const int oy_lo = RESIZE ? (lo / p_src) * p_out : 0, orows = RESIZE ? (rows / p_src) * p_out : 0;
+    float *gout = RESIZE ? zimg + (size_t)oy_lo * S : zimg + (size_t)lo * width;
     if (counted && s_bandcnt[band] == 0) {          // no face reaches the band (workgroup-uniform)
+      if (RESIZE) {                                 // every tap is the clamped background: min(1000, clamp_max) exactly
+        const float bgv = fminf(__uint_as_float(kFillBits), clamp_max);
+        for (int i = tid; i < orows * S; i += kBandWaves * 64) gout[i] = bgv;
+      } else
       if (vec4) {
         const v4u_t t = {kFillBits, kFillBits, kFillBits, kFillBits};
         for (int i = tid; i < (npix >> 2); i += kBandWaves * 64)
@@ -509,6 +521,17 @@ tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, in
     }
     __syncthreads();
     // stream the band out
+    if (RESIZE) {
+      const float scale = (float)height / (float)S;
+      for (int i = tid; i < orows * S; i += kBandWaves * 64) {
+        const int r = i / S, ox = i - r * S;
+        const Lin ly = lin_index(oy_lo + r, scale, height), lx = lin_index(ox, scale, width);
+        const float *r0 = cells + ly.i0 * width, *r1 = cells + ly.i1 * width;
+        const float v00 = fminf(r0[lx.i0], clamp_max), v01 = fminf(r0[lx.i1], clamp_max);
+        const float v10 = fminf(r1[lx.i0], clamp_max), v11 = fminf(r1[lx.i1], clamp_max);
+        gout[i] = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+      }
+    } else
     if (vec4) {
       for (int i = tid; i < (npix >> 2); i += kBandWaves * 64) {
         const uint4 v = reinterpret_cast<const uint4 *>(s_band)[i];
@@ -582,19 +605,29 @@ using namespace shr;
 static int g_tri_band = -1;   // SHR_TUNE_TRI_BAND: -1 = by batch size (below), 0 = never (the global-atomic kernel), n > 0 = always, bands of <= n rows
 int shr::tri_set_band(int v) { g_tri_band = v; return SHR_OK; }
 
+// resize_S > 0: the band kernel with the clamp + resize epilogue (RESIZE above; depth = [B][S][S]); -1 when it does not fit
 static int tri_raster_common(bool indexed, const float *src, const int *faces, int B, int F, int NV, int W, int H,
-                             float *depth, hipStream_t s) {
+                             float *depth, hipStream_t s, int resize_S = 0, float clamp_max = 0.f) {
+  int p_src = 1, p_out = 1;
+  if (resize_S > 0) {
+    if (W != H || resize_S > H) return -1;
+    int a = H, c = resize_S;
+    while (c) { const int t = a % c; a = c; c = t; }
+    p_src = H / a; p_out = resize_S / a;
+  }
   // The band kernel: the row ranges of all faces (4 F bytes) + sixteen wave scratches + a band of at least 8 rows
   // in one CU's LDS, 16-bit face numbers and row numbers.
   constexpr int kLds = 160 * 1024;
   const long long fixed = (long long)((F + 7) & ~7) * 6 + (long long)kBandWaves * kBandScratchBytes + 4096 + 16;   // (+ the static arrays: band counters, pending faces; + the band's rounding to 16 bytes)
   long long Rmax = (kLds - fixed) / (4LL * W);
   if (Rmax > H) Rmax = H;
+  Rmax -= Rmax % p_src;                                  // (resize: whole periods of source rows per band)
+  if (resize_S > 0 && (Rmax < p_src || g_tri_band == 0 || !(F > 0 && F <= 65535 && H <= 65535))) return -1;
   // Which kernel: the band kernel wherever it fits (round 5, after raster_batch's level walk: hand mesh @640x640,
   // tools/exp_tri_band.py -- 1 crop 20.8 us against 78 for the atomic kernel, 48 crops 142 against 173, 256 crops 348
   // against 461); the atomic kernel for what does not (more than 65535 faces, rows too wide for 8 of them in LDS).
   // SHR_TUNE_TRI_BAND: 0 forces the atomic kernel, n > 0 bands of at most n rows.
-  if (g_tri_band != 0 && F > 0 && F <= 65535 && Rmax >= 8 && H <= 65535 && W <= 65535) {
+  if (g_tri_band != 0 && F > 0 && F <= 65535 && (Rmax >= 8 || resize_S > 0) && H <= 65535 && W <= 65535) {
     const int cus = device_cus();   // (per device: common.h)
     // Rows per band and workgroups per crop.  A band costs a fixed part -- one batch's latency: the gather of its faces,
     // the set-up's chain of divisions, three barriers -- worth ~24 rows of raster and stream-out (256 crops: 8.8 us per
@@ -608,13 +641,14 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
     int R = (int)Rmax, segs = 1;
     if (g_tri_band > 0) {
       if (g_tri_band < R) R = g_tri_band;
+      R = R < p_src ? p_src : R - R % p_src;
       const int nb = (H + R - 1) / R;
       segs = B >= cus ? 1 : (cus + B - 1) / B;
       if (segs > nb) segs = nb;
     } else {
       float best = -1.f;
       const int lo = (int)(Rmax < 8 ? Rmax : 8);
-      for (int r = (int)Rmax; r >= lo; r--) {
+      for (int r = (int)Rmax; r >= lo; r -= p_src) {
         const int nb = (H + r - 1) / r;
         // far fewer crops than CUs: cus / B workgroups per crop, all resident at once; from half a crop per CU on: up to
         // 8 per crop (200 crops as 200 workgroups leave 56 CUs idle for a whole crop's time)
@@ -635,16 +669,18 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
     if (segs > nbands) segs = nbands;
     if (segs > 65535) segs = 65535;
     const size_t lds = (size_t)((F + 7) & ~7) * 6 + (((size_t)R * W * 4 + 15) & ~(size_t)15) + (size_t)kBandWaves * kBandScratchBytes;
-    static AttrDone attr_done[2];   // per (kernel, device)
+    static AttrDone attr_done[4];   // per (kernel, device)
     auto launch = [&](auto kernel, int which) -> int {
       const hipError_t e = allow_dynamic_lds(kernel, kLds - 4096, &attr_done[which]);   // (the static arrays take the rest)
       if (e != hipSuccess) return (int)e;
       hipLaunchKernelGGL(kernel, dim3((unsigned)B, (unsigned)segs), dim3(kBandWaves * 64), lds, s, src, faces, B, F, NV, W, H,
-                         depth, R, nbands);
+                         depth, R, nbands, resize_S, p_src, p_out, clamp_max);
       return (int)hipGetLastError();
     };
+    if (resize_S > 0) return indexed ? launch(tri_band_kernel<true, true>, 2) : launch(tri_band_kernel<false, true>, 3);
     return indexed ? launch(tri_band_kernel<true>, 0) : launch(tri_band_kernel<false>, 1);
   }
+  if (resize_S > 0) return -1;
   const size_t n = (size_t)B * W * H;
   uint32_t *z = reinterpret_cast<uint32_t *>(depth);
   const size_t n4 = n / 4;
@@ -664,6 +700,13 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
       hipLaunchKernelGGL(tri_raster_kernel<false>, dim3(blocks), dim3(256), 0, s, src, faces, B, F, NV, W, H, depth);
   }
   return (int)hipGetLastError();
+}
+
+// shr_mesh_depth_fwd's non-lattice sizes (mesh_depth.hip): vertices + faces -> clamp + resize of the 640 x 640 raster as
+// ONE band-kernel launch; -1 when the band kernel does not take the problem
+int shr::tri_band_resize(const float *vertices, const int *faces, int B, int NV, int F, int src_size, int S, float clamp_max,
+                         float *depth, hipStream_t s) {
+  return tri_raster_common(true, vertices, faces, B, F, NV, src_size, src_size, depth, s, S, clamp_max);
 }
 
 extern "C" int shr_tri_raster_fwd(const float *face_vertices, int B, int F, int W, int H, float *depth,

@@ -99,7 +99,7 @@ def sphere_raster_bwd(spheres, grad_depth, argmin=None):
 
 TUNE_FWD_LDS_BYTES, TUNE_FWD_OWNER_LDS_BYTES, TUNE_BWD_LDS_BYTES, TUNE_FORCE_GENERAL, TUNE_FWD_WAVES = 1, 2, 3, 4, 5
 TUNE_FWD_SHARES, TUNE_BWD_SHARES, TUNE_D2M_WAVES, TUNE_D2M_BAND_UNITS, TUNE_PERSISTENT, TUNE_FWD_ZBUF_BYTES = 6, 7, 8, 9, 10, 11
-TUNE_BWD_WAVES, TUNE_MSE_BOX, TUNE_FWD_RUN_TABLE, TUNE_D2M_TILED, TUNE_TRI_BAND = 12, 13, 14, 15, 16
+TUNE_BWD_WAVES, TUNE_MSE_BOX, TUNE_FWD_RUN_TABLE, TUNE_D2M_TILED, TUNE_TRI_BAND, TUNE_MESH_BAND = 12, 13, 14, 15, 16, 17
 
 
 def set_tuning(key, value):

@@ -201,6 +201,33 @@ def test_fused_depth_render_equals_the_explicit_chain(S):
     assert (fused < 100).float().mean().item() > 0.02
 
 
+@pytest.mark.parametrize("S", [256, 320, 400, 500, 640, 230])
+@pytest.mark.parametrize("B", [1, 5, 70, 300])
+def test_band_kernel_with_resize_epilogue_equals_the_tile_kernel(S, B):
+    """Sizes without a lattice kernel whose resize samples at least half of the source pixels (S = 256 from 640 ...):
+    the triangle band kernel at full resolution with clamp + resize as its stream-out (tri_raster.hip RESIZE) against the
+    tile kernel (SHR_TUNE_MESH_BAND 0) -- the same rasterized values through the same bilinear formula: bit for bit, at
+    every launch plan (one crop: many workgroups per crop; 300 crops: more crops than CUs)."""
+    from spherehand_amd import hand_model, ops
+    from spherehand_amd.joint_angle import sample_poses
+    from spherehand_amd.kinematicsTransformation import HandTransformationMat
+    from spherehand_amd.render import DepthRender
+    mesh = hand_model.load_mesh()
+    dr = DepthRender(mesh, S).cuda()
+    fk = HandTransformationMat([b["offset_matrix"].astype("float32") for b in mesh["bones"]]).cuda()
+    with torch.no_grad():
+        verts = dr.lbs(fk(sample_poses(B, seed=S).cuda()), dr.camera, None).contiguous()
+    faces = dr.rasterizer.faces_i32
+    try:
+        ops.set_tuning(ops.TUNE_MESH_BAND, 0)
+        tile = ops.mesh_depth_fwd(verts, faces, S, 640, 100.0)
+    finally:
+        ops.set_tuning(ops.TUNE_MESH_BAND, 1)
+    band = ops.mesh_depth_fwd(verts, faces, S, 640, 100.0)
+    assert torch.equal(band, tile)
+    assert 0.02 < (band < 100).float().mean().item() < 0.6
+
+
 @pytest.mark.parametrize("S", [400, 500, 640])
 def test_tile_kernel_at_small_ratios(S):
     """shr_mesh_depth_fwd accepts any S <= 640: ratios below 2 (every source pixel sampled, bilinear weights on
