@@ -526,7 +526,7 @@ tri_band_kernel(const float *__restrict__ src, const int *__restrict__ faces, in
       for (int i = tid; i < orows * S; i += kBandWaves * 64) {
         const int r = i / S, ox = i - r * S;
         const Lin ly = lin_index(oy_lo + r, scale, height), lx = lin_index(ox, scale, width);
-        const float *r0 = cells + ly.i0 * width, *r1 = cells + ly.i1 * width;
+        const float *r0 = cells + ly.i0 * width, *r1 = cells + min(ly.i1, hi) * width;   // (i1 <= hi whenever scale > 1)
         const float v00 = fminf(r0[lx.i0], clamp_max), v01 = fminf(r0[lx.i1], clamp_max);
         const float v10 = fminf(r1[lx.i0], clamp_max), v11 = fminf(r1[lx.i1], clamp_max);
         gout[i] = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
@@ -610,7 +610,7 @@ static int tri_raster_common(bool indexed, const float *src, const int *faces, i
                              float *depth, hipStream_t s, int resize_S = 0, float clamp_max = 0.f) {
   int p_src = 1, p_out = 1;
   if (resize_S > 0) {
-    if (W != H || resize_S > H) return -1;
+    if (W != H || resize_S >= H) return -1;   // (scale 1: the second tap, weight 0, is the NEXT period's first row)
     int a = H, c = resize_S;
     while (c) { const int t = a % c; a = c; c = t; }
     p_src = H / a; p_out = resize_S / a;
