@@ -123,6 +123,73 @@ def pmc_traffic(kernel):
         return None, None
 
 
+VALU_ISSUE_PER_S = 1024 * 2.4e9 / 4     # wave64 VALU instructions the device can issue per second: 256 CUs x 4 SIMDs, one per
+#                                          4 cycles per SIMD at 2.4 GHz (MI355X_MICROARCH.md) -- the ceiling of an issue-bound kernel
+
+
+def sq_valu(kernel, grid=None):
+    """Wave-level VALU instructions per launch of `kernel` (name substring; `grid` = total work-items of the launch, to
+    tell a kernel's problem sizes apart) from the newest committed SQ-counter summary (profiles/rNN_sq_counters.json:
+    rocprofv3 --pmc SQ_INSTS_VALU ... passes of the same launches; counters cannot be read from inside the process).
+    -> (valu, salu, source) or (None, None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")))
+    if not files:
+        return None, None, None
+    try:
+        d = json.load(open(files[-1]))
+    except ValueError:
+        return None, None, None
+    best = None
+    for k, v in d.items():
+        if not isinstance(v, dict) or kernel not in k:
+            continue
+        if grid is not None and not k.endswith("grid=%d" % grid):
+            continue
+        c = v.get("counters_mean_per_launch", {})
+        if "SQ_INSTS_VALU" in c and (best is None or v.get("launches_seen", 0) > best[2]):
+            best = (c["SQ_INSTS_VALU"], c.get("SQ_INSTS_SALU"), v.get("launches_seen", 0))
+    if best is None:
+        return None, None, None
+    return best[0], best[1], os.path.relpath(files[-1], ROOT)
+
+
+def valu_roof(kernel, grid, us, hbm_bytes):
+    """An ISSUE-bound kernel's line: bound "valu", the profiled wave-instruction count of this launch shape, the fraction
+    of the device's VALU issue rate it sustains over the LIVE duration, and the HBM fraction beside it (hbm_frac: the
+    same algorithmic bytes / duration / 8 TB/s the older lines called `frac`)."""
+    valu, salu, src = sq_valu(kernel, grid)
+    h = roof(hbm_bytes, us)
+    out = {"bound": "valu", "valu_insts": None if valu is None else int(valu), "salu_insts": None if salu is None else int(salu),
+           "valu_issue_peak_per_s": VALU_ISSUE_PER_S,
+           "valu_issue_frac": None if valu is None else round(valu / (VALU_ISSUE_PER_S * us * 1e-6), 4),
+           "valu_source": src, "hbm_frac": h["frac"], "hbm_achieved_GBs": h["achieved"],
+           "algorithmic_bytes_per_launch": h["algorithmic_bytes_per_launch"]}
+    return out
+
+
+def headline_timeline():
+    """The in-kernel timeline of the two headline kernels (newest profiles/rNN_headline_timeline.json, tools/
+    headline_timeline.py: s_memtime stamps of every wave at the phase boundaries): where a launch's microseconds are."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_headline_timeline.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        out = {"source": os.path.relpath(files[-1], ROOT)}
+        for k in ("fwd", "bwd"):
+            w, l = d[k]["inside_a_workgroup_us"], d[k]["launch_on_the_device_clock_us"]
+            pick = lambda dd, key: next(v for kk, v in dd.items() if key in kk)
+            out[k] = {"prologue_us": pick(w, "PROLOGUE"), "scan_or_walk_us": pick(w, "slowest wave done"),
+                      "stream_out_or_combine_us": pick(w, "second barrier"), "workgroup_lifetime_us": pick(w, "lifetime, median"),
+                      "outside_the_waves_us": pick(l, "outside the stamps"),
+                      "launch_us_of_the_instrumented_build": next(v for kk, v in d[k].items() if kk.startswith("hip_event_us"))}
+        return out
+    except (KeyError, ValueError, StopIteration):
+        return None
+
+
 def rocprof_avg_us():
     """AverageNs of the two headline kernels in the newest committed rocprofv3 --kernel-trace --stats summary of this
     command (profiles/rNN_bench_kernel_stats.csv), beside the live HIP-event means: {fwd, bwd, source} or None."""
@@ -429,11 +496,16 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
         # two-step data->model (the path the loss takes): images read once (4 S^2 each) and their foreground written as
         # 8-byte points; the search reads every crop's image list (8 B per point) + the 41 records
         "d2m_compact_kernel": dict(us=round(t_cmp, 1), images=M5, **roof(M5 * 4 * S5 * S5 + 8 * fg_px, t_cmp)),
-        "d2m_points_kernel": dict(us=round(t_pts, 1), parts=Pp, **roof(3 * 8 * fg_px + n5 * 16 * J, t_pts)),
+        # (issue-bound: DESIGN 4.3 -- 12 VALU instructions per (point, sphere) evaluated; 8-wave workgroups, one per crop)
+        "d2m_points_kernel": dict(us=round(t_pts, 1), parts=Pp, **valu_roof("d2m_points_kernel<true, 8>", n5 * Pp * 512, t_pts,
+                                                                             3 * 8 * fg_px + n5 * 16 * J)),
         # the streaming kernel (round 2; still behind shr_data_to_model_partial): every pair reads its image (4 S^2)
-        "data_to_model_kernel": dict(us=round(t_d2m, 1), workgroups_per_crop=R, **roof(n5 * (4 * S5 * S5 + 16 * J), t_d2m)),
+        "data_to_model_kernel": dict(us=round(t_d2m, 1), workgroups_per_crop=R,
+                                     **valu_roof("data_to_model_kernel<true, 4, true>", n5 * R * 256, t_d2m, n5 * (4 * S5 * S5 + 16 * J))),
         # fused render-and-compare: reads the observed image, writes the projection (returned by the loss)
-        "sphere_zbuf_mse_kernel": dict(us=round(t_mse, 1), **roof(n5 * (8 * S5 * S5 + 32 * J), t_mse)),
+        # (issue-bound: DESIGN 4.2b; the box variant, Rm row regions per crop, 16 waves per workgroup)
+        "sphere_zbuf_mse_kernel": dict(us=round(t_mse, 1), **valu_roof("sphere_zbuf_mse_box_kernel", n5 * Rm * 1024, t_mse,
+                                                                       n5 * (8 * S5 * S5 + 32 * J))),
     }
     del ws, ls2, gr2
     del ds, crit, real, obs, dep, gsp, gr
@@ -450,7 +522,8 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     a = [t.data_ptr() for t in (obs, index, cen, rad, ls, gr)]
     t_d2m = mean_launch_us(lambda s: _lib.check(lib.shr_data_to_model_partial(a[0], a[1], a[2], 3, a[3], n5, J, S, S, R,
                                                                                a[4], a[5], s), "d2m"), stream, 40, 3, 3)
-    sec["data_to_model_kernel_1152_crops_128x128"] = dict(us=round(t_d2m, 1), **roof(n5 * (4 * S * S + 16 * J), t_d2m))
+    sec["data_to_model_kernel_1152_crops_128x128"] = dict(us=round(t_d2m, 1), **valu_roof("data_to_model_kernel<true, 4, false>", n5 * R * 256,
+                                                                                         t_d2m, n5 * (4 * S * S + 16 * J)))
     # the same loss through the two-step path (384 images compacted once, 1152 point-list searches): what
     # ops.data_to_model takes from 2^23 observed pixels on -- at this size the fused loss gains nothing from it
     # (111 us either way), the stand-alone term does
@@ -472,7 +545,8 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
     m = [t.data_ptr() for t in (spheres, tgt, dep, sse, gsp)]
     t = mean_launch_us(lambda s: _lib.check(lib.shr_sphere_raster_mse(m[0], BATCH, J, S, S, m[1], None, m[2], m[3], m[4], s),
                                             "mse"), stream, 200, 3, 20)
-    sec["fused_render_and_compare_256_crops_128x128"] = dict(us=round(t, 2), **roof(BATCH * (8 * S * S + 32 * J), t))
+    sec["fused_render_and_compare_256_crops_128x128"] = dict(us=round(t, 2), **valu_roof("sphere_zbuf_mse_kernel<true, false>", BATCH * 1024, t,
+                                                                                        BATCH * (8 * S * S + 32 * J)))
 
     # ---- triangle path: DepthRender (skinning + fused raster/clamp/resize) and the literal 640x640 drop-in ----
     fkm = HandTransformationMat([b["offset_matrix"].astype("float32") for b in mesh["bones"]]).to(dev)
@@ -498,12 +572,54 @@ def secondary(lib, _lib, dev, stream, graph_step_us):
                                                "mesh_render"), stream, 20, 3, 3)
     sec["depth_render_256_crops_128x128"] = {"module_us": round(t_dr, 1),
                                              "one_launch_mesh_lattice_kernel_with_skinning_us": round(t_fr, 1),
-                                             "mesh_lattice_kernel": dict(us=round(t_md, 1), **roof(BATCH * (16 * nv + 4 * S * S) + 12 * nf, t_md))}
+                                             # (issue-bound: the reference's seven IEEE divisions per sampled pixel)
+                                             "mesh_lattice_kernel": dict(us=round(t_md, 1), **valu_roof("mesh_lattice_kernel<1, 16, 32, false", BATCH * 1024, t_md,
+                                                                                                      BATCH * (16 * nv + 4 * S * S) + 12 * nf))}
+    # ---- DepthRender at config 5's resolution (S = 256 from 640: no lattice; the band kernel with the resize epilogue) and
+    # HandSynthesizer (network/util_modules.py:104-122: FK + RandScale + DepthRender + x depth_scale + DepthNoise + heat-maps)
+    # as ONE launch, eager and as a hipGraph
+    from spherehand_amd.util_modules import HandSynthesizer
+    dr256 = DepthRender(mesh, 256).to(dev)
+    with torch.no_grad():
+        T64 = T[:64].contiguous()
+        t_dr256 = torch_us(lambda: dr256(T64), 20)
+        v256 = dr256.lbs(T64, dr256.camera, None).contiguous()
+    out256 = torch.empty(64, 256, 256, device=dev)
+    t_md256 = mean_launch_us(lambda s: _lib.check(lib.shr_mesh_depth_fwd(v256.data_ptr(), v[1], 64, nv, nf, 640, 256, 100.0, out256.data_ptr(), s),
+                                                  "mesh_depth"), stream, 20, 3, 3)
+    sec["depth_render_64_crops_256x256_us"] = {"module_us": round(t_dr256, 1), "tri_band_kernel_with_resize_epilogue_us": round(t_md256, 1),
+                                               "is": "DepthRender(mesh, 256): skinning launch + the triangle band kernel at 640 x 640 whose "
+                                                     "stream-out is clamp + bilinear resize (round 5: the tile kernel, 304 us)"}
+    del out256, v256
+    syn = HandSynthesizer(mesh, S, 16, 1.0, 0.01).to(dev)
+    pose_syn = sample_poses(BATCH, seed=2).to(dev)
+    syn_eager = sorted(mean_launch_us(lambda _s: syn(pose_syn), stream, 50, 1, 20 if i == 0 else 0, warm_ms=300.0 if i == 0 else 0.0)
+                       for i in range(5))
+    gsyn = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gsyn, stream=stream):
+        syn(pose_syn)
+    t_syn_graph = mean_launch_us(lambda _s: gsyn.replay(), stream, 100, 3, 10)
+    del gsyn
+    syn.one_launch = False
+    t_syn3 = mean_launch_us(lambda _s: syn(pose_syn), stream, 50, 3, 20)
+    syn.fused = False
+    t_syn_modules = mean_launch_us(lambda _s: syn(pose_syn), stream, 30, 3, 10)
+    sec["hand_synthesizer_256_crops_128x128_us"] = {
+        "eager_us": round(syn_eager[2], 1), "eager_fastest_slowest_batch_us": [round(syn_eager[0], 1), round(syn_eager[-1], 1)],
+        "one_hipgraph_us": round(t_syn_graph, 1), "three_launches_eager_us": round(t_syn3, 1),
+        "module_by_module_us": round(t_syn_modules, 1), "heatmap_size": 16,
+        "is": "256 poses -> (noised scaled depth [256,128,128], uv / depth heat-maps [256,41,16,16], key-points): ONE launch "
+              "(shr_hand_synth_fwd: every workgroup runs its crop's FK + draws, skins, rasterizes, scales, noises, paints); "
+              "three_launches = shr_synth_pose_fwd + shr_mesh_render_post_fwd + shr_heatmap_render_fwd; module_by_module = "
+              "round 5's chain (fused = False: ~15 launches, torch RNG)"}
+    del syn
     raw = torch.empty(BATCH, 640, 640, device=dev)
     r = [fv.data_ptr(), raw.data_ptr()]
     t_tri = mean_launch_us(lambda s: _lib.check(lib.shr_tri_raster_fwd(r[0], BATCH, nf, 640, 640, r[1], s), "tri"),
                            stream, 5, 3, 2)
-    sec["depth_rasterization_forward_640x640_256_crops"] = dict(us=round(t_tri, 1), **roof(BATCH * (36 * nf + 4 * 640 * 640), t_tri))
+    # (bound by the reference's seven IEEE divisions per covered pixel: latency / issue; HBM fraction beside it)
+    sec["depth_rasterization_forward_640x640_256_crops"] = dict(us=round(t_tri, 1), **valu_roof("tri_band_kernel<false", None, t_tri,
+                                                                                                BATCH * (36 * nf + 4 * 640 * 640)))
     del raw, fv
 
     # ---- the whole north-star chain once: pose[256,26] -> FK -> key-point skinning -> raster forward -> backward ->
@@ -760,6 +876,26 @@ def main():
                 step_full()
             stream.synchronize()
         elapsed_full = timed_steps(step_full, args.steps, args.warmup, dist, dev)
+        # STRONG-scaling leg: BASELINE's batch of 256 crops split over the ranks (256 / N each, the same step, max-over-ranks
+        # time) -- the metric as BASELINE.json words it ("batch 256 ... at 1/2/4/8 MI355X"); at N = 1 it IS the headline.
+        strong = None
+        if world > 1 or dist is not None:
+            n_strong = max(1, BATCH // world)
+            sp_s, gp_s = spheres[:n_strong].contiguous(), grad[:n_strong].contiguous()
+            d_s, o_s, g_s = depth[:n_strong], owner[:n_strong], gsph[:n_strong]
+            ps = [t.data_ptr() for t in (sp_s, gp_s, d_s, g_s, o_s)]
+
+            def step_strong():
+                _lib.check(lib.shr_sphere_raster_fwd_ex(ps[0], n_strong, J, S, S, ps[2], ps[4], OWNER_TOUCHED_ROWS, sh), "fwd")
+                _lib.check(lib.shr_sphere_raster_bwd(ps[0], ps[1], ps[4], n_strong, J, S, S, ps[3], sh), "bwd")
+            t0 = time.perf_counter()
+            while (time.perf_counter() - t0) * 1e3 < CLOCK_WARMUP_MS:
+                for _ in range(50):
+                    step_strong()
+                stream.synchronize()
+            el_s = timed_steps(step_strong, args.steps, args.warmup, dist, dev)
+            strong = {"value": round(world * n_strong * args.steps / el_s, 1), "unit": "crops/s", "crops_per_rank": n_strong,
+                      "global_batch": world * n_strong, "ms_per_step": round(el_s / args.steps * 1e3, 6)}
         big = sec = None
         if rank == 0 and world == 1 and dist is None and not args.no_secondary:
             # one hipGraph replay of the headline step (forward + backward as one graph launch)
@@ -833,6 +969,12 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 6),
             "higher_is_better": True,
             "scaling": "weak",
+            # the same metric with BASELINE's batch of 256 SPLIT over the ranks (256 / N crops each; N = 1: the headline itself)
+            "strong": strong if strong is not None else {"value": round(world * BATCH * args.steps / elapsed, 1), "unit": "crops/s",
+                                                         "crops_per_rank": BATCH, "global_batch": BATCH,
+                                                         "ms_per_step": round(elapsed / args.steps * 1e3, 6)},
+            "strong_is": "strong scaling: a global batch of 256 crops, 256 / N per rank, max-over-ranks time of the same K steps; "
+                         "`value` is weak scaling (256 crops per rank)",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -881,7 +1023,8 @@ def main():
                                                    "sc1 stores of depth + the owner bytes of %d rows, the records read: "
                                                    "no arithmetic (shr_selftest_launch_floor)" % (BATCH, floor_lds, rows_t),
                                           **{k: v for k, v in roof(bytes_fwd, floor_us).items() if k in ("achieved", "frac")}},
-                         "plain_fill_of_the_depth_output_us": round(fill_us, 3)},
+                         "plain_fill_of_the_depth_output_us": round(fill_us, 3),
+                         "timeline": headline_timeline()},
         }
         if big is not None:
             out["roofline"]["large_batch"] = big

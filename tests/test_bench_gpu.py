@@ -53,6 +53,7 @@ def test_bench_one_rank_over_rccl():
     assert sec["grad_bucket_bytes"] == 2308946 * 4 and sec["grad_bucket_allreduce_us"] > 0
     assert sec["ddp_training_step_25x3_real_48_synt_64x64_ms"] > 0
     assert d["value"] > 1e6 and 0 < d["roofline"]["frac"] < 1
+    assert d["strong"]["crops_per_rank"] == 256 and d["strong"]["value"] > 1e6       # (one rank: the whole batch)
 
 
 def test_bench_starts_its_own_ranks():
@@ -71,6 +72,10 @@ def test_bench_starts_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["config"]["rccl_ranks"] == 2
     assert abs(d["value"] - 2 * 256 * 20 / (d["ms_per_step"] * 1e-3 * 20)) <= 1e-3 * d["value"]
+    # both scaling legs: weak (256 crops per rank: `value`) and strong (BASELINE's batch of 256 split over the ranks)
+    assert d["scaling"] == "weak" and d["strong"]["crops_per_rank"] == 128 and d["strong"]["global_batch"] == 256
+    assert abs(d["strong"]["value"] - 256 / (d["strong"]["ms_per_step"] * 1e-3)) <= 1e-3 * d["strong"]["value"]
+    assert d["strong"]["value"] > 1e5
 
 
 def test_bench_rejects_a_world_size_mismatch():
