@@ -82,6 +82,10 @@ constexpr int kPadRows = 0;   // rows after the region's last (none: a chunk nev
 #ifndef SHR_BG_WAVES
 #define SHR_BG_WAVES 7
 #endif
+#ifndef SHR_BG_WAVES_BOX
+#define SHR_BG_WAVES_BOX SHR_BG_WAVES
+#endif
+constexpr int kBgWavesBox = SHR_BG_WAVES_BOX;   // ... in the BOX kernels (two workgroups per CU: launches that are VALU-issue-bound)
 constexpr int kBgWaves = SHR_BG_WAVES;   // forward: waves that store the background rows before the first barrier
 // (storing them after the barrier instead, with smaller list shares for those waves, moves the barrier from 4.6 k
 // to 3.8 k cycles but the stores then cost the scan conversion more than that: measured 8.9 vs 8.6 us)
@@ -98,7 +102,10 @@ __device__ __forceinline__ uint32_t depth_key(float d) {
   return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
 }
 __device__ __forceinline__ float key_depth(uint32_t k) {
-  return __uint_as_float(k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu));
+  // (top bit set: the float was non-negative, only the sign flips back; clear: every bit does -- an arithmetic shift and one
+  // three-input bit operation.  The select form, k ^ (k & 0x80000000 ? 0x80000000 : ~0), compiled to a 64-bit compare +
+  // select + xor per cell on the u64 z-buffers; same bits, and no measurable difference: round 6, tools/ab_variant.py)
+  return __uint_as_float(k ^ ((uint32_t)(~((int32_t)k >> 31)) | 0x80000000u));
 }
 // 64-bit cells (depth key << 32 | owner): ds_min_u64 keeps the nearest hit and, among equal depths, the lowest sphere
 // index; the background cell is (key(100) << 32 | 0xFFFFFFFF).  One case needs a second look when a cell is decoded:
@@ -879,7 +886,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   // traffic of their own in front of the request their records are there ~0.7 k cycles after the wave's start.
   // (Measured and not kept on this split: the storing waves at raised priority, +0.1 us; the initialisation of the
   // touched rows only, once the records are in, +0.2 us; other work-list shares.)
-  const int nbgw = TABLE ? 8 : min(kBgWaves, nwaves - 1);
+  const int nbgw = TABLE ? 8 : min(BOX ? kBgWavesBox : kBgWaves, nwaves - 1);
   const int bg_first = TABLE ? 8 : 1;
   const bool bg_wave = nwaves == 1 || (wave_s >= bg_first && wave_s < bg_first + nbgw);
   const bool valid = lane < J;
@@ -1571,7 +1578,8 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   Axis ax = axis_of(W, axk.mulx), ay = axis_of(H, axk.muly);
   const float kx = axk.kx, ky = axk.ky;   // pixels per millimetre (launch constants: common.h AxisK)
   const int wave_s = rfl(wave);
-  const bool bg_wave = wave_s >= 1 && wave_s <= kBgWaves;
+  constexpr int kBgW = BOX ? kBgWavesBox : kBgWaves;
+  const bool bg_wave = wave_s >= 1 && wave_s <= kBgW;
   const bool valid = lane < J;
   const bool pf_wave = wave_s == kZWaves - 1;
   const bool has_next = PERSIST && n + crop_step < N;
@@ -1635,7 +1643,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
     if (out) {
       const float4 bgd = make_float4(kBackground, kBackground, kBackground, kBackground);
       const int nbg = ua + (nunits - ub);
-      for (int t = wave_s - 1; t < nbg; t += kBgWaves) {
+      for (int t = wave_s - 1; t < nbg; t += kBgW) {
         const int u = t < ua ? t : t - ua + ub;
         const int c = (u << 6) + lane;
         if (c < nchunk) stream_store(out4 + c, bgd);
@@ -1747,10 +1755,11 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
       }
       const float e0 = d.x - t.x, e1 = d.y - t.y, e2 = d.z - t.z, e3 = d.w - t.w;
       sse += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
-      k01.x = ((Key)__float_as_uint(2.f * e0) << 32) | (k01.x & 0xffu);
-      k01.y = ((Key)__float_as_uint(2.f * e1) << 32) | (k01.y & 0xffu);
-      k23.x = ((Key)__float_as_uint(2.f * e2) << 32) | (k23.x & 0xffu);
-      k23.y = ((Key)__float_as_uint(2.f * e3) << 32) | (k23.y & 0xffu);
+      // (the low word stays as it is -- the owner's index, 0xFFFFFFFF on a background cell: the walk compares its low byte)
+      k01.x = ((Key)__float_as_uint(2.f * e0) << 32) | (uint32_t)k01.x;
+      k01.y = ((Key)__float_as_uint(2.f * e1) << 32) | (uint32_t)k01.y;
+      k23.x = ((Key)__float_as_uint(2.f * e2) << 32) | (uint32_t)k23.x;
+      k23.y = ((Key)__float_as_uint(2.f * e3) << 32) | (uint32_t)k23.y;
       cell[0] = k01;
       cell[1] = k23;
     };

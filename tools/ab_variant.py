@@ -1,16 +1,21 @@
 """A/B of the sphere rasterizer forward / backward between the product library and a variant built with extra -D flags:
     python tools/ab_variant.py build -DEXP_FLAG ...     (anywhere: tools/libspherehand_exp.so)
-    python tools/ab_variant.py                          (GPU box: alternating timings at 256 / 1152 / 9216 crops, same-bits check)"""
+    python tools/ab_variant.py build:NAME -DEXP_FLAG ...   (several variants side by side: tools/libspherehand_exp_NAME.so)
+    python tools/ab_variant.py                          (GPU box: alternating timings at 256 / 1152 / 9216 crops, same-bits check,
+                                                         the product library against every variant library found)"""
 import ctypes, glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 EXP = os.path.join(ROOT, "tools", "libspherehand_exp.so")
 
 
-def build(flags):
+def build(flags, name=""):
+    global EXP
+    if name:
+        EXP = os.path.join(ROOT, "tools", "libspherehand_exp_%s.so" % name)
     from spherehand_amd import build as b
     b.build()
-    obj = "/tmp/sphere_raster_exp.o"
+    obj = "/tmp/sphere_raster_exp%s.o" % name
     subprocess.check_call([b.HIPCC] + [f for f in b.FLAGS if f != "-shared"] + flags +
                           ["-c", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(b.PKG, "csrc"), "-o", obj,
                            os.path.join(b.PKG, "csrc", "sphere_raster.hip")])
@@ -27,7 +32,9 @@ def main():
     from spherehand_amd.kinematicsTransformation import HandTransformationMat
     from spherehand_amd.render import HandBallPrimitiveRender
     vp, i = ctypes.c_void_p, ctypes.c_int
-    libs = {"product": _lib.lib(), "variant": ctypes.CDLL(EXP)}
+    libs = {"product": _lib.lib()}
+    for f in sorted(glob.glob(os.path.join(ROOT, "tools", "libspherehand_exp*.so"))):
+        libs[os.path.basename(f)[len("libspherehand_exp"):-3].lstrip("_") or "variant"] = ctypes.CDLL(f)
     for l in libs.values():
         l.shr_sphere_raster_fwd_ex.argtypes = [vp, i, i, i, i, vp, vp, i, vp]
         l.shr_sphere_raster_bwd.argtypes = [vp, vp, vp, i, i, i, i, vp, vp]
@@ -67,9 +74,12 @@ def main():
                         sse = torch.empty(n * R, device=dev); gsp = torch.empty(n * R * J * 4, device=dev)
                         m = lambda s: l.shr_sphere_raster_mse(p[0], n, J, S, S, tgt.data_ptr(), None, None if os.environ.get("NODEPTH") else p[1], sse.data_ptr(), gsp.data_ptr(), s)
                         assert m(stream.cuda_stream) == 0
-                        print("n %5d %-8s render-and-compare %7.2f us" % (n, name, bench.mean_launch_us(m, stream, reps, 3, 3, warm_ms=30.0)), flush=True)
-                    print("n %5d %-8s fwd+owner %7.2f  bwd %7.2f  fwd depth-only %7.2f us%s" % (n, name, tf, tb, t0, same), flush=True)
+                        print("n %5d %-10s render-and-compare %7.2f us" % (n, name, bench.mean_launch_us(m, stream, reps, 3, 3, warm_ms=30.0)), flush=True)
+                    print("n %5d %-10s fwd+owner %7.2f  bwd %7.2f  fwd depth-only %7.2f us%s" % (n, name, tf, tb, t0, same), flush=True)
 
 
 if __name__ == "__main__":
-    build(sys.argv[2:]) if len(sys.argv) > 1 and sys.argv[1] == "build" else main()
+    if len(sys.argv) > 1 and sys.argv[1].startswith("build"):
+        build(sys.argv[2:], sys.argv[1][6:])
+    else:
+        main()
