@@ -1570,6 +1570,13 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   }
   const int region = blockIdx.y, nregions = gridDim.y;
   const int lane = tid & 63, wave = tid >> 6;
+#ifdef EXP_MSE_STAGGER   // (timing experiment: the second workgroup of every CU starts EXP_MSE_STAGGER x 3.4 us late)
+  {
+    const unsigned wg = blockIdx.x + blockIdx.y * gridDim.x;
+    if (wg >= 256u && wg < 512u)
+      for (int k = 0; k < EXP_MSE_STAGGER; k++) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   SHR_TL_ENTRY(2);
   const int r0 = region * rows_per_region;
   const int r1 = min(H, r0 + rows_per_region);
@@ -1689,6 +1696,8 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
     wl.sph = sph;
     wl.item = s_items[lane];
     wl.end = s_ends[lane];
+    // (EXP_MSE_SKIP_*: timing-only ablations of tools/ab_variant.py -- wrong results, never in the product build)
+#ifndef EXP_MSE_SKIP_SCAN
     walk_my_slice<POW2, kSphereCostMse | (SEG2 ? kSeg2Tag : 0), true>(
         wl, J, s_flag[1], wave, kZWaves, shares_fwd, lane, ax, ay, 0, clip, pitch,
         [&](int j, const float4 s, int cell_a, int cell_b, float, float ca, float yga, float ygb, bool ok_a,
@@ -1709,6 +1718,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
           }
         },
         [](int) {});
+#endif
     if (pf_wave && has_next) s_next[lane] = sph_next;
     SHR_TL(2, 3);   // this wave's scan slice is done
     // (a region no sphere touches -- the top and the bottom quarter of a 256 x 256 hand crop cut into four 64-row
@@ -1763,6 +1773,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
       cell[0] = k01;
       cell[1] = k23;
     };
+#ifndef EXP_MSE_SKIP_CONVERT
 #pragma unroll
     for (int k = 0; k < kTgtAhead; k++)
       if (wave_s + (k << 4) < nunits) convert_unit(wave_s + (k << 4), tpre[k]);
@@ -1770,6 +1781,9 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
       const int c = (u << 6) + lane;
       convert_unit(u, tgt4[min(c, nchunk - 1)]);
     }
+#else
+    sse += tpre[0].x + tpre[1].y + tpre[2].z + tpre[3].w;
+#endif
     SHR_TL(2, 5);   // this wave's convert units are done
     if (!untouched) __syncthreads();
     SHR_TL(2, 6);   // past the third barrier: the walk starts
@@ -1777,6 +1791,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
     // ---- walk (backward): static slices, per-run DPP sums into the wave's LDS row ------------
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const int cell_max = (p0 * pitch + cu0) + (pe - p0) * pitch - 1;   // the z-buffer's last cell, as the walk counts cells
+#ifndef EXP_MSE_SKIP_WALK
     walk_my_slice<POW2, kSphereCostMse | (SEG2 ? kSeg2Tag : 0), true>(
         wl, J, s_flag[1], wave, kZWaves, shares_bwd, lane, ax, ay, 0, clip, pitch,
         [&](int j, const float4 s, int cell_a, int cell_b, float dx, float ca, float yga, float ygb, bool ok_a,
@@ -1803,6 +1818,9 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
           if (lane >= 60) atomicAdd(reinterpret_cast<float *>(s_part + wave * J + j) + (lane & 3), t);
           a0 = a1 = a2 = a3 = 0.f;
         });
+#else
+    (void)cell_max; (void)a0; (void)a1; (void)a2; (void)a3;
+#endif
   }
   if (tile_lo < tile_hi) {
     // ---- general path (or the rows beyond the z-buffer): 32x8 tiles, owners and gradient in registers ---

@@ -14,7 +14,7 @@ from conftest import ROOT
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
-CASES = {"*": 200, "sphere": 100, "mesh": 100, "d2m": 150}
+CASES = {"*": 200, "sphere": 100, "mesh": 100, "d2m": 150, "band": 60, "synth": 60}
 SEED = 20260929
 
 
@@ -30,6 +30,6 @@ def test_every_family_of_the_fuzzer_is_clean(fuzz):
     lines = []
     res = fuzz.run(None, CASES, None, SEED, log=lines.append)
     print("\n".join(lines))
-    assert set(res) == {name for name, _ in fuzz.FAMILIES} and len(res) == 12
+    assert set(res) == {name for name, _ in fuzz.FAMILIES} and len(res) == 14
     assert all(n == CASES.get(name, CASES["*"]) for name, (n, _) in res.items()), res
     assert sum(m for _, m in res.values()) == 0, "\n".join(lines)

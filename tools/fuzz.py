@@ -172,6 +172,88 @@ def mesh_case():
         np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_mesh_fail.npz"), verts=verts, faces=faces, S=S, src=src,
                  tile=tile.cpu().numpy(), chain=chain.cpu().numpy(), raw=raw.cpu().numpy())
 
+def band_case():
+    """sizes whose resize samples at least half of the source pixels: the triangle band kernel with clamp + resize as its
+    stream-out (tri_raster.hip RESIZE) against the tile kernel -- same rasterized values, same bilinear formula: bit for bit;
+    both against the explicit chain on the raw raster (1e-5)"""
+    global fails
+    src = int(rs.choice([640, 320, 200, 96])); S = int(rs.choice([s_ for s_ in (64, 80, 96, 128, 160, 200, 256, 300, 320, 400, 512, 639) if s_ < src and 8 * s_ * s_ >= src * src]))
+    B = int(rs.choice([1, 2, 5, 70, 300])) if src <= 200 else int(rs.choice([1, 2, 5]))
+    NV = int(rs.choice([12, 200, 1500])); F = int(rs.choice([1, 100, 700, 3382]))
+    xy = rs.uniform(-0.15 * src, 1.15 * src, (B, NV, 2)); z = rs.uniform(-80, 140, (B, NV, 1))
+    verts = np.concatenate([xy, z, np.ones((B, NV, 1))], -1).astype(np.float32)
+    base = rs.randint(0, NV, (F, 1)); faces = ((base + rs.randint(0, max(2, NV // rs.choice([4, 40, 400])), (F, 3))) % NV).astype(np.int32)
+    if rs.rand() < 0.5:
+        verts = np.take_along_axis(verts, np.argsort(verts[:, :, 0] + verts[:, :, 1] * 0.01, 1)[:, :, None], 1)
+    band_rows = int(rs.choice([-1, -1, 8, 20]))
+    try:
+        ops.set_tuning(ops.TUNE_TRI_BAND, band_rows)      # (band heights: several launch plans of the same problem)
+        band = ops.mesh_depth_fwd(dev(verts), dev(faces), S, src, 100.0)
+        ops.set_tuning(ops.TUNE_MESH_BAND, 0)
+        tile = ops.mesh_depth_fwd(dev(verts), dev(faces), S, src, 100.0)
+    finally:
+        ops.set_tuning(ops.TUNE_MESH_BAND, 1); ops.set_tuning(ops.TUNE_TRI_BAND, -1)
+    raw = ops.tri_raster_indexed_fwd(src, src, dev(verts), dev(faces))
+    chain = torch.nn.functional.interpolate(torch.clamp(raw, max=100.0).unsqueeze(1), size=(S, S), mode="bilinear",
+                                            align_corners=False).squeeze(1)
+    ok = torch.equal(band, tile) and bool((band - chain).abs().max().item() <= 1e-5 * max(1.0, chain.abs().max().item()))
+    if not ok:
+        fails += 1
+        print("BAND-RESIZE MISMATCH", dict(B=B, NV=NV, F=F, src=src, S=S, band_rows=band_rows), int((band != tile).sum()),
+              (band - chain).abs().max().item())
+
+_syn = {}
+def synth_case():
+    """HandSynthesizer: ONE launch == three launches bit for bit (draws included); noise off == the module chain on the same
+    draws; noise on == DepthNoise on the numpy restatement of the kernels' generator (5e-6)"""
+    global fails
+    from spherehand_amd import hand_model, synth_rng
+    from spherehand_amd.util_modules import HandSynthesizer
+    S, hm = [(32, 8), (64, 16), (128, 32), (128, 16), (64, 4)][rs.randint(5)]
+    noise, heat = bool(rs.randint(2)), bool(rs.randint(2))
+    key = (S, hm)
+    if key not in _syn:
+        mesh = hand_model.load_mesh()
+        _syn[key] = [HandSynthesizer(mesh, S, hm, 1.0, 0.01).cuda() for _ in range(2)]
+    a, b = _syn[key]
+    B = int(rs.choice([1, 2, 7, 40, 300]))
+    p = (rs.uniform(-1, 1, (B, 26)) * rs.choice([0.3, 1.5, 3.2])).astype(np.float32)
+    p[:, 3:6] = rs.uniform(-40, 40, (B, 3))
+    pose = dev(p)
+    seed, ctr = int(rs.randint(1, 2 ** 31)), int(rs.randint(0, 1000))
+    for m, one in ((a, True), (b, False)):
+        m.add_noise, m.out_heatmap, m.one_launch = noise, heat, one
+        m.reseed(seed, device=pose.device); m._rng_seed = torch.initial_seed(); m.rng_state[1] = ctr
+    oa, ob = a(pose), b(pose)
+    oa, ob = (oa, ob) if heat else ((oa,), (ob,))
+    why = []
+    if not (torch.equal(a.last_draws.view(torch.int32), b.last_draws.view(torch.int32)) and all(torch.equal(x, y) for x, y in zip(oa, ob))):
+        why.append("one launch != three launches: draws %s, outputs %s" % (torch.equal(a.last_draws.view(torch.int32), b.last_draws.view(torch.int32)),
+                                                                          [int((x != y).sum()) for x, y in zip(oa, ob)]))
+    f, keys = synth_rng.sample_draws(seed, ctr, B, 0.1)
+    d = a.last_draws.cpu().numpy()
+    if not (np.array_equal(bits(d[0:4]), bits(f)) and np.array_equal(d[4:6].view(np.uint32), keys)):
+        why.append("draws != numpy restatement")
+    dr = a.last_draws
+    T = a.hand_skeleton_transform(pose) * torch.cat([dr[0:3].t(), torch.ones(B, 1, device="cuda")], 1).view(B, 1, 4, 1)
+    with torch.no_grad():
+        clean = a.dm_render(T, dr[3].clone()) * a.depth_scale
+    if noise:
+        expect = synth_rng.depth_noise(clean.cpu().numpy(), keys, 0.5, 0.05)
+        err = np.abs(oa[0].cpu().numpy() - expect)
+        if not err.max() <= 5e-6:      # (v_log_f32 near 1: see tests/test_synth_gpu.py)
+            why.append("noise: max err %.3g at %s (%d px above 5e-6)" % (err.max(), np.unravel_index(err.argmax(), err.shape), int((err > 5e-6).sum())))
+    elif not torch.equal(oa[0], clean):
+        why.append("clean depth != module chain")
+    if heat:
+        with torch.no_grad():
+            hm_ref = a.hm_render(T, dr[3].clone(), a.uv_hm_scale, a.depth_scale)
+        if not all(torch.equal(x, y) for x, y in zip(oa[1:], hm_ref)):
+            why.append("heat-maps != module")
+    if why:
+        fails += 1
+        print("SYNTH MISMATCH", dict(S=S, hm=hm, B=B, noise=noise, heat=heat, seed=seed, ctr=ctr), why)
+
 _fk = None
 def fk_case():
     """forward kinematics forward / backward against the torch-op evaluation of the same chain"""
@@ -419,7 +501,8 @@ def ks_case():
 
 
 FAMILIES = (("sphere", sphere_case), ("tri", tri_case), ("d2m", d2m_case), ("mesh", mesh_case), ("fk", fk_case), ("gn", gn_case),
-            ("mv", mv_case), ("sa", sa_case), ("pl", pl_case), ("lbs", lbs_case), ("hm", hm_case), ("ks", ks_case))
+            ("mv", mv_case), ("sa", sa_case), ("pl", pl_case), ("lbs", lbs_case), ("hm", hm_case), ("ks", ks_case),
+            ("band", band_case), ("synth", synth_case))
 
 
 def reset_tuning():
