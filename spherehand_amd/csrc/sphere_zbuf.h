@@ -1705,6 +1705,14 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
           const float dya = yga - s.y, dyb = ygb - s.y;
           float qa = ca - dya * dya, qb = ca - dyb * dyb;
           if (decltype(row_test)::value) { qa = ok_a ? qa : -1.f; qb = ok_b ? qb : -1.f; }
+#ifdef EXP_MSE_SCAN_JUNK   // (timing experiment: EXP_MSE_SCAN_JUNK independent VALU instructions more per chunk pair)
+          {
+            float junk = qa;
+#pragma unroll
+            for (int k = 0; k < EXP_MSE_SCAN_JUNK; k++) asm volatile("v_add_f32 %0, %1, %1" : "=v"(junk) : "v"(qb));
+            asm volatile("" : : "v"(junk));
+          }
+#endif
           unsigned jv = (unsigned)j;
           asm("" : "+v"(jv));   // (kept in the low register of the 64-bit pair across the run, see the forward)
           auto put = [&](Key *cell, float d) { atomicMin(cell, ((Key)depth_key(d) << 32) | jv); };
