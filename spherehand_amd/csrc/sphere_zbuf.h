@@ -864,6 +864,13 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
     asm volatile("" : "+v"(tid));
   }
   const int lane = tid & 63, wave = tid >> 6;
+  // BOX (two workgroups per CU): a workgroup in its PROLOGUE -- records, list, background rows: latency and stores, few
+  // instructions, and every wave has to arrive -- outranks the co-resident workgroup's scan, whose waves otherwise win the
+  // SIMDs' oldest-first arbitration and stretch this phase (in-kernel timeline: the youngest waves reach the first barrier
+  // last).  Round 6, tools/ab_variant.py: forward + owner bytes 23.8 -> 22.5 us at 1152 crops, 41.9 -> 39.1 at 2304, depth-only
+  // @256 x 256 57.8 -> 55.3; 9216 crops unchanged; the same bits.  (Priority 2 or 3: the same.  The stream-out at raised
+  // priority: nothing.  The backward's staging at raised priority: +3 % at 9216 crops -- not taken.)
+  if (BOX) __builtin_amdgcn_s_setprio(1);
   SHR_TL_ENTRY(0);
   // (the workgroup size rides in the same launch argument: blockDim.x is a hidden kernel argument that is NOT among
   // the preloaded ones -- reading it put an s_load round trip in front of the records' request)
@@ -1051,6 +1058,7 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   }
   SHR_TL(0, 1);   // this wave's work in front of the first barrier is done (list / table / background rows / init)
   __syncthreads();
+  if (BOX) __builtin_amdgcn_s_setprio(0);
   SHR_TL(0, 2);   // past the first barrier: the scan starts
   if (!(list_wave || bg_wave || tab_wave)) sph = s_sph[lane];
   const bool has_next = PERSIST && n + crop_step < N;   // (the launcher keeps a prefetch wave whenever gridDim.x < N)
@@ -1570,6 +1578,9 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   }
   const int region = blockIdx.y, nregions = gridDim.y;
   const int lane = tid & 63, wave = tid >> 6;
+  // (BOX: the prologue and the convert pass -- the phases that wait for memory and issue the stores -- outrank the co-resident
+  // workgroup's scan / walk, see the forward: 1152 crops @128 x 128 43.3 -> 42.5 us, 9216 crops 302 -> 293, @256 x 256 160.1 -> 159.5)
+  if (BOX) __builtin_amdgcn_s_setprio(1);
 #ifdef EXP_MSE_STAGGER   // (timing experiment: the second workgroup of every CU starts EXP_MSE_STAGGER x 3.4 us late)
   {
     const unsigned wg = blockIdx.x + blockIdx.y * gridDim.x;
@@ -1672,6 +1683,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   }
   SHR_TL(2, 1);   // this wave's work in front of the first barrier is done
   __syncthreads();
+  if (BOX) __builtin_amdgcn_s_setprio(0);
   SHR_TL(2, 2);   // past the first barrier
   if (!(wave_s == 0 || bg_wave)) sph = s_sph[lane];
   float4 sph_next = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1734,6 +1746,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
     // z-buffer, the walk has nothing to visit: the two barriers around the convert pass order nothing)
     const bool untouched = ua >= ub && tile_lo >= tile_hi;
     if (!untouched) __syncthreads();
+    if (BOX) __builtin_amdgcn_s_setprio(1);
     SHR_TL(2, 4);   // past the second barrier: the convert pass starts
 
     // ---- convert: error, its square, gradient image in place ---------------------------------
@@ -1793,6 +1806,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
     sse += tpre[0].x + tpre[1].y + tpre[2].z + tpre[3].w;
 #endif
     SHR_TL(2, 5);   // this wave's convert units are done
+    if (BOX) __builtin_amdgcn_s_setprio(0);
     if (!untouched) __syncthreads();
     SHR_TL(2, 6);   // past the third barrier: the walk starts
 

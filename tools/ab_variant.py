@@ -10,16 +10,18 @@ EXP = os.path.join(ROOT, "tools", "libspherehand_exp.so")
 
 
 def build(flags, name=""):
+    """(SRC=data_to_model in the environment: the variant flags go to that translation unit instead of sphere_raster)"""
     global EXP
     if name:
         EXP = os.path.join(ROOT, "tools", "libspherehand_exp_%s.so" % name)
     from spherehand_amd import build as b
     b.build()
-    obj = "/tmp/sphere_raster_exp%s.o" % name
+    unit = os.environ.get("SRC", "sphere_raster")
+    obj = "/tmp/%s_exp%s.o" % (unit, name)
     subprocess.check_call([b.HIPCC] + [f for f in b.FLAGS if f != "-shared"] + flags +
                           ["-c", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(b.PKG, "csrc"), "-o", obj,
-                           os.path.join(b.PKG, "csrc", "sphere_raster.hip")])
-    objs = [o for o in glob.glob(os.path.join(b.OBJ_DIR, "*.o")) if not o.endswith("sphere_raster.o")]
+                           os.path.join(b.PKG, "csrc", unit + ".hip")])
+    objs = [o for o in glob.glob(os.path.join(b.OBJ_DIR, "*.o")) if not o.endswith(unit + ".o")]
     subprocess.check_call([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", EXP, obj] + objs)
     print(EXP, flags)
 

@@ -5,7 +5,7 @@ ramp (first wave's entry of the last workgroup to start) / prologue (to the firs
 / drain -- against the HIP-event duration of the same launches and the launch floor.
 
     python tools/headline_timeline.py build     (anywhere: cross-compiles tools/libspherehand_tl.so)
-    python tools/headline_timeline.py           (on the GPU box: writes gpurun_out/r05_headline_timeline.json)"""
+    python tools/headline_timeline.py           (on the GPU box: writes gpurun_out/r06_headline_timeline.json)"""
 import ctypes
 import glob
 import json
@@ -121,7 +121,7 @@ def main():
             },
         }
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r05_headline_timeline.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r06_headline_timeline.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 

@@ -55,5 +55,5 @@ out = {"kernel_us (HIP events, instrumented build)": round(t_us, 1), "shader_clo
        "per_wave_us_scan_done": [round(med(rel[:, :, w, 3]) / ghz / 1e3, 2) for w in range(16)],
        "per_wave_us_convert_done": [round(med(rel[:, :, w, 5]) / ghz / 1e3, 2) for w in range(16)],
        "per_wave_us_walk_done": [round(med(rel[:, :, w, 7]) / ghz / 1e3, 2) for w in range(16)]}
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r05_mse_timeline.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r06_mse_timeline.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
