@@ -1,14 +1,15 @@
 """The counter-based random numbers of the synthetic branch, restated in numpy.
 
-HandSynthesizer's one-graph path (util_modules.HandSynthesizer, three launches: shr_synth_pose_fwd,
+HandSynthesizer's kernel path (util_modules.HandSynthesizer: ONE launch, shr_hand_synth_fwd, or three: shr_synth_pose_fwd,
 shr_mesh_render_post_fwd, shr_heatmap_render_fwd) draws RandScale's factors, the focal jitter and DepthNoise's per-pixel
 shifts and depth noise INSIDE its kernels.  No generator state is carried from draw to draw: a draw is a hash of what it
 is for (csrc/common.h rng_hash / rng_key / noise_shift / noise_normal), so the numbers do not depend on the launch
 geometry and this module reproduces them on the host -- which is how tests/test_synth_gpu.py checks the noised images
 value by value, and how a user regenerates the draws of a call from (seed, call counter).
 
-    seed, counter    HandSynthesizer.rng_state (int64 [2] on the device): seed = torch.initial_seed() when the state was
-                     (re)seeded, counter = calls since then; the render launch advances it
+    seed, counter    HandSynthesizer.rng_state (int64 [4] on the device: seed, call counter, the launch's ticket, unused):
+                     seed = torch.initial_seed() when the state was (re)seeded, counter = calls since then; the render
+                     launch's LAST workgroup advances it
     key(b, k)        rng_key(seed, counter, sample b, word k): k = 0..2 RandScale, 3 focal jitter, 4 / 5 the sample's
                      pixel-noise keys
     uniform          top 24 bits / 2^24 (torch.rand's float32 construction)
