@@ -953,7 +953,7 @@ def main():
                             "avg_us": {"fwd": rp["launched_from_c"]["fwd"], "bwd": rp["launched_from_c"]["bwd"]},
                             "source": rp["launched_from_c"]["source"],
                             "is": "same algorithmic bytes / AverageNs of the committed rocprofv3 --kernel-trace --stats "
-                                  "run of the C-loop launches (tools/collect_profiles_r04.sh); a different process "
+                                  "run of the C-loop launches (tools/collect_profiles_r06.sh); a different process "
                                   "than this line's live HIP-event means"}
         out = {
             "metric": "depth crops/s (raster fwd+bwd, 128x128, batch 256)",
