@@ -94,7 +94,10 @@ constexpr int kOffItems = 1024;
 constexpr int kOffEnds = 2048;
 constexpr int kOffFlags = 2304;
 constexpr int kOffNext = 2304 + 64;       // [64] float4: the NEXT crop's records (persistent workgroups)
-constexpr int kHdrBytes = kOffNext + 1024;
+#ifndef SHR_HDR_PAD
+#define SHR_HDR_PAD 0
+#endif
+constexpr int kHdrBytes = kOffNext + 1024 + SHR_HDR_PAD;   // (SHR_HDR_PAD: experiment -- where the z-buffers start relative to the LDS banks)
 constexpr int kMaxFastWidth = 8192;  // 16-bit fields of the work items
 
 __device__ __forceinline__ uint32_t depth_key(float d) {
@@ -1631,8 +1634,14 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   // conversion instead of costing the convert pass one HBM round trip per unit.
   constexpr int kTgtAhead = 4;   // a 128x128 crop / a 64-row region of a 256-wide one: 64 units, four per wave
   float4 tpre[kTgtAhead];
+#ifdef EXP_MSE_LATE_TARGET    // (experiment: requested past the first barrier, under the scan, instead of at the kernel's entry)
+#elif !defined(EXP_MSE_SKIP_TARGET)   // (timing experiment: the observed image is never read)
 #pragma unroll
   for (int k = 0; k < kTgtAhead; k++) tpre[k] = tgt4[min(((wave_s + (k << 4)) << 6) + lane, nchunk - 1)];
+#else
+#pragma unroll
+  for (int k = 0; k < kTgtAhead; k++) tpre[k] = make_float4((float)lane, 1.f, 2.f, (float)k);
+#endif
   int ua = 0, ub = nunits;
   if (bg_wave) {   // rows no sphere touches: depth = background, stored while wave 0 builds the list
     int cv0, cv1, cu0 = 0, cu1 = W - 1;
@@ -1684,6 +1693,10 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   SHR_TL(2, 1);   // this wave's work in front of the first barrier is done
   __syncthreads();
   if (BOX) __builtin_amdgcn_s_setprio(0);
+#ifdef EXP_MSE_LATE_TARGET
+#pragma unroll
+  for (int k = 0; k < kTgtAhead; k++) tpre[k] = tgt4[min(((wave_s + (k << 4)) << 6) + lane, nchunk - 1)];
+#endif
   SHR_TL(2, 2);   // past the first barrier
   if (!(wave_s == 0 || bg_wave)) sph = s_sph[lane];
   float4 sph_next = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1913,8 +1926,12 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   // ---- reductions: waves in order --------------------------------------------------------------
   sse = wave_sum_lane63(sse);
   SHR_TL(2, 7);   // this wave's walk (and tile code) is done
-  __syncthreads();
-  float *s_wsum = reinterpret_cast<float *>(s_items);   // the work list is done with
+  // the waves' partial sums: in the next crop's record slots where no next crop exists (not PERSIST: the box variant) -- a place
+  // of their own, so ONE barrier closes the walk and publishes them; over the work list otherwise, behind a barrier of its own
+  // (round 6: -0.3 to -1.2 % on the fused kernel; the header keeps its size, so no z-buffer moves -- SHR_HDR_PAD 16 .. 192
+  // measured on the way: where the z-buffers start relative to the LDS banks changes nothing, +-0.3 %)
+  float *s_wsum = PERSIST ? reinterpret_cast<float *>(s_items) : reinterpret_cast<float *>(s_next);
+  if (PERSIST) __syncthreads();
   if (lane == 63) s_wsum[wave] = sse;
   __syncthreads();
   const size_t slot = (size_t)(slot_by_crop ? c : n) * nregions + region;
