@@ -1606,6 +1606,10 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   const bool has_next = PERSIST && n + crop_step < N;
   // crop_index (shr_sphere_raster_mse_indexed): workgroup n renders crop c = crop_index[n] of the batch -- its records,
   // its observed image, its slot of the depth output -- and reports into slot n of the partial results
+#if defined(EXP_MSE_EMPTY) && EXP_MSE_EMPTY == 3   // (timing experiment: the launch alone -- every workgroup returns at once)
+  if (tid == 0 && n == 0x7fffffff) sse_out[0] = 0.f;
+  return;
+#endif
   const int c = crop_index ? crop_index[n] : n;
   float4 sph = make_float4(0.f, 0.f, 0.f, 0.f);
   if (valid && (wave_s == 0 || bg_wave))   // the others: wave 0's LDS copy, later
@@ -1656,7 +1660,16 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
       if (BOX) {   // everything the other waves derive from the box (see the forward)
         cu0 &= ~3;
         const int bw = cu1 >= cu0 ? ((cu1 | 3) - cu0 + 1) : 4;
-        const int pitch = box_pitch(bw);
+        int pitch = box_pitch(bw);
+        // A box whose rows do not all fit at that pitch would leave its last rows to the tile code -- at 256 x 256 nearly
+        // every hand region: 64 rows x 136 cells against 8 504 in half of a CU's LDS, i.e. EIGHT rows of tile code per
+        // region, 14-17 us of the kernel's 160 (round 6, EXP_MSE_SKIP_TILE).  A tighter row pitch (even: 16-byte cell pairs;
+        // never a multiple of 32 cells) that holds the whole box is taken instead: the padding only spreads a chunk's rows
+        // over the banks, no lane writes there, and the waves wait for LDS 1-2 % of their cycles.
+        if ((cv1 - cv0 + 1) * pitch > zcells) {
+          for (int pad = kRowPad - 2; pad >= 2; pad -= 2)
+            if (((bw + pad) & 31) != 0 && (cv1 - cv0 + 1) * (bw + pad) <= zcells) { pitch = bw + pad; break; }
+        }
         const int split = (cv0 + zcells / pitch) & ~(kTileH - 1);        // rows [cv0, split) fit the z-buffer
         const bool over = split <= cv1;
         s_flag[4] = cv0; s_flag[5] = over ? split : cv1 + 1; s_flag[6] = cu0; s_flag[7] = bw;
@@ -1698,6 +1711,10 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   for (int k = 0; k < kTgtAhead; k++) tpre[k] = tgt4[min(((wave_s + (k << 4)) << 6) + lane, nchunk - 1)];
 #endif
   SHR_TL(2, 2);   // past the first barrier
+#if defined(EXP_MSE_EMPTY) && EXP_MSE_EMPTY == 1   // (timing experiment: the prologue alone -- every workgroup returns past the first barrier)
+  if (tid == 0) sse_out[(size_t)n * nregions + region] = tpre[0].x + tpre[1].y + tpre[2].z + tpre[3].w + (float)s_flag[1];
+  return;
+#endif
   if (!(wave_s == 0 || bg_wave)) sph = s_sph[lane];
   float4 sph_next = make_float4(0.f, 0.f, 0.f, 0.f);
   if (pf_wave && has_next && valid)
@@ -1857,7 +1874,11 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
     (void)cell_max; (void)a0; (void)a1; (void)a2; (void)a3;
 #endif
   }
+#ifdef EXP_MSE_SKIP_TILE   // (timing experiment: the rows a box has beyond its z-buffer are dropped instead of going through the tile code)
+  if (false) {
+#else
   if (tile_lo < tile_hi) {
+#endif
     // ---- general path (or the rows beyond the z-buffer): 32x8 tiles, owners and gradient in registers ---
     // (rows_per_region is a multiple of the tile height whenever there are several regions)
     const int tiles_x = (W + kTileW - 1) / kTileW;
@@ -1909,15 +1930,10 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
           sw += mine ? pw[k] : 0.f;
         }
         if (__ballot(any) == 0) continue;
-        sx = wave_sum_lane63(sx);
-        sy = wave_sum_lane63(sy);
-        sz = wave_sum_lane63(sz);
-        sw = wave_sum_lane63(sw);
-        if (lane == 63) {
-          float4 a = acc[j];
-          a.x += sx; a.y += sy; a.z += sz; a.w += sw;
-          acc[j] = a;
-        }
+        // (one transposed four-component wave sum -- 15 instructions against 24 for four separate ones: round 6, the rows a
+        // wide box leaves to this code are 4-5 % of config 5's box rows and cost four times a z-buffer row)
+        const float t4 = wave_sum4_transposed(sx, sy, sz, sw, lane);
+        if (lane >= 60) reinterpret_cast<float *>(acc + j)[lane & 3] += t4;
       }
     }
   }
