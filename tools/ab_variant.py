@@ -52,6 +52,18 @@ def main():
         for n in [int(v) for v in os.environ.get("NS", "256,1152,9216").split(",")]:
             with torch.no_grad():
                 sph = hbr.spheres(fk(sample_poses(n, seed=7).to(dev))).contiguous()
+            obs = index = None
+            if os.environ.get("C5"):    # config 5's own projections (WIDE boxes) and observed images (three crops share one): n = 9 B
+                from spherehand_amd.datasets import SyntheticMultiviewDataset
+                from spherehand_amd.multiview_utility import MutualProjectionLoss
+                ds = SyntheticMultiviewDataset(mesh, n // 9, S, seed=0, device=dev)
+                crit = MutualProjectionLoss(S, mesh).to(dev)
+                with torch.no_grad():
+                    _, pts = crit.mutual_projection(ds.cam.to(dev), ds.inv_cam.to(dev), ds.joints.to(dev) + torch.randn(ds.joints.shape, device=dev))
+                rad = crit.data_to_model_criterion.radiuses.view(-1)
+                sph = torch.cat([pts.squeeze(-1).reshape(n, J, 3), rad.view(1, J, 1).expand(n, J, 1)], -1).contiguous()
+                obs = ds.dms.to(dev).view(n // 3, S, S).contiguous()
+                index = crit._indices(n // 9, 3, dev)[0]
             depth = torch.empty(n, S, S, device=dev); owner = torch.empty(n, S, S, device=dev, dtype=torch.uint8)
             grad = torch.randn(n, S, S, device=dev); gs = torch.empty(n, J, 4, device=dev)
             p = [t.data_ptr() for t in (sph, depth, owner, grad, gs)]
@@ -72,9 +84,10 @@ def main():
                     if name == "product": ref = {"d": key[0], "g": key[1]}
                     if os.environ.get("MSE"):   # the fused render-and-compare kernel on the same crops (target: the depth map + noise)
                         R = l.shr_sphere_raster_mse_regions(S, S)
-                        tgt = (ref.get("d", depth) + 3.0 * torch.randn_like(depth)).contiguous()
+                        tgt = obs if obs is not None else (ref.get("d", depth) + 3.0 * torch.randn_like(depth)).contiguous()
                         sse = torch.empty(n * R, device=dev); gsp = torch.empty(n * R * J * 4, device=dev)
-                        m = lambda s: l.shr_sphere_raster_mse(p[0], n, J, S, S, tgt.data_ptr(), None, None if os.environ.get("NODEPTH") else p[1], sse.data_ptr(), gsp.data_ptr(), s)
+                        m = lambda s: l.shr_sphere_raster_mse(p[0], n, J, S, S, tgt.data_ptr(), None if index is None else index.data_ptr(),
+                                                              None if os.environ.get("NODEPTH") else p[1], sse.data_ptr(), gsp.data_ptr(), s)
                         assert m(stream.cuda_stream) == 0
                         print("n %5d %-10s render-and-compare %7.2f us" % (n, name, bench.mean_launch_us(m, stream, reps, 3, 3, warm_ms=30.0)), flush=True)
                     print("n %5d %-10s fwd+owner %7.2f  bwd %7.2f  fwd depth-only %7.2f us%s" % (n, name, tf, tb, t0, same), flush=True)

@@ -5,6 +5,9 @@
 #   noSCAN / noCONVERT / noWALK / noCW / noSCW   a phase compiled out (EXP_MSE_SKIP_*)
 #   junk4 / junk8 / junk16                       that many independent VALU instructions more per chunk pair of the scan
 #   stag2 / stag5                                the second workgroup of every CU starts 2 / 5 x 3.4 us late
+#   notile                                       the rows a wide box leaves to the tile code are dropped
+#   noSCWT / noSCWTt / empty1T / empty3          the skeleton without the observed-image loads / and without the tile code / only the
+#                                                prologue up to the first barrier / only the launch
 # Build here (no GPU needed):   bash tools/exp_mse_phases.sh build
 # Run on the GPU box:           bash tools/exp_mse_phases.sh        -> gpurun_out/r06_mse_phases.txt
 set -u
@@ -16,14 +19,20 @@ if [ "${1:-}" = "build" ]; then
   python tools/ab_variant.py build:noSCW -DEXP_MSE_SKIP_SCAN -DEXP_MSE_SKIP_CONVERT -DEXP_MSE_SKIP_WALK | tail -1
   for v in 4 8 16; do python tools/ab_variant.py build:junk$v -DEXP_MSE_SCAN_JUNK=$v | tail -1; done
   for v in 2 5; do python tools/ab_variant.py build:stag$v -DEXP_MSE_STAGGER=$v | tail -1; done
+  python tools/ab_variant.py build:notile -DEXP_MSE_SKIP_TILE | tail -1
+  python tools/ab_variant.py build:noSCWT -DEXP_MSE_SKIP_SCAN -DEXP_MSE_SKIP_CONVERT -DEXP_MSE_SKIP_WALK -DEXP_MSE_SKIP_TARGET | tail -1
+  python tools/ab_variant.py build:noSCWTt -DEXP_MSE_SKIP_SCAN -DEXP_MSE_SKIP_CONVERT -DEXP_MSE_SKIP_WALK -DEXP_MSE_SKIP_TARGET -DEXP_MSE_SKIP_TILE | tail -1
+  python tools/ab_variant.py build:empty1T -DEXP_MSE_EMPTY=1 -DEXP_MSE_SKIP_TARGET | tail -1
+  python tools/ab_variant.py build:empty3 -DEXP_MSE_EMPTY=3 | tail -1
   exit 0
 fi
 mkdir -p gpurun_out
 {
+  echo "# (config 5's own projections and observed images: C5=1 -- wide boxes; centred hands read ~8 us less)"
   echo "# fused render-and-compare, 1152 crops @256x256, us per launch (mean of 3 rounds x 3 batches of 40 launches), tools/exp_mse_phases.sh"
   for nd in 0 1; do
     if [ $nd = 1 ]; then export NODEPTH=1; echo "## without the depth output (return_projections = False)"; else unset NODEPTH; echo "## with the depth output"; fi
-    S=256 NS=1152 MSE=1 python tools/ab_variant.py 2>&1 | grep render | awk '{a[$3]+=$5; c[$3]++} END {for (k in a) printf "%-10s %.1f\n", k, a[k]/c[k]}' | sort
+    C5=1 S=256 NS=1152 MSE=1 python tools/ab_variant.py 2>&1 | grep render | awk '{a[$3]+=$5; c[$3]++} END {for (k in a) printf "%-10s %.1f\n", k, a[k]/c[k]}' | sort
   done
 } > gpurun_out/r06_mse_phases.txt
 cat gpurun_out/r06_mse_phases.txt
