@@ -181,6 +181,7 @@ class Engine:
         self.hand_synthesizer = None
         if opts.synthesize and dev.type == 'cuda':
             self.hand_synthesizer = HandSynthesizer(c.mesh, S, c.heatmap_size, c.uv_hm_scale, c.depth_scale).to(dev)
+            self.hand_synthesizer.seed_offset = self.env.rank      # ranks seeded alike (identical initial weights) still draw their own noise
         # network/engine.py:71-73: the frozen palm re-predictor the Eval metric goes through
         # (loaded on the first evaluation step: a training-only run needs neither the module nor its weight file)
         self._pose_denoiser = pose_denoiser.to(dev).eval() if pose_denoiser is not None else None

@@ -236,8 +236,8 @@ class HandSynthesizer(nn.Module):
     (ops.synth_pose), skinning + camera + triangle raster + clamp + resize + `* depth_scale` + DepthNoise
     (ops.mesh_render_post: the noise runs in the rasterizer's epilogue), key-point skinning + heat-map camera + paint
     (ops.heatmap_render).  The random numbers come from a counter-based generator inside the kernels (synth_rng.py
-    restates it): `rng_state` = (seed, call counter) lives on the device, seed = torch.initial_seed() at the first
-    call -- and again whenever torch.manual_seed() has CHANGED it since; reseed() restarts the stream by hand.  Parity with
+    restates it): `rng_state` = (seed, call counter, ticket) lives on the device, seed = torch.initial_seed() + seed_offset at
+    the first call -- and again whenever torch.manual_seed() has CHANGED it since; reseed() restarts the stream by hand.  Parity with
     the reference's torch.rand / randn draws is in distribution; with the same draws (`last_draws`) and the noise off
     the outputs equal the module-by-module chain bit for bit.  fused = False: that chain -- RandScale's three CPU
     draws, torch.rand for the focal jitter, DepthRender, DepthNoise on one torch.randn, Hand3DHeatmapRender."""
@@ -257,13 +257,17 @@ class HandSynthesizer(nn.Module):
         self.fused = True
         self.one_launch = True       # the whole forward as ONE kernel where its sizes allow (ops.hand_synth)
         self.rng_state = None        # int64 [4] on the device: (seed, call counter, the launch's ticket, unused)
+        self.seed_offset = 0         # added to torch.initial_seed(): Engine sets the rank, so that ranks seeded alike draw differently
         self._rng_seed = None
         self.last_draws = None       # [6,B] of the last fused call: s_x, s_y, s_z, focal jitter, the two noise keys (bits)
         self._kp_bone_i32 = None
 
+    def _default_seed(self):
+        return torch.initial_seed() + int(self.seed_offset)
+
     def reseed(self, seed=None, device=None):
-        """Restart the kernels' random stream: seed (default torch.initial_seed()), call counter 0."""
-        seed = torch.initial_seed() if seed is None else int(seed)
+        """Restart the kernels' random stream: seed (default torch.initial_seed() + seed_offset), call counter 0."""
+        seed = self._default_seed() if seed is None else int(seed)
         self._rng_seed = seed
         s64 = seed & (2 ** 64 - 1)
         dev = device if device is not None else (self.rng_state.device if self.rng_state is not None else None)
@@ -273,7 +277,7 @@ class HandSynthesizer(nn.Module):
         self.rng_state = torch.tensor([s64 - 2 ** 64 if s64 >= 2 ** 63 else s64, 0, 0, 0], dtype=torch.int64, device=dev)
 
     def _state(self, dev):
-        if self.rng_state is None or self.rng_state.device != dev or self._rng_seed != torch.initial_seed():
+        if self.rng_state is None or self.rng_state.device != dev or self._rng_seed != self._default_seed():
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("HandSynthesizer: call the module (or reseed(device=...)) once before capturing it: "
                                    "seeding the generator state is a host-to-device copy")

@@ -52,6 +52,10 @@ def test_draws_equal_the_numpy_restatement_and_the_counter_advances(one_launch):
     assert _state(syn) == (7, 2)
     syn.reseed()
     assert _state(syn) == (7, 0)
+    # seed_offset (Engine: the rank): ranks under one torch seed draw different streams
+    syn.seed_offset = 3
+    syn(pose)
+    assert _state(syn) == (10, 1)
 
 
 @pytest.mark.parametrize("one_launch", [True, False])
