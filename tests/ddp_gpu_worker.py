@@ -36,6 +36,7 @@ class ShardedSynth:
         from spherehand_amd.joint_angle import sample_poses
         poses = sample_poses(GLOBAL_SYNT, seed=21).cuda()
         torch.manual_seed(99)
+        synth.seed_offset = 0          # (Engine gives every rank its own noise stream: here every rank renders the SAME global batch)
         out = synth(poses)
         n = GLOBAL_SYNT // world
         self.out = tuple(o[rank * n:(rank + 1) * n].contiguous() for o in out)
