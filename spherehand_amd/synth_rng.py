@@ -76,7 +76,7 @@ def shift_thresholds(sigma_xy=0.5):
 def noise_field(keys, H, W, sigma_xy=0.5):
     """Per-pixel draws of one call: (dx [B,H,W] int, dy [B,H,W] int, n [B,H,W] float64 standard normal) from the
     samples' keys [2, B] (csrc/common.h noise_shift / noise_normal; the kernels evaluate the normal with the hardware's
-    log2 / sqrt / cos: the noised depth agrees to 3e-7, a pixel in millions -- u1 within 2^-16 of 1 -- to 4e-6)."""
+    log2 / sqrt / cos: the noised depth agrees to 3e-7, a pixel in millions -- u1 within 2^-16 of 1 -- to 1e-5)."""
     keys = np.asarray(keys, np.uint32)
     B = keys.shape[1]
     p = np.arange(H * W, dtype=np.uint64)[None, :]

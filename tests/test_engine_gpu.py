@@ -158,7 +158,7 @@ def test_hand_synthesizer_values_against_the_oracle_chain(S, fused):
         sy = torch.clamp((rn[1] * 0.5 + 0.5).long() + v, 0, S - 1)
         g = torch.gather(depth.reshape(B, S * S), 1, (sy * S + sx).reshape(B, S * S)).view(B, S, S)
         expect = torch.where(g < 1.0, g + rn[2] * 0.05, g)
-    assert (out - expect).abs().max().item() <= (5e-6 if fused else 1e-6)      # (fused: hardware log2 near 1, tests/test_synth_gpu.py)
+    assert (out - expect).abs().max().item() <= (2e-5 if fused else 1e-6)      # (fused: hardware log2 near 1, tests/test_synth_gpu.py)
     assert (out != depth).float().mean().item() > 0.02     # (the noise did something)
 
 

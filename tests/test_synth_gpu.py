@@ -103,9 +103,10 @@ def test_one_launch_equals_three_launches():
 def test_noised_images_equal_depth_noise_on_the_restated_draws(S):
     """Noise on: every pixel = DepthNoise's formula (network/util_modules.py:60-84) applied to the clean image with the
     shifts and normals synth_rng derives from the sample's keys -- shifts exactly (background and >= 1.0 pixels must be
-    bit-equal), the depth noise to 5e-6: the kernels evaluate Box-Muller with the hardware's log2 / sqrt / cos, and v_log_f32's
-    ~1e-7 ABSOLUTE error is a percent of log2(u1) when u1 is within 2^-16 of 1 -- a normal of ~0.004 sigma_z that is then off
-    by up to 4e-5 sigma_z (one pixel in ~5 million reaches 2-4e-6; tools/fuzz.py found it); everything else agrees to 3e-7."""
+    bit-equal), the depth noise to 2e-5: the kernels evaluate Box-Muller with the hardware's log2 / sqrt / cos, and v_log_f32
+    loses its relative accuracy where log2(u1) -> 0: for u1 within 2^-16 of 1 (one draw in 65 536) the normal -- ~0.004, a
+    negligible sample -- comes out up to 1.5e-4 off (tools/fuzz.py: one pixel in ~5 million at 2-8e-6 of scaled depth);
+    everything else agrees to 3e-7."""
     from spherehand_amd import synth_rng
     B = 5
     clean, noisy = _syn(S, add_noise=False, out_heatmap=False), _syn(S, add_noise=True, out_heatmap=False)
@@ -118,7 +119,7 @@ def test_noised_images_equal_depth_noise_on_the_restated_draws(S):
     keys = noisy.last_draws[4:6].cpu().numpy().view(np.uint32)
     expect = synth_rng.depth_noise(c.cpu().numpy(), keys, 0.5, 0.05)
     got = n.cpu().numpy()
-    assert np.abs(got - expect).max() <= 5e-6 and (np.abs(got - expect) > 5e-7).mean() < 1e-5
+    assert np.abs(got - expect).max() <= 2e-5 and (np.abs(got - expect) > 5e-7).mean() < 1e-5
     dx, dy, _ = synth_rng.noise_field(keys, S, S, 0.5)
     v = np.clip(np.arange(S)[None, :, None] + dy, 0, S - 1); u = np.clip(np.arange(S)[None, None, :] + dx, 0, S - 1)
     z = c.cpu().numpy()[np.arange(B)[:, None, None], v, u]

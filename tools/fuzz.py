@@ -205,7 +205,7 @@ def band_case():
 _syn = {}
 def synth_case():
     """HandSynthesizer: ONE launch == three launches bit for bit (draws included); noise off == the module chain on the same
-    draws; noise on == DepthNoise on the numpy restatement of the kernels' generator (5e-6)"""
+    draws; noise on == DepthNoise on the numpy restatement of the kernels' generator (2e-5)"""
     global fails
     from spherehand_amd import hand_model, synth_rng
     from spherehand_amd.util_modules import HandSynthesizer
@@ -241,8 +241,8 @@ def synth_case():
     if noise:
         expect = synth_rng.depth_noise(clean.cpu().numpy(), keys, 0.5, 0.05)
         err = np.abs(oa[0].cpu().numpy() - expect)
-        if not err.max() <= 5e-6:      # (v_log_f32 near 1: see tests/test_synth_gpu.py)
-            why.append("noise: max err %.3g at %s (%d px above 5e-6)" % (err.max(), np.unravel_index(err.argmax(), err.shape), int((err > 5e-6).sum())))
+        if not err.max() <= 2e-5:      # (v_log_f32 near 1: see tests/test_synth_gpu.py)
+            why.append("noise: max err %.3g at %s (%d px above 2e-5)" % (err.max(), np.unravel_index(err.argmax(), err.shape), int((err > 2e-5).sum())))
     elif not torch.equal(oa[0], clean):
         why.append("clean depth != module chain")
     if heat:
