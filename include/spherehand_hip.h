@@ -304,7 +304,9 @@ int shr_depth_noise(const float *depth, const float *normal3, int B, int H, int 
  * Random numbers: rng_state[3] = (seed, call counter, ticket) in device memory; a draw is a hash of (seed, counter, sample,
  * word) and, per pixel, of (sample key, pixel index) -- csrc/common.h rng_*, restated in numpy by
  * spherehand_amd/synth_rng.py.  Parity with the reference's torch generator is in distribution (as for any RNG-
- * dependent step); with the noise off and the same draws the images are the reference chain's bit for bit. */
+ * dependent step); with the noise off and the same draws the images are the reference chain's bit for bit.
+ * One launch at a time per rng_state: launches that share a state must be ordered (one stream, or events) -- the
+ * counter is read by every workgroup and advanced by the last one to finish. */
 int shr_synth_pose_fwd(const float *params, int B, const float *offset, const float *offset_inv,
                        const unsigned long long *rng_state, float rand_scale, float *T, float *draws, void *stream);
 int shr_mesh_render_post_fwd(const float *T, int B, int NB, int NV, const int32_t *skin_vertex_start,

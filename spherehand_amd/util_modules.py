@@ -259,29 +259,38 @@ class HandSynthesizer(nn.Module):
         self.rng_state = None        # int64 [4] on the device: (seed, call counter, the launch's ticket, unused)
         self.seed_offset = 0         # added to torch.initial_seed(): Engine sets the rank, so that ranks seeded alike draw differently
         self._rng_seed = None
+        self._seed_explicit = None   # set by reseed(seed): that seed instead of torch's
+        self._rng_counter = 0        # the call counter the next (re)seeding starts from
         self.last_draws = None       # [6,B] of the last fused call: s_x, s_y, s_z, focal jitter, the two noise keys (bits)
         self._kp_bone_i32 = None
 
     def _default_seed(self):
         return torch.initial_seed() + int(self.seed_offset)
 
-    def reseed(self, seed=None, device=None):
-        """Restart the kernels' random stream: seed (default torch.initial_seed() + seed_offset), call counter 0."""
-        seed = self._default_seed() if seed is None else int(seed)
+    def reseed(self, seed=None, device=None, counter=0):
+        """Restart the kernels' random stream at call `counter`.  seed = None: follow torch -- torch.initial_seed() +
+        seed_offset, re-read whenever torch.manual_seed() changes it; an explicit seed stays until the next reseed()."""
+        self._seed_explicit = None if seed is None else int(seed)
+        self._rng_counter = int(counter)
+        dev = device if device is not None else (self.rng_state.device if self.rng_state is not None else None)
+        self.rng_state = None
+        if dev is not None:
+            self._materialise(dev)
+
+    def _materialise(self, dev):
+        seed = self._default_seed() if self._seed_explicit is None else self._seed_explicit
         self._rng_seed = seed
         s64 = seed & (2 ** 64 - 1)
-        dev = device if device is not None else (self.rng_state.device if self.rng_state is not None else None)
-        if dev is None:
-            self.rng_state = None
-            return
-        self.rng_state = torch.tensor([s64 - 2 ** 64 if s64 >= 2 ** 63 else s64, 0, 0, 0], dtype=torch.int64, device=dev)
+        self.rng_state = torch.tensor([s64 - 2 ** 64 if s64 >= 2 ** 63 else s64, self._rng_counter, 0, 0], dtype=torch.int64, device=dev)
+        self._rng_counter = 0
 
     def _state(self, dev):
-        if self.rng_state is None or self.rng_state.device != dev or self._rng_seed != self._default_seed():
+        stale = self._seed_explicit is None and self._rng_seed != self._default_seed()      # torch was re-seeded
+        if self.rng_state is None or self.rng_state.device != dev or stale:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("HandSynthesizer: call the module (or reseed(device=...)) once before capturing it: "
                                    "seeding the generator state is a host-to-device copy")
-            self.reseed(device=dev)
+            self._materialise(dev)
         return self.rng_state
 
     def _fused_ok(self, parameters):

@@ -52,6 +52,16 @@ def test_draws_equal_the_numpy_restatement_and_the_counter_advances(one_launch):
     assert _state(syn) == (7, 2)
     syn.reseed()
     assert _state(syn) == (7, 0)
+    # an explicit seed (and call counter) stays whatever torch is seeded with, also when set before the first call
+    fresh = _syn(64, one_launch=one_launch)
+    fresh.reseed(4242, counter=5)
+    torch.manual_seed(1)
+    fresh(pose)
+    assert _state(fresh) == (4242, 6)
+    torch.manual_seed(2)
+    fresh(pose)
+    assert _state(fresh) == (4242, 7)
+    torch.manual_seed(7)
     # seed_offset (Engine: the rank): ranks under one torch seed draw different streams
     syn.seed_offset = 3
     syn(pose)
@@ -203,9 +213,7 @@ def test_capture_and_replay_in_a_hipgraph():
     for k, (depth, uv, dh, xyz, draws) in enumerate(results):
         f, keys = synth_rng.sample_draws(17, ctr0 + k, B, 0.1)
         assert np.array_equal(draws.cpu().numpy()[0:4].view(np.uint32), f.view(np.uint32))
-        eager.reseed(17, device=pose.device)
-        eager.rng_state[1] = ctr0 + k
-        eager._rng_seed = torch.initial_seed()
+        eager.reseed(17, device=pose.device, counter=ctr0 + k)        # (an explicit seed: torch's later seeds do not touch it)
         e = eager(fresh[k])
         for a, b in zip((depth, uv, dh, xyz), e):
             assert torch.equal(a, b)

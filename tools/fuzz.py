@@ -223,7 +223,7 @@ def synth_case():
     seed, ctr = int(rs.randint(1, 2 ** 31)), int(rs.randint(0, 1000))
     for m, one in ((a, True), (b, False)):
         m.add_noise, m.out_heatmap, m.one_launch = noise, heat, one
-        m.reseed(seed, device=pose.device); m._rng_seed = torch.initial_seed(); m.rng_state[1] = ctr
+        m.reseed(seed, device=pose.device, counter=ctr)
     oa, ob = a(pose), b(pose)
     oa, ob = (oa, ob) if heat else ((oa,), (ob,))
     why = []
