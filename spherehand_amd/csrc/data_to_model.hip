@@ -367,6 +367,14 @@ d2m_compact_kernel(const float *__restrict__ depth, int H, int W, int geom, uint
     const int cnt = (int)fg[0] + (int)fg[1] + (int)fg[2] + (int)fg[3];
     if (cnt) atomicAdd(&s_wcnt[wave * 16 + (x >> cbs)], cnt);
   }
+  // All four pieces are waited for HERE.  A piece past the image's end is never looked at (`in &&` above), so along that path
+  // the compiler kept the loads "in flight" into the second pass and put vmcnt(3) .. vmcnt(0) in front of whatever reads
+  // or reuses their registers there -- between the point stores, which count in the same in-order vmcnt queue: a wave stood
+  // with at most three stores under way (SQ counters, round 5: 59 % of this kernel's wave cycles parked at a wait).
+#ifndef EXP_COMPACT_NO_FENCE
+#pragma unroll
+  for (int k = 0; k < kCompactUnits; k++) asm volatile("" : : "v"(t[k].x), "v"(t[k].y), "v"(t[k].z), "v"(t[k].w));
+#endif
   __syncthreads();
   // tile prefix: lane = position of a tile in the region's boustrophedon order (at most 64 tiles)
   const int nsb = (kCompactWaves + SB - 1) / SB, ntiles = nsb * NC;

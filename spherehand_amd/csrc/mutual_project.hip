@@ -100,26 +100,38 @@ mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ 
     // (is_mv == 2: the same-view pairs only, and sse_part / gsp_part hold just those B*V entries, like the d2m parts)
     const int N = B * V * V, NE = (is_mv == 2 ? B * V : N) * Rm;
     double am = 0.0, ad = 0.0;
-    for (int e0 = threadIdx.x; e0 < NE; e0 += 1024) {
-      float v[4];
+    // (eight loads in flight: two rounds of four, added round by round -- the sums are those of the one-round loop)
+    for (int e0 = threadIdx.x; e0 < NE; e0 += 2048) {
+      float v[2][4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int e = e0 + 256 * u;
-        bool take = e < NE;
-        if (take && is_mv == 0) {
-          const int n = e / Rm, j = n % V, i = (n / V) % V;
-          take = i == j;
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int e = e0 + 1024 * h + 256 * u;
+          bool take = e < NE;
+          if (is_mv == 0) {
+            const int ec = min(e, NE - 1), n = ec / Rm, j = n % V, i = (n / V) % V;
+            take = take && i == j;
+          }
+          const float x = sse_part[min(e, NE - 1)];   // (always requested -- a load behind a branch waits before the next one is issued)
+          v[h][u] = take ? x : 0.f;
         }
-        v[u] = take ? sse_part[e] : 0.f;
-      }
-      am += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+      am += ((double)v[0][0] + (double)v[0][1]) + ((double)v[0][2] + (double)v[0][3]);
+      if (e0 + 1024 < NE) am += ((double)v[1][0] + (double)v[1][1]) + ((double)v[1][2] + (double)v[1][3]);
     }
     const int DE = (is_mv == 1 ? N : B * V) * Rd;     // d2m entries: every pair, or the same-view pairs only
-    for (int e0 = threadIdx.x; e0 < DE; e0 += 1024) {
-      float v[4];
+    for (int e0 = threadIdx.x; e0 < DE; e0 += 2048) {
+      float v[2][4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) v[u] = e0 + 256 * u < DE ? d2m_part[e0 + 256 * u] : 0.f;
-      ad += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int e = e0 + 1024 * h + 256 * u;
+          const float x = d2m_part[min(e, DE - 1)];
+          v[h][u] = e < DE ? x : 0.f;
+        }
+      ad += ((double)v[0][0] + (double)v[0][1]) + ((double)v[0][2] + (double)v[0][3]);
+      if (e0 + 1024 < DE) ad += ((double)v[1][0] + (double)v[1][1]) + ((double)v[1][2] + (double)v[1][3]);
     }
     s_m[threadIdx.x] = am; s_d[threadIdx.x] = ad;
     __syncthreads();
@@ -146,13 +158,31 @@ mv_loss_combine_kernel(const float *__restrict__ cam, const float *__restrict__ 
     const long long n = ((long long)b * V + i) * V + j;
     const long long e = is_mv == 1 ? n : (long long)b * V + i;
     const long long nm = is_mv == 2 ? e : n;
+    // the first four parts of either kind are requested side by side (a loop of unknown length waits for every part
+    // before it asks for the next: with config 5's 4 + 2 parts six chained round trips per lane, most of this kernel's
+    // 5-8 us); added in the same order
+    float4 am[4];
+    float ad[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; r++) am[r] = gsp_part[(nm * Rm + min(r, Rm - 1)) * J + k];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float *a = gd2m_part + ((e * Rd + min(r, Rd - 1)) * J + k) * 3;
+      ad[r][0] = a[0]; ad[r][1] = a[1]; ad[r][2] = a[2];
+    }
     float gx = 0.f, gy = 0.f, gz = 0.f;
-    for (int r = 0; r < Rm; r++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (r < Rm) { gx += am[r].x; gy += am[r].y; gz += am[r].z; }
+    for (int r = 4; r < Rm; r++) {
       const float4 a = gsp_part[(nm * Rm + r) * J + k];
       gx += a.x; gy += a.y; gz += a.z;
     }
     float dx = 0.f, dy = 0.f, dz = 0.f;
-    for (int r = 0; r < Rd; r++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (r < Rd) { dx += ad[r][0]; dy += ad[r][1]; dz += ad[r][2]; }
+    for (int r = 4; r < Rd; r++) {
       const float *a = gd2m_part + ((e * Rd + r) * J + k) * 3;
       dx += a[0]; dy += a[1]; dz += a[2];
     }

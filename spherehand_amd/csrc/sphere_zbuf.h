@@ -942,6 +942,15 @@ sphere_zbuf_fwd_kernel(const float4 *__restrict__ spheres, int N, int J_, int H_
   // a wave issues a wave-wide store every ~55 cycles, so ~6 stores apiece fit in wave 0's
   // shadow.  The other waves learn the touched box after the barrier.
 
+  // The records are waited for HERE by every wave -- the waves that asked for them need them now, the others asked for nothing.
+  // Left to the compiler, the wait sits on each path's first use, and along the paths of the waves that never use the loaded
+  // value it stays "pending": wherever those registers are written later (in the scan, in the stream-out) the compiler puts a
+  // vmcnt(0) -- which at run time waits for the stores issued since: vmcnt counts loads and stores in one in-order queue and
+  // the stream stores are asm statements the compiler does not count.  The storing waves stood at the scan's entry until
+  // their background rows had reached memory.
+#ifndef EXP_NO_RECORD_FENCE
+  asm volatile("" : : "v"(sph.x), "v"(sph.y), "v"(sph.z), "v"(sph.w));
+#endif
   if (list_wave) {
     s_sph[lane] = sph;
     // general path unless every sphere is tame and at least one has z <= 100: a pixel's
@@ -1567,6 +1576,17 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   // wave requests the next crop's records after the first barrier and parks them in LDS (see the forward).
   const int crop_step = gridDim.x;
   for (int n = blockIdx.x, crop_it = 0; PERSIST ? n < N : crop_it == 0; n += crop_step, ++crop_it) {
+  int region = blockIdx.y;
+  const int nregions = gridDim.y;
+  // Launch order of a crop's row regions (the box variant's grid is crops x regions, crops fastest): from the second quarter
+  // on, the first quarter last.  A hand crop's outer regions are mostly rows no sphere touches -- workgroups of ~3 us that
+  // only store background and sum the error, against ~25 us for a region with the hand in it: all of them at the END of the
+  // launch they fill the slots the last round of long workgroups leaves idle (1152 crops @256 x 256: 149.5 -> 147.4 us; the other
+  // rotations 153 / 162 us -- a long workgroup in the tail -- and any order that MIXES short and long ones 162-200 us: the dispatcher
+  // hands workgroups to the CUs in turn, not to the first free one).
+#ifndef EXP_MSE_NO_ROTATE
+  if (BOX && !PERSIST && (nregions & 3) == 0) region = (region + (nregions >> 2)) & (nregions - 1);
+#endif
   // Every crop starts from OPAQUE copies of the launch constants and of the thread index: otherwise the compiler
   // hoists each crop-invariant value out of the crop loop and keeps it in a register (forward: 92 instead of 51
   // VGPRs; the fused kernel spilled).
@@ -1579,7 +1599,6 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
     asm volatile("" : "+s"(J), "+s"(H), "+s"(W), "+s"(rows_per_region), "+s"(w4_shift), "+s"(zcells));
     asm volatile("" : "+v"(tid));
   }
-  const int region = blockIdx.y, nregions = gridDim.y;
   const int lane = tid & 63, wave = tid >> 6;
   // (BOX: the prologue and the convert pass -- the phases that wait for memory and issue the stores -- outrank the co-resident
   // workgroup's scan / walk, see the forward: 1152 crops @128 x 128 43.3 -> 42.5 us, 9216 crops 302 -> 293, @256 x 256 160.1 -> 159.5)
@@ -1647,6 +1666,9 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   for (int k = 0; k < kTgtAhead; k++) tpre[k] = make_float4((float)lane, 1.f, 2.f, (float)k);
 #endif
   int ua = 0, ub = nunits;
+#ifndef EXP_NO_RECORD_FENCE
+  asm volatile("" : : "v"(sph.x), "v"(sph.y), "v"(sph.z), "v"(sph.w));   // (the records: waited for by every wave, see the forward)
+#endif
   if (bg_wave) {   // rows no sphere touches: depth = background, stored while wave 0 builds the list
     int cv0, cv1, cu0 = 0, cu1 = W - 1;
     if (BOX) touched_box(sph, valid, ax, ay, kx, ky, W, r0, r1, lane, cv0, cv1, cu0, cu1);
@@ -1680,6 +1702,11 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
         s_flag[11] = over ? min(r1, (r0 + ((ub << 6) + w4 - 1) / w4 + kTileH - 1) & ~(kTileH - 1)) : r1;
       }
     }
+    // The background rows' depth is NOT stored here, as the forward does it, but by the convert pass below, unit by unit:
+    // this kernel has the observed image's pieces in flight from its entry, and a store issued behind them makes every later
+    // wait for a piece a wait for that store (one in-order vmcnt queue).  Stored here, the untouched rows cost the kernel
+    // 7 us more at 1152 crops @256 x 256 (157.2 -> 150.0), 2.1 of 41.7 at 128 x 128, 18 of 295 at 9216 crops.
+#ifdef EXP_MSE_BG_PROLOGUE
     if (out) {
       const float4 bgd = make_float4(kBackground, kBackground, kBackground, kBackground);
       const int nbg = ua + (nunits - ub);
@@ -1689,6 +1716,7 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
         if (c < nchunk) stream_store(out4 + c, bgd);
       }
     }
+#endif
   }
   if (wave_s == 0) {
     s_sph[lane] = sph;
@@ -1728,7 +1756,12 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   const int p0 = BOX ? rfl(s_flag[4]) : r0, pe = BOX ? rfl(s_flag[5]) : r1;
   const int cu0 = BOX ? rfl(s_flag[6]) : 0, bw = BOX ? rfl(s_flag[7]) : W;
   const int pitch = BOX ? rfl(s_flag[8]) : LW, clip = BOX ? rfl(s_flag[9]) : r1;
-  const int tile_lo = general ? r0 : (BOX ? rfl(s_flag[10]) : r1), tile_hi = general ? r1 : (BOX ? rfl(s_flag[11]) : r1);
+  // (both words read whatever `general` says: as conditional reads they gave the compiler a branch structure with a dead edge
+  // from here to the closing reductions, along which it believed the observed image's pieces still in flight -- and made every
+  // wave wait for its depth stores there)
+  int flag_lo = BOX ? rfl(s_flag[10]) : r1, flag_hi = BOX ? rfl(s_flag[11]) : r1;
+  if (BOX) asm volatile("" : "+s"(flag_lo), "+s"(flag_hi));
+  const int tile_lo = general ? r0 : flag_lo, tile_hi = general ? r1 : flag_hi;
   Key *zb = zbuf - (p0 * pitch + cu0);   // cell of pixel (v, u) = zb[v * pitch + u]
 
   float sse = 0.f;
@@ -1787,9 +1820,12 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
       if (POW2 || w4_shift >= 0) { v = c >> w4_shift; x = (c & (w4 - 1)) << 2; }
       else { v = c / w4; x = (c - v * w4) << 2; }
       if (BOX && v + r0 >= tile_lo && v + r0 < tile_hi) return;   // rows left to the tile code (whole units, background ones among them)
-      if (u < ua || u >= ub) {   // background rows (already stored)
+      if (u < ua || u >= ub) {   // background rows
         const float e0 = kBackground - t.x, e1 = kBackground - t.y, e2 = kBackground - t.z, e3 = kBackground - t.w;
         sse += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+#if !defined(EXP_MSE_BG_PROLOGUE) && !defined(EXP_MSE_NO_BG_STORE)
+        if (out) stream_store(out4 + c, make_float4(kBackground, kBackground, kBackground, kBackground));
+#endif
         return;
       }
       if (BOX) {
@@ -1825,12 +1861,25 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
       cell[1] = k23;
     };
 #ifndef EXP_MSE_SKIP_CONVERT
+    // Every requested piece of the observed image is waited for HERE, before the pass issues its first store.  vmcnt counts
+    // loads and stores in one in-order queue: left alone, the wait in front of piece k covers the stores of units 0 .. k - 1
+    // -- conditional, so the compiler cannot count them -- and becomes vmcnt(0) at the last unit and again at the walk's
+    // entry (the pieces' registers are reused): the depth stores' write latency on every wave's critical path, twice.
+    // The pieces were requested at the kernel's entry; nothing else is in flight but a background wave's early stores.
+#ifndef EXP_MSE_NO_LOAD_FENCE
+#pragma unroll
+    for (int k = 0; k < kTgtAhead; k++) asm volatile("" : : "v"(tpre[k].x), "v"(tpre[k].y), "v"(tpre[k].z), "v"(tpre[k].w));
+#endif
 #pragma unroll
     for (int k = 0; k < kTgtAhead; k++)
       if (wave_s + (k << 4) < nunits) convert_unit(wave_s + (k << 4), tpre[k]);
     for (int u = wave_s + (kTgtAhead << 4); u < nunits; u += kZWaves) {
       const int c = (u << 6) + lane;
-      convert_unit(u, tgt4[min(c, nchunk - 1)]);
+      float4 t = tgt4[min(c, nchunk - 1)];
+#ifndef EXP_MSE_NO_LOAD_FENCE
+      asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));   // (as above: no piece is left pending on the paths that do not use it)
+#endif
+      convert_unit(u, t);
     }
 #else
     sse += tpre[0].x + tpre[1].y + tpre[2].z + tpre[3].w;
@@ -1874,6 +1923,12 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
     (void)cell_max; (void)a0; (void)a1; (void)a2; (void)a3;
 #endif
   }
+#ifndef EXP_MSE_NO_LOAD_FENCE
+  if (general) {   // (the pieces nobody used: see the convert pass -- both ways into the code below are now free of pending loads)
+#pragma unroll
+    for (int k = 0; k < kTgtAhead; k++) asm volatile("" : : "v"(tpre[k].x), "v"(tpre[k].y), "v"(tpre[k].z), "v"(tpre[k].w));
+  }
+#endif
 #ifdef EXP_MSE_SKIP_TILE   // (timing experiment: the rows a box has beyond its z-buffer are dropped instead of going through the tile code)
   if (false) {
 #else

@@ -6,6 +6,9 @@
 #   junk4 / junk8 / junk16                       that many independent VALU instructions more per chunk pair of the scan
 #   stag2 / stag5                                the second workgroup of every CU starts 2 / 5 x 3.4 us late
 #   notile                                       the rows a wide box leaves to the tile code are dropped
+#   oldwaits / bgpro / nolfence / norot / nobgst   round 6's store / wait changes undone (all / background rows stored in the prologue /
+#                                                no wait for the observed image in front of the convert pass / regions in image order);
+#                                                nobgst: the background rows never stored (wrong output: what those stores cost)
 #   noSCWT / noSCWTt / empty1T / empty3          the skeleton without the observed-image loads / and without the tile code / only the
 #                                                prologue up to the first barrier / only the launch
 # Build here (no GPU needed):   bash tools/exp_mse_phases.sh build
@@ -24,6 +27,12 @@ if [ "${1:-}" = "build" ]; then
   python tools/ab_variant.py build:noSCWTt -DEXP_MSE_SKIP_SCAN -DEXP_MSE_SKIP_CONVERT -DEXP_MSE_SKIP_WALK -DEXP_MSE_SKIP_TARGET -DEXP_MSE_SKIP_TILE | tail -1
   python tools/ab_variant.py build:empty1T -DEXP_MSE_EMPTY=1 -DEXP_MSE_SKIP_TARGET | tail -1
   python tools/ab_variant.py build:empty3 -DEXP_MSE_EMPTY=3 | tail -1
+  # the store / wait findings of round 6 (docs/EXPERIMENTS.md S5), each undone on its own and all together
+  python tools/ab_variant.py build:oldwaits -DEXP_MSE_NO_LOAD_FENCE -DEXP_MSE_BG_PROLOGUE -DEXP_NO_RECORD_FENCE -DEXP_MSE_NO_ROTATE | tail -1
+  python tools/ab_variant.py build:bgpro -DEXP_MSE_BG_PROLOGUE | tail -1
+  python tools/ab_variant.py build:nolfence -DEXP_MSE_NO_LOAD_FENCE | tail -1
+  python tools/ab_variant.py build:norot -DEXP_MSE_NO_ROTATE | tail -1
+  python tools/ab_variant.py build:nobgst -DEXP_MSE_NO_BG_STORE | tail -1
   exit 0
 fi
 mkdir -p gpurun_out
