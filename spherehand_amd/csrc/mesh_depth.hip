@@ -69,7 +69,11 @@ struct FaceSetup {
   bool live;
 };
 
-__device__ __forceinline__ FaceSetup face_setup_from(const float (&fv)[9], int src) {
+__device__ __forceinline__ FaceSetup face_setup_from(const float (&fv_)[9], int src) {
+  // (opaque copies: see tri_raster.hip face_setup -- without them the sort's selects become loads from a scratch array)
+  float fv[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) { fv[k] = fv_[k]; asm("" : "+v"(fv[k])); }
   FaceSetup s;
   s.live = false;
   if ((fv[7] - fv[1]) * (fv[3] - fv[0]) < (fv[4] - fv[1]) * (fv[6] - fv[0])) return s;

@@ -45,7 +45,13 @@ struct FaceSetup {
 };
 
 // .cu:25-69 for one face
-__device__ __forceinline__ FaceSetup face_setup(const float f[9], int width, int height) {
+__device__ __forceinline__ FaceSetup face_setup(const float f_[9], int width, int height) {
+  // (opaque copies: the compiler turns the selects of the sort below -- "vertex order[a] of three" -- into ONE load from a
+  // select of addresses, which pins the nine values to a scratch array: 3 scratch stores and 9 dependent scratch loads per
+  // set-up, ScratchSize 48, in every kernel that sets faces up; values that are no longer loads stay in registers)
+  float f[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) { f[k] = f_[k]; asm("" : "+v"(f[k])); }
   FaceSetup s;
   s.live = 1;
   if ((f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0])) s.live = 0;  // :33 back face
