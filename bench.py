@@ -319,6 +319,17 @@ def large_batch(lib, _lib, dev, stream):
         out[str(n)] = {"fwd_us": round(f, 2), "bwd_us": round(b, 2), "fwd_us_per_256": round(f * 256 / n, 3),
                        "bwd_us_per_256": round(b * 256 / n, 3), "fwd_frac": roof(bf, f)["frac"],
                        "bwd_frac": roof(bb, b)["frac"], "crops_per_s_fwd_bwd": round(n / ((f + b) * 1e-6), 1)}
+        # what these launches are bound by: the profiled wave-level VALU instructions of the same launch shapes (forward:
+        # 1024 work-items per crop, backward: 512) against the device's issue rate over the live durations -- beside the HBM
+        # fractions above, which stay the contract's `frac`
+        for tag, kern, grid, us, hfrac in (("fwd", "sphere_zbuf_fwd_kernel<true, ", n * 1024, f, out[str(n)]["fwd_frac"]),
+                                           ("bwd", "sphere_zbuf_bwd_kernel<true, true, false, 8, false, false>", n * 512, b, out[str(n)]["bwd_frac"])):
+            valu, _, src = sq_valu(kern, grid)
+            if valu is not None:
+                vf = round(valu / (VALU_ISSUE_PER_S * us * 1e-6), 4)
+                out[str(n)][tag + "_valu_issue_frac"] = vf
+                out[str(n)][tag + "_bound"] = "valu" if vf > hfrac else "hbm"
+                out[str(n)]["valu_source"] = src
         del sph, depth, owner, grad, gs
     out["1152@256"] = config5_size_kernels(lib, _lib, dev, stream, mesh)
     return out
