@@ -1618,7 +1618,13 @@ sphere_zbuf_mse_body(const float4 *__restrict__ spheres, int N, int J_, int H_, 
   Axis ax = axis_of(W, axk.mulx), ay = axis_of(H, axk.muly);
   const float kx = axk.kx, ky = axk.ky;   // pixels per millimetre (launch constants: common.h AxisK)
   const int wave_s = rfl(wave);
+  // (ONE wave derives the touched box and publishes it: this kernel stores the background rows in its convert pass -- see
+  // there --, so the forward's seven storing waves would each evaluate the box for nothing; EXP_MSE_BG_PROLOGUE brings them back)
+#if defined(EXP_MSE_BG_PROLOGUE) || defined(EXP_MSE_SEVEN_BOXES)
   constexpr int kBgW = BOX ? kBgWavesBox : kBgWaves;
+#else
+  constexpr int kBgW = 1;
+#endif
   const bool bg_wave = wave_s >= 1 && wave_s <= kBgW;
   const bool valid = lane < J;
   const bool pf_wave = wave_s == kZWaves - 1;

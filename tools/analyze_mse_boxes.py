@@ -43,3 +43,39 @@ print("box width percentiles 10/50/75/90/99/max:", np.percentile(bws, [10, 50, 7
 for need_cells in (8504, 9000, 9500, 10000, 10500, 11000):
     fit = sum(1 for b, n in zip(bws, needs) if n * (b + 2) <= need_cells)
     print("  z-buffer of %5d cells: %.1f %% of the boxes fit at pitch bw + 2" % (need_cells, 100.0 * fit / len(bws)))
+
+# What other z-buffer layouts would need (round 6, docs/EXPERIMENTS.md S5): the rows' own extents (per row the hull of the
+# spheres' spans, + 1 pixel of margin, whole 4-pixel pieces, + 2 cells of padding) and two half boxes (the box's rows cut in
+# two at the best row, each half with its own columns).
+k2 = k * k
+tot = over_rows = over_half = 0
+cells_box, cells_rows, cells_half = [], [], []
+left_rows = left_half = 0
+for r in range(S // R):
+    r0, r1 = R * r, R * r + R - 1
+    vv = np.arange(r0, r1 + 1)[None, None, :]                                   # [1, 1, R]
+    yg = (vv - S / 2) / k                                                          # mm (pixel centres; half-pixel conventions are inside the margin)
+    dy = yg - p[:, :, 1:2]
+    hw = np.sqrt(np.maximum(rad[None, :, None] ** 2 - dy * dy, 0.0)) * k           # half width in pixels, 0 where the row misses the sphere
+    hit = (rad[None, :, None] ** 2 - dy * dy) > 0
+    cx = p[:, :, 0:1] * k + S / 2
+    lo = np.where(hit, np.floor(cx - hw) - 1, 1e9).min(1); hi = np.where(hit, np.ceil(cx + hw) + 1, -1e9).max(1)   # [N, R]
+    lo = np.clip(lo, 0, S - 1); hi = np.clip(hi, 0, S - 1)
+    for i in range(p.shape[0]):
+        rows = np.nonzero(hi[i] >= lo[i])[0]
+        if rows.size == 0: continue
+        a = lo[i, rows].astype(int) & ~3; b = (hi[i, rows].astype(int) | 3) + 1
+        w = b - a                                                                   # per-row widths (multiples of 4)
+        n = rows[-1] - rows[0] + 1
+        box_w = b.max() - a.min()
+        tot += 1
+        cells_box.append(n * (box_w + 2)); cells_rows.append(int((w + 2).sum()))
+        if cells_rows[-1] > zc: over_rows += 1
+        best = min(((np.arange(n) < m) * 0).sum() + (m * ((b[:m].max() - a[:m].min()) + 2) if m else 0) + ((n - m) * ((b[m:].max() - a[m:].min()) + 2) if m < n else 0)
+                   for m in range(0, n + 1, 8)) if rows.size == n else n * (box_w + 2)
+        cells_half.append(int(best))
+        if best > zc: over_half += 1
+cb, cr, ch = np.array(cells_box), np.array(cells_rows), np.array(cells_half)
+print("cells needed -- one box (pitch bw + 2): %d of %d regions over %d cells; two half boxes: %d; per-row extents: %d" %
+      (int((cb > zc).sum()), tot, zc, over_half, over_rows))
+print("   per-row / box cell ratio: median %.2f, p90 %.2f; largest per-row need %d cells" % (np.median(cr / cb), np.percentile(cr / cb, 90), cr.max()))
