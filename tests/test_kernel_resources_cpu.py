@@ -12,6 +12,30 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ASM = None
+
+
+def _bodies(text, pattern):
+    """{mangled name: instruction lines} of the kernels whose name matches `pattern`."""
+    lines = text.split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
+    out = {}
+    for n, i in enumerate(starts):
+        name = lines[i].split(":")[0]
+        if re.search(pattern, name):
+            out[name] = lines[i:starts[n + 1] if n + 1 < len(starts) else len(lines)]
+    return out
+
+
+def _compile_asm(unit, tmp):
+    from spherehand_amd import build
+    out = str(tmp / (unit + ".s"))
+    flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call([build.HIPCC] + flags + ["-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"),
+                                                   "-I", os.path.join(build.PKG, "csrc"), "-o", out,
+                                                   os.path.join(build.PKG, "csrc", unit + ".hip")],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
 
 
 @pytest.fixture(scope="module")
@@ -24,6 +48,8 @@ def descriptors(tmp_path_factory):
                                                    os.path.join(build.PKG, "csrc", "sphere_raster.hip")],
                           stderr=subprocess.DEVNULL)
     text = open(out).read()
+    global _ASM
+    _ASM = text
     meta = text[text.index("amdhsa.kernels:"):]
     kernels = {}
     for block in meta.split("  - .agpr_count:")[1:]:
@@ -58,3 +84,39 @@ def test_backward_leaves_its_load_registers_alone(descriptors):
     for name, d in bwd.items():
         assert d["vgpr_count"] <= 114, (name, d)      # 96 for the compiler + v[96:113] named in the asm statements
         assert d["vgpr_spill_count"] == 0, (name, d)
+
+
+def test_no_wave_waits_for_its_own_stores(descriptors):
+    """vmcnt is ONE in-order queue for loads and stores, and the stream stores are asm statements the compiler's wait
+    insertion does not count: a `s_waitcnt vmcnt` behind a store waits for that store (docs/EXPERIMENTS.md S5).
+    Forward, one workgroup per crop: none behind the first store (the records are waited for by every wave in front of
+    it).  Fused box kernel: in the convert pass -- between the second and the third barrier -- every wait sits in front of
+    the pass's first store, except the one directly behind the load of a unit beyond the four requested at the entry."""
+    fwd = {n: b for n, b in _bodies(_ASM, "sphere_zbuf_fwd_kernel").items()
+           if re.findall(r"Lb([01])E", re.search(r"kernelI((?:L[bi]\d+E)+)", n).group(1))[3] == "0"}     # PERSIST = false
+    assert len(fwd) >= 20
+    for name, body in fwd.items():
+        first = next(i for i, l in enumerate(body) if "global_store" in l)
+        late = [l.strip() for l in body[first:] if "vmcnt" in l]
+        assert not late, (name, late)
+    box = _bodies(_ASM, "sphere_zbuf_mse_box_kernel")
+    assert len(box) == 2
+    for name, body in box.items():
+        bars = [i for i, l in enumerate(body) if "s_barrier" in l]
+        conv = body[bars[1]:bars[2]]
+        first = next(i for i, l in enumerate(conv) if "global_store" in l)
+        for i in range(first, len(conv)):
+            if "vmcnt" in conv[i]:
+                assert any("global_load" in l for l in conv[max(0, i - 3):i]), (name, i, conv[i])
+        # ... and the walk that follows starts without one (its first 300 instructions: the slice set-up and the first runs)
+        assert not [l for l in body[bars[2]:bars[2] + 300] if "vmcnt" in l], name
+
+
+@pytest.mark.parametrize("unit", ["tri_raster", "mesh_depth"])
+def test_face_setup_stays_in_registers(unit, tmp_path):
+    """The sort of a face's vertices by x is three selects per coordinate; the compiler once turned them into loads from a
+    select of addresses, which pinned the nine coordinates to a 48-byte scratch array in every kernel that sets faces up
+    (DESIGN.md section 4.4): no kernel of these units uses scratch memory."""
+    text = _compile_asm(unit, tmp_path)
+    sizes = [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)]
+    assert len(sizes) >= 8 and max(sizes) == 0, sizes
