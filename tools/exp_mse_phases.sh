@@ -8,7 +8,8 @@
 #   notile                                       the rows a wide box leaves to the tile code are dropped
 #   oldwaits / bgpro / nolfence / norot / nobgst   round 6's store / wait changes undone (all / background rows stored in the prologue /
 #                                                no wait for the observed image in front of the convert pass / regions in image order);
-#                                                nobgst: the background rows never stored (wrong output: what those stores cost)
+#                                                nobgst: the background rows never stored (wrong output: what those stores cost);
+#                                                box7: seven waves evaluate the touched box, as in the forward, instead of one
 #   noSCWT / noSCWTt / empty1T / empty3          the skeleton without the observed-image loads / and without the tile code / only the
 #                                                prologue up to the first barrier / only the launch
 # Build here (no GPU needed):   bash tools/exp_mse_phases.sh build
@@ -33,6 +34,7 @@ if [ "${1:-}" = "build" ]; then
   python tools/ab_variant.py build:nolfence -DEXP_MSE_NO_LOAD_FENCE | tail -1
   python tools/ab_variant.py build:norot -DEXP_MSE_NO_ROTATE | tail -1
   python tools/ab_variant.py build:nobgst -DEXP_MSE_NO_BG_STORE | tail -1
+  python tools/ab_variant.py build:box7 -DEXP_MSE_SEVEN_BOXES | tail -1
   exit 0
 fi
 mkdir -p gpurun_out
